@@ -1,0 +1,203 @@
+/*
+ * moira_pb.h -- C ABI of libmoira_pb.so: the MI355X (gfx950) Poisson-binomial
+ * read-quality filter.
+ *
+ * This is the drop-in boundary for ONE path of fpusan/moira: what
+ * moira/bernoullimodule.c (the CPython-2 extension `bernoulli`) and
+ * moira.py's per-read dispatch compute today.  Every entry point below names
+ * the reference interface it replaces as `ref: file:line` (paths are relative
+ * to the reference checkout).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Every function returns an int status: MPB_OK (0) or a negative MPB_E_*.
+ *     mpb_last_error() returns a thread-local human-readable message for the
+ *     last failing call on the calling thread.  Nothing throws across the ABI.
+ *   - The caller owns every buffer it passes.  The context owns its device
+ *     workspace, LUTs, stream and events and frees them in mpb_destroy().
+ *   - One context per device; calls on one context must not overlap (one host
+ *     thread per device, as moira's Pool workers were one process per task).
+ *   - There is NO CPU implementation in this library.  If no HIP device is
+ *     usable, mpb_create() fails with MPB_E_NODEVICE; nothing falls back.
+ *
+ * Quality-matrix encoding ("packed qscores"), produced by mpb_pack_read():
+ *   one read = one row of `row_stride` bytes (row_stride % 16 == 0),
+ *   byte k < len :  1..254  Phred score Q (Q==0 was clamped to 1,
+ *                            ref: moira/bernoullimodule.c:104-107, moira/moira.py:814)
+ *                   0        the base is 'N' (ambiguous; skipped by the DP,
+ *                            ref: moira/bernoullimodule.c:196-199)
+ *                   255      the base is 'n' (counted as ambiguous by the C
+ *                            reference, ref: moira/bernoullimodule.c:196, but
+ *                            not by `--ambigs disallow`, ref: moira/moira.py:911)
+ *   byte k >= len:  ignored (the kernels mask it; 0 is conventional).
+ */
+#ifndef MOIRA_PB_H
+#define MOIRA_PB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPB_OK            0
+#define MPB_E_INVALID    -1   /* bad argument (ValueError on the Python side)   */
+#define MPB_E_NODEVICE   -2   /* no usable HIP device / bad device id           */
+#define MPB_E_HIP        -3   /* a HIP runtime call failed (message has detail) */
+#define MPB_E_NOMEM      -4   /* device or host allocation failed               */
+#define MPB_E_RANGE      -5   /* a qscore cannot be encoded (Q < 0 or Q > 254)  */
+
+/* --ambigs modes, ref: moira/moira.py:658-659, :827-828, :911 */
+#define MPB_AMBIG_TREAT_AS_ERRORS 0
+#define MPB_AMBIG_IGNORE          1
+#define MPB_AMBIG_DISALLOW        2
+
+/* flags for mpb_filter_params.flags */
+#define MPB_FLAG_ROUND      1u   /* --round: floor(ee) before the compare, ref: moira/moira.py:830-831 */
+#define MPB_FLAG_FAST_FMA   2u   /* NOT bit-exact: contract a*v+b*w into fma (|rel err| ~1e-13). Off by default. */
+
+/* kernel ids for mpb_kernel_time() */
+#define MPB_K_PREPASS   0   /* lambda/sigma/Ns estimate + row classing        */
+#define MPB_K_SCAN      1   /* class histogram scan / tile table              */
+#define MPB_K_SCATTER   2   /* stable scatter of read indices by class        */
+#define MPB_K_DP        3   /* the Poisson-binomial DP + epilogue (dominant)  */
+#define MPB_K_OVERFLOW  4   /* re-run of reads whose predicted row count was too small */
+#define MPB_K_COUNT     5
+
+typedef struct mpb_ctx mpb_ctx;
+
+/*
+ * Filter parameters = the filter-relevant moira flags.
+ *   alpha      --alpha     (0,1)   ref: moira/moira.py:668,736; moira/bernoullimodule.c:79-83
+ *   uncert     --uncert    (0,1]   ref: moira/moira.py:663-665,949-950
+ *   maxerrors  --maxerrors >0 or NaN when unset (then uncert mode)
+ *                                  ref: moira/moira.py:666,925-926
+ *   ambig_mode --ambigs            ref: moira/moira.py:658,827-828,911
+ *   flags      MPB_FLAG_*
+ */
+typedef struct mpb_filter_params {
+    double   alpha;
+    double   uncert;
+    double   maxerrors;
+    int32_t  ambig_mode;
+    uint32_t flags;
+} mpb_filter_params;
+
+/* Totals of one filter call (what moira prints at moira/moira.py:508-519). */
+typedef struct mpb_filter_counts {
+    int64_t n_reads;
+    int64_t n_pass;
+    int64_t n_fail;
+    int64_t n_overflow;   /* reads that needed the second (wide) pass; diagnostic */
+} mpb_filter_counts;
+
+/* ---- library ------------------------------------------------------------ */
+const char *mpb_version(void);
+const char *mpb_last_error(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int mpb_device_count(void);
+
+/* ---- context ------------------------------------------------------------ */
+/* Creates the per-device context: stream, events, the 256-entry {1-p, p'} LUT
+ * built on the host with libm pow exactly as ref: moira/bernoullimodule.c:202
+ * and :140-145 do, uploaded once. */
+int mpb_create(int device_id, mpb_ctx **out);
+int mpb_destroy(mpb_ctx *ctx);
+/* The HIP stream the context launches on (as void*), for callers that want to
+ * order their own work (e.g. torch) against it. */
+int mpb_stream(mpb_ctx *ctx, void **stream_out);
+int mpb_synchronize(mpb_ctx *ctx);
+
+/* ---- device memory plumbing (so a ctypes-only host needs no torch) -------- */
+int mpb_malloc(mpb_ctx *ctx, int64_t bytes, void **dptr_out);
+int mpb_free(mpb_ctx *ctx, void *dptr);
+int mpb_memcpy_h2d(mpb_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes);
+int mpb_memcpy_d2h(mpb_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes);
+int mpb_memset(mpb_ctx *ctx, void *dst_dev, int value, int64_t bytes);
+
+/* ---- packing (host, integer only) ---------------------------------------- */
+/* Encode one read into a row of the quality matrix.
+ * Replaces the list->int[] marshalling + Q0 clamp of
+ * ref: moira/bernoullimodule.c:92-108 and the N test of :196.
+ * `seq` may be NULL (no ambiguous bases).  Returns MPB_E_RANGE if a score is
+ * negative (the Python reference raises ValueError, ref: moira/moira.py:1603-1604)
+ * or above 254. Bytes [len, row_bytes) are zeroed. */
+int mpb_pack_read(const char *seq, const int32_t *quals, int32_t len,
+                  uint8_t *row_out, int32_t row_bytes);
+/* Same from a raw FASTQ quality string (ASCII, `offset` = --fastq_offset,
+ * ref: moira/moira.py:1177). */
+int mpb_pack_read_ascii(const char *seq, const char *qual_ascii, int32_t len,
+                        int32_t offset, uint8_t *row_out, int32_t row_bytes);
+
+/* ---- the hot path --------------------------------------------------------- */
+/*
+ * Filter a batch that is RESIDENT IN HBM.
+ *   d_q         device, n rows of row_stride bytes (row_stride % 16 == 0, 16-B aligned)
+ *   d_len       device int32[n], or NULL when every read has `fixed_len` bases
+ *   outputs     device: d_ee double[n], d_ns int32[n], d_pass uint8[n]
+ *   counts      host, may be NULL (when non-NULL the call synchronises)
+ * Per read i this computes what
+ *   bernoulli.calculate_errors_PB(seq, quals, alpha)   ref: moira/bernoullimodule.c:66-114,182-263
+ *   + process_data's "ee += Ns" / floor                ref: moira/moira.py:827-831
+ *   + write_results' keep/discard predicate            ref: moira/moira.py:911,925-926,949-950
+ * compute, with the Python semantics where the C reference has undefined
+ * behaviour (first CDF row already above 1-alpha -> ee = 0,
+ * ref: moira/moira.py:1611,1629 vs moira/bernoullimodule.c:254).
+ * d_ee[i] is the value process_data returns (after +Ns / floor).
+ * Asynchronous on the context's stream unless `counts` is given.
+ */
+int mpb_filter_device(mpb_ctx *ctx,
+                      const uint8_t *d_q, int64_t n, int64_t row_stride,
+                      const int32_t *d_len, int32_t fixed_len,
+                      const mpb_filter_params *params,
+                      double *d_ee, int32_t *d_ns, uint8_t *d_pass,
+                      mpb_filter_counts *counts);
+
+/*
+ * Same for a batch in HOST memory: chunks it, overlaps H2D / kernels / D2H on
+ * the context's streams, writes host outputs.  Replaces the per-read
+ * Pool.apply_async dispatch + .get() barrier of ref: moira/moira.py:431-454.
+ */
+int mpb_filter_host(mpb_ctx *ctx,
+                    const uint8_t *q, int64_t n, int64_t row_stride,
+                    const int32_t *len, int32_t fixed_len,
+                    const mpb_filter_params *params,
+                    double *ee, int32_t *ns, uint8_t *pass,
+                    mpb_filter_counts *counts);
+
+/*
+ * One read, the exact signature-level twin of
+ *   bernoulli.calculate_errors_PB(contig, contig_quals, alpha) -> (ee, Ns)
+ * ref: moira/bernoullimodule.c:66-114.  Validates alpha in (0,1) (:79-83),
+ * clamps Q0->1 (:104-107), counts 'N' and 'n' (:196).  `ee` is the raw
+ * percentile (no +Ns, no floor).  Runs the HIP path on a batch of one.
+ */
+int mpb_calculate_errors_PB(mpb_ctx *ctx, const char *contig,
+                            const int32_t *contig_quals, int32_t len,
+                            double alpha, double *ee, int32_t *ns);
+
+/* ---- synthetic workload (BASELINE.json configs; integer-only generator) ---- */
+/* Fill a device quality matrix with the counter-based synthetic model of
+ * include/mpb_synth.h (identical integers on host and device).
+ * fixed_len > 0: every read has fixed_len bases, d_len may be NULL.
+ * fixed_len == 0: ragged, lengths drawn in [min_len, max_len] and written to d_len. */
+int mpb_synth_fill_device(mpb_ctx *ctx, uint8_t *d_q, int64_t n, int64_t row_stride,
+                          int32_t fixed_len, int32_t min_len, int32_t max_len,
+                          int32_t *d_len, uint64_t seed, int64_t first_read);
+
+/* ---- measurement ----------------------------------------------------------- */
+/* When enabled, every launch of kernel `MPB_K_*` is bracketed by HIP events on
+ * the context's stream; mpb_kernel_time() returns accumulated milliseconds and
+ * the number of launches since the last reset (it synchronises the stream). */
+int mpb_timing_enable(mpb_ctx *ctx, int on);
+int mpb_timing_reset(mpb_ctx *ctx);
+int mpb_kernel_time(mpb_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+/* Histogram of the DP row-budget classes of the last mpb_filter_device call:
+ * caps[i] = rows (J_cap) of class i, counts[i] = reads in it.  Returns the
+ * number of classes written (<= max_classes).  Synchronises. */
+int mpb_last_class_histogram(mpb_ctx *ctx, int32_t *caps, int64_t *counts, int32_t max_classes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOIRA_PB_H */

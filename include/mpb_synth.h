@@ -1,0 +1,69 @@
+/*
+ * mpb_synth.h -- counter-based synthetic read-quality model.
+ *
+ * The reference ships no generator; BASELINE.json's configs are "synthetic
+ * 300 bp qscore arrays", so the model is defined here, once, integer-only, and
+ * compiled unchanged into the HIP library (device fill kernel), the oracle
+ * (host fill) and nothing else -- host and device produce identical bytes.
+ *
+ * Per read:  h  = mix64(seed, read);   r16 = 16-bit "quality class" draw
+ * Per base:  t  = pos/len in Q10,  cube = t^3 in Q10
+ *            drop  = floor((4 + 30*r) * cube)            (r = r16/65536)
+ *            noise = uniform {0..5}
+ *            Q     = clamp(38 - drop - noise, 2, 40)
+ *            with probability 66/65536 (~0.1 %) the base is 'N' (byte 0)
+ * Output byte uses the packed-qscore encoding of moira_pb.h.
+ */
+#ifndef MPB_SYNTH_H
+#define MPB_SYNTH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MPB_HD __host__ __device__ inline
+#else
+#define MPB_HD static inline
+#endif
+
+#define MPB_SYNTH_N_THRESH 66u      /* of 65536: ~0.1 % ambiguous bases */
+
+MPB_HD uint64_t mpb_mix64(uint64_t x)
+{
+    /* splitmix64 finaliser */
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+MPB_HD uint64_t mpb_synth_read_hash(uint64_t seed, uint64_t read)
+{
+    return mpb_mix64(mpb_mix64(seed) ^ (read * 0xD1342543DE82EF95ull));
+}
+
+/* length of read `read` for the ragged configs: uniform in [min_len, max_len] */
+MPB_HD int32_t mpb_synth_len(uint64_t hread, int32_t min_len, int32_t max_len)
+{
+    uint64_t span = (uint64_t)(max_len - min_len + 1);
+    uint64_t u = (mpb_mix64(hread ^ 0xA5A5A5A5A5A5A5A5ull) >> 32) * span >> 32;
+    return min_len + (int32_t)u;
+}
+
+/* packed byte of base `pos` of a read of `len` bases */
+MPB_HD uint8_t mpb_synth_byte(uint64_t hread, uint32_t pos, uint32_t len)
+{
+    uint32_t r16 = (uint32_t)(hread & 0xFFFFu);
+    uint64_t slope = (4ull << 16) + 30ull * r16;            /* Q16: 4 .. 34 */
+    uint64_t t = ((uint64_t)pos << 10) / len;               /* Q10: 0 .. 1023 */
+    uint64_t cube = (t * t * t) >> 20;                      /* Q10 */
+    int32_t drop = (int32_t)((slope * cube) >> 26);
+    uint64_t h = mpb_mix64(hread + 0x632BE59BD9B4E019ull * (uint64_t)(pos + 1));
+    int32_t noise = (int32_t)(((h & 0xFFFFu) * 6u) >> 16);
+    uint32_t nflag = (uint32_t)((h >> 16) & 0xFFFFu);
+    int32_t q = 38 - drop - noise;
+    if (q < 2) q = 2;
+    if (q > 40) q = 40;
+    return nflag < MPB_SYNTH_N_THRESH ? (uint8_t)0 : (uint8_t)q;
+}
+
+#endif /* MPB_SYNTH_H */
