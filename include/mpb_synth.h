@@ -6,9 +6,14 @@
  * compiled unchanged into the HIP library (device fill kernel), the oracle
  * (host fill) and nothing else -- host and device produce identical bytes.
  *
- * Per read:  h  = mix64(seed, read);   r16 = 16-bit "quality class" draw
- * Per base:  t  = pos/len in Q10,  cube = t^3 in Q10
- *            drop  = floor((4 + 30*r) * cube)            (r = r16/65536)
+ * Per read:  h  = mix64(seed, read);   r16 = 16-bit "quality class" draw,
+ *            c16 = second 16-bit draw: c16 < MPB_SYNTH_DEGRADED (12 %) marks a
+ *            "degraded" read whose quality falls linearly instead of cubically
+ *            (the heavy tail real runs show: moira/test/test1.fastq needs up to
+ *            135 DP rows, 2.6 % of its reads more than 64)
+ * Per base:  t  = pos/len in Q10,  shape = t^3 (normal) or t (degraded) in Q10
+ *            drop  = floor(slope * shape),  slope = 4 + 30*r (normal),
+ *                                                   16 + 32*r (degraded), r = r16/65536
  *            noise = uniform {0..5}
  *            Q     = clamp(38 - drop - noise, 2, 40)
  *            with probability 66/65536 (~0.1 %) the base is 'N' (byte 0)
@@ -26,6 +31,7 @@
 #endif
 
 #define MPB_SYNTH_N_THRESH 66u      /* of 65536: ~0.1 % ambiguous bases */
+#define MPB_SYNTH_DEGRADED 7864u    /* of 65536: 12 % degraded reads */
 
 MPB_HD uint64_t mpb_mix64(uint64_t x)
 {
@@ -53,10 +59,12 @@ MPB_HD int32_t mpb_synth_len(uint64_t hread, int32_t min_len, int32_t max_len)
 MPB_HD uint8_t mpb_synth_byte(uint64_t hread, uint32_t pos, uint32_t len)
 {
     uint32_t r16 = (uint32_t)(hread & 0xFFFFu);
-    uint64_t slope = (4ull << 16) + 30ull * r16;            /* Q16: 4 .. 34 */
+    uint32_t c16 = (uint32_t)((hread >> 16) & 0xFFFFu);
+    int degraded = c16 < MPB_SYNTH_DEGRADED;
+    uint64_t slope = degraded ? (16ull << 16) + 32ull * r16 : (4ull << 16) + 30ull * r16;   /* Q16 */
     uint64_t t = ((uint64_t)pos << 10) / len;               /* Q10: 0 .. 1023 */
-    uint64_t cube = (t * t * t) >> 20;                      /* Q10 */
-    int32_t drop = (int32_t)((slope * cube) >> 26);
+    uint64_t shape = degraded ? t : (t * t * t) >> 20;      /* Q10 */
+    int32_t drop = (int32_t)((slope * shape) >> 26);
     uint64_t h = mpb_mix64(hread + 0x632BE59BD9B4E019ull * (uint64_t)(pos + 1));
     int32_t noise = (int32_t)(((h & 0xFFFFu) * 6u) >> 16);
     uint32_t nflag = (uint32_t)((h >> 16) & 0xFFFFu);
