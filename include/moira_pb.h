@@ -55,6 +55,8 @@ extern "C" {
 /* flags for mpb_filter_params.flags */
 #define MPB_FLAG_ROUND      1u   /* --round: floor(ee) before the compare, ref: moira/moira.py:830-831 */
 #define MPB_FLAG_FAST_FMA   2u   /* NOT bit-exact: contract a*v+b*w into fma (|rel err| ~1e-13). Off by default. */
+#define MPB_FLAG_TEST_UNDERPREDICT 4u /* test hook: halve every predicted row budget so that the
+                                         overflow (second) pass is exercised; results are unchanged */
 
 /* kernel ids for mpb_kernel_time() */
 #define MPB_K_PREPASS   0   /* lambda/sigma/Ns estimate + row classing        */

@@ -1,0 +1,547 @@
+// mpb_api.cpp -- the C ABI of libmoira_pb.so (declared in include/moira_pb.h).
+//
+// Host side of the path: context (device, stream, LUT, workspace), argument validation with
+// the reference's error behaviour (moira/bernoullimodule.c:79-90), packing
+// (moira/bernoullimodule.c:92-108,196), and the launch sequence of mpb_kernels.hip.
+// There is no CPU compute path in this file: every result comes from the HIP kernels.
+
+#include "../../include/moira_pb.h"
+#include "mpb_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#define MPB_VERSION_STR "moira_pb 0.1.0 (gfx950)"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? MPB_E_NOMEM : MPB_E_HIP, "%s failed: %s", \
+                        #expr, hipGetErrorString(e_));                                        \
+    } while (0)
+
+struct TimedSpan { int kid; hipEvent_t a, b; };
+
+struct mpb_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;
+    double2 *d_lut = nullptr;
+    // workspace, grown on demand
+    int64_t ws_cap = 0;
+    MpbWorkspace ws{};
+    void *ws_block = nullptr;
+    void *ws_small = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    double acc_ms[MPB_K_COUNT] = {0};
+    int64_t acc_n[MPB_K_COUNT] = {0};
+    // single-read scratch (device) + host staging for filter_host
+    void *one_dev = nullptr;
+    int64_t one_cap = 0;
+    void *stage_dev = nullptr;
+    int64_t stage_cap = 0;
+};
+
+extern "C" {
+
+const char *mpb_version(void) { return MPB_VERSION_STR; }
+const char *mpb_last_error(void) { return g_err; }
+
+int mpb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// {1-p, p'} exactly as the reference evaluates them (ref: moira/bernoullimodule.c:202,140-145):
+//   p  = pow(10, q / -10.0)
+//   a  = prob_j_errors(p, 0, 1) = pow(1 - p, 1)
+//   b  = prob_j_errors(p, 1, 1) = ((1-1+1)/(1.0*1)) * (p/(1-p)) * pow(1 - p, 1)
+// evaluated on the host with libm (this TU is built with -ffp-contract=off).  Bytes 0 ('N')
+// and 255 ('n') are the identity step of the DP: skipping a base == multiplying by {1, 0}.
+static void build_lut(double2 *lut)
+{
+    for (int q = 0; q < 256; q++) {
+        if (q == 0 || q == 255) { lut[q].x = 1.0; lut[q].y = 0.0; continue; }
+        volatile double p = pow(10, (q / -10.0));
+        volatile double a = pow((1 - p), 1);
+        volatile double r = p / (1 - p);
+        volatile double b1 = ((1 - 1 + 1) / (1.0 * 1)) * r;
+        volatile double b = b1 * a;
+        lut[q].x = a;
+        lut[q].y = b;
+    }
+}
+
+int mpb_create(int device_id, mpb_ctx **out)
+{
+    if (!out) return fail(MPB_E_INVALID, "mpb_create: out is NULL");
+    *out = nullptr;
+    int n = mpb_device_count();
+    if (n <= 0) return fail(MPB_E_NODEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device_id < 0 || device_id >= n)
+        return fail(MPB_E_NODEVICE, "device %d out of range (0..%d)", device_id, n - 1);
+    HIPCHK(hipSetDevice(device_id));
+    mpb_ctx *c = new (std::nothrow) mpb_ctx();
+    if (!c) return fail(MPB_E_NOMEM, "host allocation failed");
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 256 * sizeof(double2));
+    if (e == hipSuccess) {
+        double2 h[256];
+        build_lut(h);
+        e = hipMemcpy(c->d_lut, h, sizeof(h), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        int rc = fail(MPB_E_HIP, "context setup failed: %s", hipGetErrorString(e));
+        mpb_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return MPB_OK;
+}
+
+int mpb_destroy(mpb_ctx *c)
+{
+    if (!c) return MPB_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
+    if (c->ws_block) (void)hipFree(c->ws_block);
+    if (c->ws_small) (void)hipFree(c->ws_small);
+    if (c->one_dev) (void)hipFree(c->one_dev);
+    if (c->stage_dev) (void)hipFree(c->stage_dev);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+    return MPB_OK;
+}
+
+#define CTXCHK(c)                                                     \
+    do {                                                              \
+        if (!(c)) return fail(MPB_E_INVALID, "%s: ctx is NULL", __func__); \
+        HIPCHK(hipSetDevice((c)->device));                            \
+    } while (0)
+
+int mpb_stream(mpb_ctx *c, void **stream_out)
+{
+    CTXCHK(c);
+    if (!stream_out) return fail(MPB_E_INVALID, "stream_out is NULL");
+    *stream_out = (void *)c->stream;
+    return MPB_OK;
+}
+
+int mpb_synchronize(mpb_ctx *c)
+{
+    CTXCHK(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MPB_OK;
+}
+
+int mpb_malloc(mpb_ctx *c, int64_t bytes, void **dptr_out)
+{
+    CTXCHK(c);
+    if (!dptr_out || bytes < 0) return fail(MPB_E_INVALID, "mpb_malloc: bad arguments");
+    *dptr_out = nullptr;
+    HIPCHK(hipMalloc(dptr_out, bytes > 0 ? (size_t)bytes : 16));
+    return MPB_OK;
+}
+
+int mpb_free(mpb_ctx *c, void *dptr)
+{
+    CTXCHK(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (dptr) HIPCHK(hipFree(dptr));
+    return MPB_OK;
+}
+
+int mpb_memcpy_h2d(mpb_ctx *c, void *dst, const void *src, int64_t bytes)
+{
+    CTXCHK(c);
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(MPB_E_INVALID, "mpb_memcpy_h2d: bad arguments");
+    if (bytes == 0) return MPB_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MPB_OK;
+}
+
+int mpb_memcpy_d2h(mpb_ctx *c, void *dst, const void *src, int64_t bytes)
+{
+    CTXCHK(c);
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(MPB_E_INVALID, "mpb_memcpy_d2h: bad arguments");
+    if (bytes == 0) return MPB_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MPB_OK;
+}
+
+int mpb_memset(mpb_ctx *c, void *dst, int value, int64_t bytes)
+{
+    CTXCHK(c);
+    if (bytes < 0 || (bytes > 0 && !dst)) return fail(MPB_E_INVALID, "mpb_memset: bad arguments");
+    if (bytes == 0) return MPB_OK;
+    HIPCHK(hipMemsetAsync(dst, value, (size_t)bytes, c->stream));
+    return MPB_OK;
+}
+
+// ---- packing ---------------------------------------------------------------------------------
+
+static inline uint8_t pack_one(char base, int q)
+{
+    if (q == 0) q = 1;                       // ref: bernoullimodule.c:104-107
+    if (base == 'N') return 0;               // ref: bernoullimodule.c:196 (78)
+    if (base == 'n') return 255;             // ref: bernoullimodule.c:196 (110)
+    return (uint8_t)q;
+}
+
+int mpb_pack_read(const char *seq, const int32_t *quals, int32_t len, uint8_t *row_out, int32_t row_bytes)
+{
+    if (len < 0 || !row_out || (len > 0 && !quals)) return fail(MPB_E_INVALID, "mpb_pack_read: bad arguments");
+    if (len > row_bytes) return fail(MPB_E_INVALID, "read of %d bases does not fit a %d-byte row", len, row_bytes);
+    for (int i = 0; i < len; i++) {
+        const int q = quals[i];
+        if (q < 0) return fail(MPB_E_RANGE, "Qualities must have positive values.");
+        if (q > 254) return fail(MPB_E_RANGE, "quality %d at base %d exceeds the encodable maximum 254", q, i);
+        row_out[i] = pack_one(seq ? seq[i] : 'A', q);
+    }
+    memset(row_out + len, 0, (size_t)(row_bytes - len));
+    return MPB_OK;
+}
+
+int mpb_pack_read_ascii(const char *seq, const char *qual_ascii, int32_t len, int32_t offset,
+                        uint8_t *row_out, int32_t row_bytes)
+{
+    if (len < 0 || !row_out || (len > 0 && !qual_ascii)) return fail(MPB_E_INVALID, "mpb_pack_read_ascii: bad arguments");
+    if (len > row_bytes) return fail(MPB_E_INVALID, "read of %d bases does not fit a %d-byte row", len, row_bytes);
+    for (int i = 0; i < len; i++) {
+        const int q = (int)(unsigned char)qual_ascii[i] - offset;     // ref: moira.py:1177
+        if (q < 0) return fail(MPB_E_RANGE, "Qualities must have positive values.");
+        if (q > 254) return fail(MPB_E_RANGE, "quality %d at base %d exceeds the encodable maximum 254", q, i);
+        row_out[i] = pack_one(seq ? seq[i] : 'A', q);
+    }
+    memset(row_out + len, 0, (size_t)(row_bytes - len));
+    return MPB_OK;
+}
+
+// ---- workspace ---------------------------------------------------------------------------------
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+static int ensure_workspace(mpb_ctx *c, int64_t n)
+{
+    if (!c->ws_small) {
+        // tables (2), overflow counter, pass counter
+        const size_t bytes = 2 * align_up(sizeof(MpbTables), 256) + 512 + 2 * MPB_DPARGS_SLOT;
+        HIPCHK(hipMalloc(&c->ws_small, bytes));
+        HIPCHK(hipMemset(c->ws_small, 0, bytes));
+        char *p = (char *)c->ws_small;
+        c->ws.tables = (MpbTables *)p;
+        c->ws.tables2 = (MpbTables *)(p + align_up(sizeof(MpbTables), 256));
+        c->ws.ovf_count = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256));
+        c->ws.pass_count = (unsigned long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 256);
+        c->ws.dp_args = p + 2 * align_up(sizeof(MpbTables), 256) + 512;
+        c->ws.lut = c->d_lut;
+    }
+    if (n <= c->ws_cap) return MPB_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->ws_block) { HIPCHK(hipFree(c->ws_block)); c->ws_block = nullptr; c->ws_cap = 0; }
+    const int64_t cap = n + n / 8 + 1024;
+    const int64_t nb = (cap + MPB_PRE_READS - 1) / MPB_PRE_READS;
+    const int64_t b_cls = align_up(cap, 256);
+    const int64_t b_perm = align_up((cap + (int64_t)MPB_NCLS * 64) * 4, 256);
+    const int64_t b_hist = align_up(nb * MPB_NCLS * 4, 256);
+    const int64_t b_ovf = align_up(cap * 4, 256);
+    HIPCHK(hipMalloc(&c->ws_block, (size_t)(b_cls + b_perm + b_hist + b_ovf)));
+    char *p = (char *)c->ws_block;
+    c->ws.cls = (uint8_t *)p; p += b_cls;
+    c->ws.perm = (int32_t *)p; p += b_perm;
+    c->ws.blockhist = (int32_t *)p; p += b_hist;
+    c->ws.ovf_list = (int32_t *)p;
+    c->ws_cap = cap;
+    return MPB_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+
+static hipEvent_t get_event(mpb_ctx *c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Span {
+    mpb_ctx *c; int kid; hipEvent_t a = nullptr, b = nullptr;
+    Span(mpb_ctx *c_, int kid_) : c(c_), kid(kid_)
+    {
+        if (c->timing) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~Span()
+    {
+        if (c->timing) { (void)hipEventRecord(b, c->stream); c->spans.push_back({kid, a, b}); }
+    }
+};
+
+static int resolve_spans(mpb_ctx *c)
+{
+    if (c->spans.empty()) return MPB_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &s : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->acc_ms[s.kid] += ms; c->acc_n[s.kid] += 1; }
+        c->event_pool.push_back(s.a);
+        c->event_pool.push_back(s.b);
+    }
+    c->spans.clear();
+    return MPB_OK;
+}
+
+int mpb_timing_enable(mpb_ctx *c, int on) { CTXCHK(c); c->timing = on != 0; return MPB_OK; }
+
+int mpb_timing_reset(mpb_ctx *c)
+{
+    CTXCHK(c);
+    int rc = resolve_spans(c);
+    if (rc) return rc;
+    for (int k = 0; k < MPB_K_COUNT; k++) { c->acc_ms[k] = 0; c->acc_n[k] = 0; }
+    return MPB_OK;
+}
+
+int mpb_kernel_time(mpb_ctx *c, int kid, double *total_ms, int64_t *launches)
+{
+    CTXCHK(c);
+    if (kid < 0 || kid >= MPB_K_COUNT) return fail(MPB_E_INVALID, "kernel id %d out of range", kid);
+    int rc = resolve_spans(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->acc_ms[kid];
+    if (launches) *launches = c->acc_n[kid];
+    return MPB_OK;
+}
+
+// ---- the hot path --------------------------------------------------------------------------------
+
+// Phi^-1 (Acklam's rational approximation, |rel err| < 1.2e-9): only steers the row-budget
+// prediction, never a result.
+static double inv_norm_cdf(double p)
+{
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                               1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                               6.680131188771972e+01, -1.328068155288572e+01};
+    static const double cc[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                                -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00,
+                               3.754408661907416e+00};
+    const double pl = 0.02425;
+    if (p < pl) {
+        double q = sqrt(-2 * log(p));
+        return (((((cc[0] * q + cc[1]) * q + cc[2]) * q + cc[3]) * q + cc[4]) * q + cc[5]) /
+               ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+    }
+    if (p > 1 - pl) {
+        double q = sqrt(-2 * log(1 - p));
+        return -(((((cc[0] * q + cc[1]) * q + cc[2]) * q + cc[3]) * q + cc[4]) * q + cc[5]) /
+               ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+    }
+    double q = p - 0.5, r = q * q;
+    return (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+           (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1);
+}
+
+static int check_params(const mpb_filter_params *p)
+{
+    if (!p) return fail(MPB_E_INVALID, "params is NULL");
+    if (!(p->alpha > 0 && p->alpha < 1))                       // ref: bernoullimodule.c:79-83
+        return fail(MPB_E_INVALID, "Alpha must be between 0 and 1");
+    if (p->ambig_mode < 0 || p->ambig_mode > 2) return fail(MPB_E_INVALID, "unknown ambig_mode %d", p->ambig_mode);
+    const bool has_me = p->maxerrors == p->maxerrors;
+    if (has_me && !(p->maxerrors > 0)) return fail(MPB_E_INVALID, "maxerrors must be > 0");           // moira.py:732
+    if (!has_me && !(p->uncert > 0 && p->uncert <= 1)) return fail(MPB_E_INVALID, "uncert must be in (0,1]");  // moira.py:728
+    return MPB_OK;
+}
+
+static MpbDevParams make_dev_params(const mpb_filter_params *p, int32_t fixed_len, int32_t max_len)
+{
+    MpbDevParams d;
+    d.thr = 1 - p->alpha;                     // same double expression as the reference
+    d.uncert = p->uncert;
+    d.maxerrors = p->maxerrors;
+    const double z = inv_norm_cdf(1 - p->alpha);
+    d.z = (float)z;
+    d.zq = (float)((z * z - 1) / 6);
+    d.ambig_mode = p->ambig_mode;
+    d.flags = p->flags;
+    d.fixed_len = fixed_len;
+    d.max_len = max_len;
+    return d;
+}
+
+int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride,
+                      const int32_t *d_len, int32_t fixed_len, const mpb_filter_params *params,
+                      double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
+{
+    CTXCHK(c);
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (n < 0) return fail(MPB_E_INVALID, "n < 0");
+    if (n > 0x7fffffffll - 4096) return fail(MPB_E_INVALID, "batch of %lld reads exceeds 2^31; split it", (long long)n);
+    if (row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "row_stride must be a positive multiple of 16");
+    if (((uintptr_t)d_q & 15) != 0) return fail(MPB_E_INVALID, "quality matrix must be 16-byte aligned");
+    if (!d_len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len %d does not fit row_stride %lld", fixed_len, (long long)row_stride);
+    const int32_t max_len = d_len ? (int32_t)(row_stride < MPB_MAX_LEN ? row_stride : MPB_MAX_LEN) : fixed_len;
+    if (max_len > MPB_MAX_LEN || (d_len && row_stride > MPB_MAX_LEN + 1))
+        return fail(MPB_E_INVALID, "reads longer than %d bases are not supported", MPB_MAX_LEN);
+    if (n > 0 && (!d_q || !d_ee || !d_ns || !d_pass)) return fail(MPB_E_INVALID, "NULL device buffer");
+    if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
+    if (n == 0) return MPB_OK;
+    rc = ensure_workspace(c, n);
+    if (rc) return rc;
+    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
+    hipStream_t s = c->stream;
+    { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, s); }
+    { Span t(c, MPB_K_SCAN);     mpb_launch_scan(n, c->ws, s); }
+    { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, c->ws, s); }
+    { Span t(c, MPB_K_DP);       mpb_launch_dp(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
+    { Span t(c, MPB_K_OVERFLOW); mpb_launch_overflow(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
+    HIPCHK(hipGetLastError());
+    if (counts) {
+        mpb_launch_count(d_pass, n, c->ws, s);
+        unsigned long long np = 0;
+        int32_t novf = 0;
+        HIPCHK(hipMemcpyAsync(&np, c->ws.pass_count, sizeof(np), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&novf, c->ws.ovf_count, sizeof(novf), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        counts->n_pass = (int64_t)np;
+        counts->n_fail = n - (int64_t)np;
+        counts->n_overflow = novf;
+    }
+    return MPB_OK;
+}
+
+int mpb_last_class_histogram(mpb_ctx *c, int32_t *caps, int64_t *cnts, int32_t max_classes)
+{
+    CTXCHK(c);
+    if (!caps || !cnts || max_classes < 0) return fail(MPB_E_INVALID, "bad arguments");
+    if (!c->ws.tables) return 0;
+    static const MpbClass classes[MPB_NCLS] = MPB_CLASS_TABLE;
+    MpbTables h;
+    HIPCHK(hipMemcpyAsync(&h, c->ws.tables, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int k = 0;
+    for (; k < MPB_NCLS && k < max_classes; k++) { caps[k] = classes[k].cap; cnts[k] = h.count[k]; }
+    return k;
+}
+
+static int ensure_stage(mpb_ctx *c, int64_t bytes)
+{
+    if (bytes <= c->stage_cap) return MPB_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->stage_dev) { HIPCHK(hipFree(c->stage_dev)); c->stage_dev = nullptr; c->stage_cap = 0; }
+    HIPCHK(hipMalloc(&c->stage_dev, (size_t)bytes));
+    c->stage_cap = bytes;
+    return MPB_OK;
+}
+
+int mpb_filter_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
+                    int32_t fixed_len, const mpb_filter_params *params, double *ee, int32_t *ns,
+                    uint8_t *pass, mpb_filter_counts *counts)
+{
+    CTXCHK(c);
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (n < 0) return fail(MPB_E_INVALID, "n < 0");
+    if (row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "row_stride must be a positive multiple of 16");
+    if (n > 0 && (!q || !ee || !ns || !pass)) return fail(MPB_E_INVALID, "NULL host buffer");
+    mpb_filter_counts total = {n, 0, 0, 0};
+    // chunk so that the staging area stays bounded (<= ~1 GiB of qualities per chunk)
+    int64_t chunk = (int64_t)(1ll << 30) / row_stride;
+    if (chunk < 1024) chunk = 1024;
+    if (chunk > n) chunk = n;
+    if (n > 0) {
+        const int64_t per_read = row_stride + 4 + 8 + 4 + 1;
+        rc = ensure_stage(c, align_up(chunk * per_read + 8 * 256, 256));
+        if (rc) return rc;
+    }
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = (n - off < chunk) ? n - off : chunk;
+        char *p = (char *)c->stage_dev;
+        uint8_t *d_q = (uint8_t *)p;   p += align_up(m * row_stride, 256);
+        double *d_ee = (double *)p;    p += align_up(m * 8, 256);
+        int32_t *d_len = (int32_t *)p; p += align_up(m * 4, 256);
+        int32_t *d_ns = (int32_t *)p;  p += align_up(m * 4, 256);
+        uint8_t *d_pass = (uint8_t *)p;
+        HIPCHK(hipMemcpyAsync(d_q, q + off * row_stride, (size_t)(m * row_stride), hipMemcpyHostToDevice, c->stream));
+        if (len) HIPCHK(hipMemcpyAsync(d_len, len + off, (size_t)(m * 4), hipMemcpyHostToDevice, c->stream));
+        mpb_filter_counts cc;
+        rc = mpb_filter_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, params, d_ee, d_ns, d_pass, &cc);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ee + off, d_ee, (size_t)(m * 8), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(ns + off, d_ns, (size_t)(m * 4), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(pass + off, d_pass, (size_t)m, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        total.n_pass += cc.n_pass; total.n_fail += cc.n_fail; total.n_overflow += cc.n_overflow;
+    }
+    if (counts) *counts = total;
+    return MPB_OK;
+}
+
+int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *contig_quals, int32_t len,
+                            double alpha, double *ee, int32_t *ns)
+{
+    CTXCHK(c);
+    if (!ee || !ns) return fail(MPB_E_INVALID, "NULL output");
+    if (!(alpha > 0 && alpha < 1)) return fail(MPB_E_INVALID, "Alpha must be between 0 and 1");   // bernoullimodule.c:79-83
+    if (len < 0 || (len > 0 && !contig_quals)) return fail(MPB_E_INVALID, "bad arguments");
+    if (contig && (int32_t)strlen(contig) != len)                                               // bernoullimodule.c:85-90
+        return fail(MPB_E_INVALID, "contig and contig_quals must have the same length");
+    if (len > MPB_MAX_LEN) return fail(MPB_E_INVALID, "reads longer than %d bases are not supported", MPB_MAX_LEN);
+    const int32_t stride = (int32_t)align_up(len > 0 ? len : 1, 16);
+    std::vector<uint8_t> row((size_t)stride);
+    int rc = mpb_pack_read(contig, contig_quals, len, row.data(), stride);
+    if (rc) return rc;
+    mpb_filter_params prm;
+    prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
+    uint8_t pass = 0;
+    return mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
+}
+
+int mpb_synth_fill_device(mpb_ctx *c, uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,
+                          int32_t min_len, int32_t max_len, int32_t *d_len, uint64_t seed, int64_t first_read)
+{
+    CTXCHK(c);
+    if (n < 0 || row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "bad matrix shape");
+    if (fixed_len > 0) { if (fixed_len > row_stride) return fail(MPB_E_INVALID, "fixed_len exceeds row_stride"); }
+    else if (min_len < 1 || max_len < min_len || max_len > row_stride || !d_len)
+        return fail(MPB_E_INVALID, "ragged fill needs 1 <= min_len <= max_len <= row_stride and d_len");
+    if (n == 0) return MPB_OK;
+    if (n * (row_stride / 16) / 256 > 0x7fffffffll) return fail(MPB_E_INVALID, "fill too large for one launch; split it");
+    mpb_launch_synth(d_q, n, row_stride, fixed_len, min_len, max_len, d_len, seed, first_read, c->stream);
+    HIPCHK(hipGetLastError());
+    return MPB_OK;
+}
+
+}  // extern "C"

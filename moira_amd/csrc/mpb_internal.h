@@ -1,0 +1,82 @@
+// mpb_internal.h -- shared between the C-ABI layer (mpb_api.cpp) and the gfx950 kernels
+// (mpb_kernels.hip).  Not installed; the public surface is include/moira_pb.h.
+#ifndef MPB_INTERNAL_H
+#define MPB_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- DP row-budget classes -------------------------------------------------------------
+// A read predicted to need J rows of the DP table goes to the smallest class with
+// cap >= J.  cap = G * R: G lanes cooperate on one read, each keeps R consecutive rows of the
+// running probability vector in registers.  G == 1 is one read per lane.  R <= 16 everywhere so
+// the whole kernel fits a small VGPR budget (many waves per SIMD hide the LUT-read latency).
+#define MPB_NCLS 25
+#define MPB_MAX_LEN 1023          // cap of the widest class is 1024 = max_len + 1 rows
+
+struct MpbClass { int cap, G, R; };
+
+#define MPB_CLASS_TABLE                                                                     \
+    { {2,1,2},{3,1,3},{4,1,4},{5,1,5},{6,1,6},{7,1,7},{8,1,8},{9,1,9},{10,1,10},            \
+      {12,1,12},{14,1,14},{16,1,16},{20,2,10},{24,2,12},{32,2,16},                          \
+      {48,4,12},{64,4,16},{96,8,12},{128,8,16},{192,16,12},{256,16,16},                     \
+      {384,32,12},{512,32,16},{768,64,12},{1024,64,16} }
+
+// reads handled by one prepass / scatter block (one thread per read in the ranking step)
+#define MPB_PRE_READS 256
+
+// Device-side tables produced by the scan kernel, consumed by scatter and DP kernels.
+struct MpbTables {
+    int32_t count[MPB_NCLS];          // reads per class
+    int32_t perm_base[MPB_NCLS + 1];  // first slot of the class in perm[]
+    int32_t tile_start[MPB_NCLS + 1]; // first tile of the class (tiles ordered widest class first)
+    int32_t total_tiles;
+    int32_t pad;
+};
+
+struct MpbDevParams {
+    double thr;            // 1 - alpha, computed on the host in double (ref: bernoullimodule.c:244)
+    double uncert;
+    double maxerrors;      // NaN when unset
+    float  z;              // Phi^-1(1 - alpha), prediction only
+    float  zq;             // (z*z - 1) / 6,     prediction only
+    int32_t ambig_mode;
+    uint32_t flags;
+    int32_t fixed_len;     // used when d_len == nullptr
+    int32_t max_len;       // upper bound of every length in the batch (<= row_stride)
+};
+
+struct MpbWorkspace {
+    uint8_t  *cls;         // [n]   class id | 0x80 if the read has an upper-case N
+    int32_t  *perm;        // [n + MPB_NCLS*64] read indices grouped by class
+    int32_t  *blockhist;   // [nblocks_pre][MPB_NCLS]
+    MpbTables *tables;     // main pass
+    MpbTables *tables2;    // overflow pass
+    int32_t  *ovf_list;    // [n]
+    int32_t  *ovf_count;   // [1]
+    unsigned long long *pass_count;  // [1]
+    const double2 *lut;    // [256] {1-p, p'} on device
+    char *dp_args;         // 2 slots of MPB_DPARGS_SLOT bytes: kernel arguments of the DP passes
+};
+
+#define MPB_DPARGS_SLOT 256
+#define MPB_LUT_BYTES   (256 * 16)
+
+// Launch wrappers (mpb_kernels.hip).  All asynchronous on `s`.
+void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
+                        const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
+                        hipStream_t s);
+void mpb_launch_scan(int64_t n, const MpbWorkspace &ws, hipStream_t s);
+void mpb_launch_scatter(int64_t n, const MpbWorkspace &ws, hipStream_t s);
+void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
+                   const MpbDevParams &prm, const MpbWorkspace &ws, const int32_t *ns,
+                   double *ee, uint8_t *pass, hipStream_t s);
+void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
+                         const MpbDevParams &prm, const MpbWorkspace &ws, const int32_t *ns,
+                         double *ee, uint8_t *pass, hipStream_t s);
+void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hipStream_t s);
+void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, int32_t min_len,
+                      int32_t max_len, int32_t *len, uint64_t seed, int64_t first_read,
+                      hipStream_t s);
+
+#endif

@@ -1,0 +1,553 @@
+// mpb_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the Poisson-binomial read filter.
+//
+// Path replaced: moira/bernoullimodule.c:131-263 (prob_j_errors, sum_of_binomials,
+// interpolate, test) + the filter half of moira/moira.py:806-831 (process_data) + the
+// keep/discard predicate of moira/moira.py:911,925-926,949-950 (write_results).
+//
+// Pipeline for one HBM-resident batch (all on one stream, no host round trip):
+//   k_prepass  streams the quality matrix once (16 B per lane, coalesced), estimates per read
+//              mean / variance / third cumulant of the error count, predicts how many DP rows
+//              J the read needs (Cornish-Fisher quantile) and assigns a row-budget class;
+//              also counts ambiguous bases (Ns) and writes a per-block class histogram.
+//   k_scan / k_tables   exclusive scan of the histograms -> stable offsets, tile table.
+//   k_scatter  stable counting-sort scatter of read indices by class (deterministic).
+//   k_dp       the DP.  One wave = one tile of reads of ONE class, so every lane runs the same
+//              trip counts.  Class (G,R): G lanes share a read, each lane keeps R consecutive
+//              entries of the running probability vector v[] in VGPRs; per base
+//                  v[j] = fl( fl(a*v[j]) + fl(b*v[j-1]) )      (no FMA: bit-exact with the
+//              reference, whose inner sum has exactly these two non-zero terms), the row
+//              crossing lane boundaries by one DPP wave shift.  {a,b} come from a 4 KB LDS
+//              LUT built on the host with libm pow.  Epilogue = sequential CDF, linear
+//              interpolation, +Ns / floor / predicate.
+//   k_dp (overflow pass)  reads whose CDF did not cross inside their class budget are re-run
+//              in the widest class (rare: the predictor is tight).
+//   k_count    pass count.
+//
+// The arithmetic that must match the reference bit for bit is compiled with FP contraction
+// off (see build.py: -ffp-contract=off, and the pragma below).
+
+#include "mpb_internal.h"
+#include "../../include/mpb_synth.h"
+
+#pragma clang fp contract(off)
+
+// 4 KB {1-p, p'} LUT in LDS (dynamic shared memory, filled by k_dp, read by the class bodies)
+extern __shared__ double2 mpb_s_lut[];
+
+namespace {
+
+__constant__ MpbClass c_classes[MPB_NCLS] = MPB_CLASS_TABLE;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ------------------------------------------------------------------------------------------
+// k_prepass
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pre_byte(uint32_t qb, float &mu, float &var, float &k3,
+                                         int &nzero, int &n255)
+{
+    const bool z = qb == 0u, f = qb == 255u;
+    float p = __builtin_amdgcn_exp2f(-0.33219281f * (float)qb);   // 10^(-q/10)
+    p = (z || f) ? 0.0f : p;
+    const float pq = p * (1.0f - p);
+    mu += p;
+    var += pq;
+    k3 += pq * (1.0f - 2.0f * p);
+    nzero += z ? 1 : 0;
+    n255 += f ? 1 : 0;
+}
+
+__device__ __forceinline__ uint32_t mask_dword(uint32_t w, int nvalid_bytes)
+{
+    // keep the low `nvalid_bytes` bytes (0..4) of w
+    if (nvalid_bytes >= 4) return w;
+    if (nvalid_bytes <= 0) return 0u;
+    return w & ((1u << (8 * nvalid_bytes)) - 1u);
+}
+
+__global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, int64_t n,
+                                                 int64_t stride, const int32_t *__restrict__ len,
+                                                 MpbDevParams prm, uint8_t *__restrict__ cls,
+                                                 int32_t *__restrict__ blockhist,
+                                                 int32_t *__restrict__ ns_out)
+{
+    __shared__ int s_hist[MPB_NCLS];
+    const int tid = threadIdx.x;
+    if (tid < MPB_NCLS) s_hist[tid] = 0;
+    __syncthreads();
+
+    const int hw = tid >> 5, l32 = tid & 31;
+    const int64_t base = (int64_t)blockIdx.x * MPB_PRE_READS;
+    for (int r = hw; r < MPB_PRE_READS; r += 8) {
+        const int64_t i = base + r;
+        if (i >= n) break;
+        const int li = len ? len[i] : prm.fixed_len;
+        const uint8_t *row = q + i * stride;
+        float mu = 0.f, var = 0.f, k3 = 0.f;
+        int nzero = 0, n255 = 0;
+        for (int c = l32; c * 16 < li; c += 32) {
+            uint4 w = *reinterpret_cast<const uint4 *>(row + c * 16);
+            const int nv = li - c * 16;           // >= 1 here
+            w.x = mask_dword(w.x, nv);
+            w.y = mask_dword(w.y, nv - 4);
+            w.z = mask_dword(w.z, nv - 8);
+            w.w = mask_dword(w.w, nv - 12);
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) pre_byte((ww[d] >> (8 * t)) & 0xffu, mu, var, k3, nzero, n255);
+            nzero -= (nv < 16) ? (16 - nv) : 0;   // masked-off bytes are not 'N'
+        }
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+            mu += __shfl_xor(mu, off, 32);
+            var += __shfl_xor(var, off, 32);
+            k3 += __shfl_xor(k3, off, 32);
+            nzero += __shfl_xor(nzero, off, 32);
+            n255 += __shfl_xor(n255, off, 32);
+        }
+        if (l32 == 0) {
+            // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
+            // rows 0..j* where j* is the first row whose CDF exceeds 1-alpha.
+            const float v = fmaxf(var, 1e-12f);
+            const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;
+            int rows = (int)floorf(x + 0.5f) + 1;
+            if (prm.flags & 4u) rows = rows / 2;      // MPB_FLAG_TEST_UNDERPREDICT
+            const int scored = li - nzero - n255;
+            rows = min(rows, scored + 1);
+            rows = max(rows, 1);
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < MPB_NCLS - 1; k++) c += (rows > c_classes[k].cap) ? 1 : 0;
+            cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
+            ns_out[i] = nzero + n255;
+            atomicAdd(&s_hist[c], 1);
+        }
+    }
+    __syncthreads();
+    if (tid < MPB_NCLS) blockhist[(int64_t)blockIdx.x * MPB_NCLS + tid] = s_hist[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scan: block c turns blockhist[.][c] into exclusive prefixes and writes count[c]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan(int32_t *__restrict__ blockhist, int nblocks,
+                                              MpbTables *__restrict__ tb)
+{
+    __shared__ int s_part[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int seg = (nblocks + 255) / 256;
+    const int b0 = tid * seg, b1 = min(nblocks, b0 + seg);
+    int sum = 0;
+    for (int b = b0; b < b1; b++) sum += blockhist[(int64_t)b * MPB_NCLS + c];
+    s_part[tid] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 256 partials
+    for (int off = 1; off < 256; off <<= 1) {
+        int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;   // exclusive prefix of this thread's segment
+    for (int b = b0; b < b1; b++) {
+        const int64_t k = (int64_t)b * MPB_NCLS + c;
+        const int h = blockhist[k];
+        blockhist[k] = run;
+        run += h;
+    }
+    if (tid == 255) tb->count[c] = s_part[255];
+}
+
+__global__ void k_tables(MpbTables *__restrict__ tb, int32_t *__restrict__ ovf_count,
+                         unsigned long long *__restrict__ pass_count)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int base = 0;
+    for (int c = 0; c < MPB_NCLS; c++) {
+        tb->perm_base[c] = base;
+        base += (tb->count[c] + 63) & ~63;
+    }
+    tb->perm_base[MPB_NCLS] = base;
+    int t = 0;
+    for (int c = MPB_NCLS - 1; c >= 0; c--) {        // widest (most expensive) tiles first
+        const int rpt = 64 / c_classes[c].G;
+        tb->tile_start[c] = t;
+        t += (tb->count[c] + rpt - 1) / rpt;
+    }
+    tb->tile_start[MPB_NCLS] = t;
+    tb->total_tiles = t;
+    *ovf_count = 0;
+    *pass_count = 0ull;
+}
+
+// overflow pass: every listed read goes to one class `wc`
+__global__ void k_tables_overflow(MpbTables *__restrict__ tb, const int32_t *__restrict__ ovf_count,
+                                  int wc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int cnt = *ovf_count;
+    const int rpt = 64 / c_classes[wc].G;
+    // class c owns tiles [tile_start[c], tile_start[c] + tiles(count[c])); only wc is non-empty
+    for (int c = 0; c <= MPB_NCLS; c++) {
+        if (c < MPB_NCLS) tb->count[c] = (c == wc) ? cnt : 0;
+        tb->perm_base[c] = 0;
+        tb->tile_start[c] = 0;
+    }
+    tb->total_tiles = (cnt + rpt - 1) / rpt;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scatter: stable scatter of read indices into perm[], grouped by class
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls, int64_t n,
+                                                 const int32_t *__restrict__ blockhist,
+                                                 const MpbTables *__restrict__ tb,
+                                                 int32_t *__restrict__ perm)
+{
+    __shared__ int s_wcnt[4][MPB_NCLS];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    for (int k = tid; k < 4 * MPB_NCLS; k += 256) (&s_wcnt[0][0])[k] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + tid;
+    const bool valid = i < n;
+    const int c = valid ? (cls[i] & 0x7f) : -1;
+    int rank = 0;
+    unsigned long long remaining = __ballot(valid);
+    while (remaining) {
+        const int leader = __ffsll((long long)remaining) - 1;
+        const int cc = __shfl(c, leader);
+        const unsigned long long m = __ballot(c == cc);
+        if (c == cc) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == leader) s_wcnt[w][cc] = __popcll(m);
+        remaining &= ~m;
+    }
+    __syncthreads();
+    if (valid) {
+        int off = blockhist[(int64_t)blockIdx.x * MPB_NCLS + c];
+        for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][c];
+        perm[tb->perm_base[c] + off + rank] = (int32_t)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_dp
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dpp_wave_shr1(double x)
+{
+    // value of lane-1 (lane 0 receives 0): two 32-bit DPP moves, wave_shr:1
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool FMA>
+__device__ __forceinline__ double cell(double a, double v, double b, double w)
+{
+    if (FMA) return __builtin_fma(a, v, b * w);
+    const double x = a * v;      // fl(a*v)
+    const double y = b * w;      // fl(b*w)
+    return x + y;                // fl(x+y): three roundings, as the reference
+}
+
+// one base: advance the running vector by (a,b)
+template <int R, int G, bool FMA>
+__device__ __forceinline__ void dp_step(double (&v)[R], const double2 ab, const bool leader)
+{
+    double cin = 0.0;
+    if (G > 1) {
+        cin = dpp_wave_shr1(v[R - 1]);
+        cin = leader ? 0.0 : cin;
+    }
+#pragma unroll
+    for (int r = R - 1; r >= 1; r--) v[r] = cell<FMA>(ab.x, v[r], ab.y, v[r - 1]);
+    if (G > 1) v[0] = cell<FMA>(ab.x, v[0], ab.y, cin);
+    else v[0] = ab.x * v[0];
+}
+
+template <int R, int G, bool FMA>
+__device__ __forceinline__ void dp_dword(double (&v)[R], uint32_t w, bool leader)
+{
+#pragma unroll
+    for (int t = 0; t < 4; t++) dp_step<R, G, FMA>(v, mpb_s_lut[(w >> (8 * t)) & 0xffu], leader);
+}
+
+struct DpArgs {
+    const uint8_t *q;
+    int64_t stride;
+    const int32_t *len;
+    const int32_t *ns;
+    const uint8_t *cls;
+    double *ee;
+    uint8_t *pass;
+    int32_t *ovf_list;
+    int32_t *ovf_count;
+    MpbDevParams prm;
+    int final_pass;
+};
+
+// One tile of one class.  Deliberately NOT inlined: each (R,G) body gets its own register
+// allocation, so the kernel's VGPR budget is the widest body's, not the sum of all of them.
+template <int R, int G, bool FMA>
+__device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_t *perm_cls,
+                                     int count, int local_tile)
+{
+    const DpArgs &A = *Ap;
+    constexpr int RPT = 64 / G;
+    const int lane = lane_id();
+    const int lig = lane & (G - 1);
+    const bool leader = lig == 0;
+    const int slot = local_tile * RPT + lane / G;
+    const bool valid = slot < count;
+    const int idx = perm_cls[valid ? slot : count - 1];
+    const int li = A.len ? A.len[idx] : A.prm.fixed_len;
+    const uint8_t *row = A.q + (int64_t)idx * A.stride;
+
+    int nch = (li + 15) >> 4;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nch = max(nch, __shfl_xor(nch, off));
+    nch = __builtin_amdgcn_readfirstlane(nch);      // wave-uniform trip count
+
+    double v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = 0.0;
+    if (leader) v[0] = 1.0;
+
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if (nch > 0) cur = *reinterpret_cast<const uint4 *>(row);
+    for (int c = 0; c < nch; c++) {
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (c + 1 < nch) nxt = *reinterpret_cast<const uint4 *>(row + (c + 1) * 16);
+        const int nv = li - c * 16;       // may be <= 0 for reads shorter than the tile's longest
+        uint32_t ww[4] = {mask_dword(cur.x, nv), mask_dword(cur.y, nv - 4),
+                          mask_dword(cur.z, nv - 8), mask_dword(cur.w, nv - 12)};
+#pragma unroll
+        for (int d = 0; d < 4; d++) dp_dword<R, G, FMA>(v, ww[d], leader);
+        cur = nxt;
+    }
+
+    // ---- epilogue: sequential CDF (ref: bernoullimodule.c:233-251), first row above thr ----
+    const double thr = A.prm.thr;
+    double acc = 0.0, lo = 0.0, hi = 0.0;
+    int js = -1;
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+        if (G > 1 && g > 0) {
+            const int src = (lane & ~(G - 1)) + g - 1;
+            const double acc_s = __shfl(acc, src), lo_s = __shfl(lo, src), hi_s = __shfl(hi, src);
+            const int js_s = __shfl(js, src);
+            if (lig == g) { acc = acc_s; lo = lo_s; hi = hi_s; js = js_s; }
+        }
+        if (lig == g) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const double na = acc + v[r];          // r==0,g==0: 0 + v0 is exact
+                const bool hit = (js < 0) && (na > thr);
+                lo = hit ? acc : lo;
+                hi = hit ? na : hi;
+                js = hit ? (g * R + r) : js;
+                acc = na;
+            }
+        }
+    }
+    if (lig == G - 1 && valid) {
+        if (js < 0 && !A.final_pass) {
+            const int pos = atomicAdd(A.ovf_count, 1);
+            A.ovf_list[pos] = idx;
+        } else {
+            double e;
+            if (js < 0) {
+                e = __builtin_nan("");                 // CDF never crosses: reference runs off its table
+            } else {
+                // ref: bernoullimodule.c:170-178  errors1 + ((errors2-errors1)*((1-alpha)-prob1)/(prob2-prob1))
+                e = (double)(js - 1) + ((thr - lo) / (hi - lo));
+                if (e < 0) e = 0;
+            }
+            const int nsv = A.ns[idx];
+            if (A.prm.ambig_mode == 0) e = e + (double)nsv;              // moira.py:827-828
+            if (A.prm.flags & 1u) e = floor(e);                          // moira.py:830-831
+            bool keep;
+            if (A.prm.ambig_mode == 2 && (A.cls[idx] & 0x80)) keep = false;           // moira.py:911
+            else if (A.prm.maxerrors == A.prm.maxerrors) keep = e <= A.prm.maxerrors; // moira.py:925-926
+            else keep = e <= (double)li * A.prm.uncert;                               // moira.py:949-950
+            A.ee[idx] = e;
+            A.pass[idx] = keep ? 1 : 0;
+        }
+    }
+}
+
+// DpArgs travel through device memory so that the non-inlined class bodies can take a pointer
+__global__ void k_set_args(DpArgs a, DpArgs *__restrict__ dst) { if (threadIdx.x == 0) *dst = a; }
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void k_dp(const DpArgs *__restrict__ A,
+                                            const double2 *__restrict__ lut_g,
+                                            const MpbTables *__restrict__ tb,
+                                            const int32_t *__restrict__ perm)
+{
+    mpb_s_lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    const int total = tb->total_tiles;
+    for (int t = blockIdx.x * 4 + w; t < total; t += gridDim.x * 4) {
+        int c = 0, lt = 0;
+        for (int cc = 0; cc < MPB_NCLS; cc++) {
+            const int rpt = 64 / c_classes[cc].G;
+            const int s = tb->tile_start[cc];
+            const int e = s + (tb->count[cc] + rpt - 1) / rpt;
+            if (t >= s && t < e) { c = cc; lt = t - s; }
+        }
+        c = __builtin_amdgcn_readfirstlane(c);
+        lt = __builtin_amdgcn_readfirstlane(lt);
+        const int32_t *pc = perm + tb->perm_base[c];
+        const int cnt = tb->count[c];
+        switch (c) {
+#define MPB_CASE(ID, RR, GG) case ID: dp_tile<RR, GG, FMA>(A, pc, cnt, lt); break;
+            MPB_CASE(0, 2, 1) MPB_CASE(1, 3, 1) MPB_CASE(2, 4, 1) MPB_CASE(3, 5, 1) MPB_CASE(4, 6, 1)
+            MPB_CASE(5, 7, 1) MPB_CASE(6, 8, 1) MPB_CASE(7, 9, 1) MPB_CASE(8, 10, 1) MPB_CASE(9, 12, 1)
+            MPB_CASE(10, 14, 1) MPB_CASE(11, 16, 1) MPB_CASE(12, 10, 2) MPB_CASE(13, 12, 2)
+            MPB_CASE(14, 16, 2) MPB_CASE(15, 12, 4) MPB_CASE(16, 16, 4) MPB_CASE(17, 12, 8)
+            MPB_CASE(18, 16, 8) MPB_CASE(19, 12, 16) MPB_CASE(20, 16, 16) MPB_CASE(21, 12, 32)
+            MPB_CASE(22, 16, 32) MPB_CASE(23, 12, 64) MPB_CASE(24, 16, 64)
+#undef MPB_CASE
+        default: break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict__ pass, int64_t n,
+                                               unsigned long long *__restrict__ out)
+{
+    unsigned int s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        s += pass[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    __shared__ unsigned int s_w[4];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(s_w[0] + s_w[1] + s_w[2] + s_w[3]));
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic fill: one thread per 16-byte chunk of the matrix
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t n, int64_t stride,
+                                               int32_t fixed_len, int32_t min_len, int32_t max_len,
+                                               int32_t *__restrict__ len, uint64_t seed,
+                                               int64_t first_read)
+{
+    const int64_t cpr = stride / 16;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n * cpr) return;
+    const int64_t i = g / cpr;
+    const int c = (int)(g - i * cpr);
+    const uint64_t h = mpb_synth_read_hash(seed, (uint64_t)(first_read + i));
+    const int32_t li = fixed_len > 0 ? fixed_len : mpb_synth_len(h, min_len, max_len);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int pos = c * 16 + t;
+        const uint32_t b = pos < li ? (uint32_t)mpb_synth_byte(h, (uint32_t)pos, (uint32_t)li) : 0u;
+        w[t >> 2] |= b << (8 * (t & 3));
+    }
+    *reinterpret_cast<uint4 *>(q + i * stride + (int64_t)c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (len && c == 0) len[i] = li;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+static inline int pre_blocks(int64_t n) { return (int)((n + MPB_PRE_READS - 1) / MPB_PRE_READS); }
+
+void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
+                        const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prepass, dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm,
+                       ws.cls, ws.blockhist, ns_out);
+}
+
+void mpb_launch_scan(int64_t n, const MpbWorkspace &ws, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scan, dim3(MPB_NCLS), dim3(256), 0, s, ws.blockhist, pre_blocks(n), ws.tables);
+    hipLaunchKernelGGL(k_tables, dim3(1), dim3(64), 0, s, ws.tables, ws.ovf_count, ws.pass_count);
+}
+
+void mpb_launch_scatter(int64_t n, const MpbWorkspace &ws, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scatter, dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, ws.blockhist,
+                       ws.tables, ws.perm);
+}
+
+static_assert(sizeof(DpArgs) <= MPB_DPARGS_SLOT, "DpArgs slot too small");
+
+static DpArgs make_args(const uint8_t *q, int64_t stride, const int32_t *len, const MpbDevParams &prm,
+                        const MpbWorkspace &ws, const int32_t *ns, double *ee, uint8_t *pass, int final_pass)
+{
+    DpArgs A;
+    A.q = q; A.stride = stride; A.len = len; A.ns = ns; A.cls = ws.cls; A.ee = ee; A.pass = pass;
+    A.ovf_list = ws.ovf_list; A.ovf_count = ws.ovf_count; A.prm = prm; A.final_pass = final_pass;
+    return A;
+}
+
+void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
+                   const MpbDevParams &prm, const MpbWorkspace &ws, const int32_t *ns,
+                   double *ee, uint8_t *pass, hipStream_t s)
+{
+    // Upper bound for the tile count without a host round trip: every read in a G==1 class
+    // (64 reads per tile) plus one partial tile per class.  Classes with G > 1 have more tiles
+    // per read; the kernel's tile loop is grid-strided, so they are still covered.
+    const int64_t tiles = (n + 63) / 64 + MPB_NCLS;
+    const int blocks = (int)((tiles + 3) / 4);
+    DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 0);
+    DpArgs *dA = reinterpret_cast<DpArgs *>(ws.dp_args);
+    hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
+    if (prm.flags & 2u)
+        hipLaunchKernelGGL(k_dp<true>, dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables, ws.perm);
+    else
+        hipLaunchKernelGGL(k_dp<false>, dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables, ws.perm);
+}
+
+void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
+                         const MpbDevParams &prm, const MpbWorkspace &ws, const int32_t *ns,
+                         double *ee, uint8_t *pass, hipStream_t s)
+{
+    (void)n;
+    static const MpbClass classes[MPB_NCLS] = MPB_CLASS_TABLE;
+    int wc = MPB_NCLS - 1;
+    for (int c = MPB_NCLS - 1; c >= 0; c--)
+        if (classes[c].cap >= prm.max_len + 1) wc = c;
+    hipLaunchKernelGGL(k_tables_overflow, dim3(1), dim3(64), 0, s, ws.tables2, ws.ovf_count, wc);
+    DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 1);
+    DpArgs *dA = reinterpret_cast<DpArgs *>(ws.dp_args + MPB_DPARGS_SLOT);
+    hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
+    const int blocks = 512;
+    if (prm.flags & 2u)
+        hipLaunchKernelGGL(k_dp<true>, dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables2, ws.ovf_list);
+    else
+        hipLaunchKernelGGL(k_dp<false>, dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables2, ws.ovf_list);
+}
+
+void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hipStream_t s)
+{
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, s, pass, n, ws.pass_count);
+}
+
+void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, int32_t min_len,
+                      int32_t max_len, int32_t *len, uint64_t seed, int64_t first_read,
+                      hipStream_t s)
+{
+    const int64_t chunks = n * (stride / 16);
+    const int64_t blocks = (chunks + 255) / 256;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len,
+                       min_len, max_len, len, seed, first_read);
+}

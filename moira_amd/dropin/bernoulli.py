@@ -1,0 +1,32 @@
+"""Drop-in for moira's CPython extension `bernoulli` (moira/bernoullimodule.c).
+
+Put this directory on PYTHONPATH ahead of the compiled extension and moira.py's
+`import bernoulli` (moira/moira.py:247-251) picks it up unchanged:
+
+    bernoulli.calculate_errors_PB(contig, contig_quals, alpha) -> (expected_errors, Ns)
+
+Same signature, same exceptions (moira/bernoullimodule.c:74-90); computed on the MI355X by
+libmoira_pb.so.  `calculate_errors` is the alias BASELINE.json's north_star names.
+A per-read call pays a kernel launch; throughput comes from the batch API
+(moira_amd.engine.Engine.filter), which is what replaces moira's per-read Pool dispatch.
+"""
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from moira_amd.engine import default_engine as _default_engine  # noqa: E402
+
+__doc__ = ("This module provides an interface for calculating the expected errors of a given sequence "
+           "using a sum of Bernoulli random variables.")
+
+
+def calculate_errors_PB(contig, contig_quals, alpha):
+    """This function returns the expected errors of a given sequence with a given confidence value
+    using a sum of Bernoulli random variables."""
+    return _default_engine().calculate_errors_PB(contig, contig_quals, alpha)
+
+
+calculate_errors = calculate_errors_PB

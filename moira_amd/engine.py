@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference's filter path, batch-shaped.
+
+Reference interface mirrored (same argument meaning and error behaviour):
+  * `bernoulli.calculate_errors_PB(contig, contig_quals, alpha)`  moira/bernoullimodule.c:66-114
+  * the filter half of `process_data`                             moira/moira.py:806-831
+  * the keep/discard predicate of `write_results`                 moira/moira.py:911,925-926,949-950
+What replaces moira's per-read `Pool.apply_async` dispatch (moira/moira.py:431-454) is:
+pack a chunk of reads into an (N x L_max) uint8 matrix -> one library call -> arrays back.
+
+Everything is computed by libmoira_pb.so on the GPU; this module only marshals.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class DeviceBuffer:
+    """A device allocation owned by an Engine (freed with it or by .free())."""
+
+    def __init__(self, engine, nbytes):
+        self.engine, self.nbytes = engine, int(nbytes)
+        p = C.c_void_p()
+        L.check(engine.lib.mpb_malloc(engine.ctx, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        L.check(self.engine.lib.mpb_memcpy_h2d(self.engine.ctx, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype)
+        assert out.nbytes <= self.nbytes
+        L.check(self.engine.lib.mpb_memcpy_d2h(self.engine.ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            L.check(self.engine.lib.mpb_free(self.engine.ctx, self.ptr))
+            self.ptr = None
+
+
+class FilterResult:
+    """Per-read outputs of one batch: ee (after +Ns / floor, i.e. what process_data returns),
+    ns, passed (bool) and the batch totals."""
+
+    def __init__(self, ee, ns, passed, n_pass, n_overflow):
+        self.ee, self.ns, self.passed = ee, ns, passed
+        self.n_pass, self.n_fail, self.n_overflow = n_pass, len(ee) - n_pass, n_overflow
+
+
+class Engine:
+    """One context on one MI355X (one per process/rank; not thread-safe)."""
+
+    def __init__(self, device=0):
+        self.lib = L.load()
+        ctx = C.c_void_p()
+        L.check(self.lib.mpb_create(int(device), C.byref(ctx)))
+        self.ctx = ctx
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.mpb_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- parameters -------------------------------------------------------------------------
+    @staticmethod
+    def params(alpha=0.005, uncert=0.01, maxerrors=None, ambigs="treat_as_errors", round_=False,
+               fast_fma=False, test_underpredict=False):
+        if ambigs not in L.AMBIG:
+            raise ValueError("ambigs must be one of %s" % sorted(L.AMBIG))
+        flags = (L.FLAG_ROUND if round_ else 0) | (L.FLAG_FAST_FMA if fast_fma else 0) | \
+                (L.FLAG_TEST_UNDERPREDICT if test_underpredict else 0)
+        return L.FilterParams(float(alpha), float(uncert),
+                              math.nan if maxerrors is None else float(maxerrors),
+                              L.AMBIG[ambigs], flags)
+
+    # ---- memory -----------------------------------------------------------------------------
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def synchronize(self):
+        L.check(self.lib.mpb_synchronize(self.ctx))
+
+    def stream(self):
+        p = C.c_void_p()
+        L.check(self.lib.mpb_stream(self.ctx, C.byref(p)))
+        return p.value
+
+    # ---- packing ----------------------------------------------------------------------------
+    def pack(self, seqs, quals, stride=None):
+        """[(seq str|None)], [list[int]] -> (q uint8[n, stride], lens int32[n]).
+        Q0 -> 1, 'N' -> 0, 'n' -> 255 (see include/moira_pb.h)."""
+        n = len(quals)
+        lens = np.array([len(x) for x in quals], np.int32)
+        if stride is None:
+            stride = _round_up(max(int(lens.max()) if n else 1, 1), 16)
+        q = np.zeros((n, stride), np.uint8)
+        for i in range(n):
+            qi = np.ascontiguousarray(quals[i], dtype=np.int32)
+            s = seqs[i] if seqs is not None else None
+            if s is not None:
+                if len(s) != len(qi):
+                    raise ValueError("contig and contig_quals must have the same length")
+                s = s.encode() if isinstance(s, str) else s
+            L.check(self.lib.mpb_pack_read(s, qi.ctypes.data, len(qi), q[i].ctypes.data, stride))
+        return q, lens
+
+    # ---- the hot path -------------------------------------------------------------------------
+    def filter_device(self, d_q, n, stride, d_len=None, fixed_len=0, d_ee=None, d_ns=None, d_pass=None,
+                      params=None, want_counts=True):
+        """Filter a batch already resident in HBM.  d_* are DeviceBuffer or raw int pointers."""
+        params = params or self.params()
+        ptr = lambda b: (b.ptr if isinstance(b, DeviceBuffer) else b)
+        counts = L.FilterCounts()
+        L.check(self.lib.mpb_filter_device(self.ctx, ptr(d_q), n, stride, ptr(d_len) if d_len is not None else None,
+                                           int(fixed_len), C.byref(params), ptr(d_ee), ptr(d_ns), ptr(d_pass),
+                                           C.byref(counts) if want_counts else None))
+        return counts if want_counts else None
+
+    def filter(self, q, lens=None, fixed_len=None, **kw):
+        """Filter a packed host matrix q (n x stride uint8).  Returns FilterResult."""
+        params = kw.pop("params", None) or self.params(**kw)
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        if q.ndim != 2:
+            raise ValueError("q must be a 2-D (reads x stride) uint8 matrix")
+        n, stride = q.shape
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.int32)
+            if lens.shape != (n,):
+                raise ValueError("lens must have one entry per read")
+            if n and (lens.min() < 0 or lens.max() > stride):
+                raise ValueError("a length does not fit the row stride")
+        elif fixed_len is None:
+            raise ValueError("give lens or fixed_len")
+        ee = np.empty(n, np.float64)
+        ns = np.empty(n, np.int32)
+        ps = np.empty(n, np.uint8)
+        counts = L.FilterCounts()
+        L.check(self.lib.mpb_filter_host(self.ctx, q.ctypes.data, n, stride,
+                                         lens.ctypes.data if lens is not None else None,
+                                         0 if lens is not None else int(fixed_len), C.byref(params),
+                                         ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, C.byref(counts)))
+        return FilterResult(ee, ns, ps.astype(bool), counts.n_pass, counts.n_overflow)
+
+    def calculate_errors_PB(self, contig, contig_quals, alpha):
+        """Exact twin of bernoulli.calculate_errors_PB -> (expected_errors, Ns).
+        ref: moira/bernoullimodule.c:66-114 (argument and error behaviour)."""
+        if not isinstance(contig, str):
+            raise TypeError("argument 1 must be str, not %s" % type(contig).__name__)
+        if not isinstance(contig_quals, list):
+            raise TypeError("argument 2 must be list, not %s" % type(contig_quals).__name__)
+        alpha = float(alpha)                                   # "d" format: TypeError if not a number
+        if alpha <= 0 or alpha >= 1:
+            raise ValueError("Alpha must be between 0 and 1")
+        if len(contig_quals) != len(contig):
+            raise ValueError("contig and contig_quals must have the same length")
+        qi = np.empty(len(contig_quals), np.int32)
+        for i, v in enumerate(contig_quals):
+            if not isinstance(v, int):
+                raise TypeError("an integer is required")      # PyInt_AsLong on a non-int
+            qi[i] = v
+        ee, ns = C.c_double(), C.c_int32()
+        L.check(self.lib.mpb_calculate_errors_PB(self.ctx, contig.encode(), qi.ctypes.data, len(qi), alpha,
+                                                 C.byref(ee), C.byref(ns)))
+        return ee.value, ns.value
+
+    # ---- synthetic workload -----------------------------------------------------------------------
+    def synth_fill(self, d_q, n, stride, fixed_len=0, min_len=0, max_len=0, d_len=None, seed=1, first_read=0):
+        ptr = lambda b: (b.ptr if isinstance(b, DeviceBuffer) else b)
+        L.check(self.lib.mpb_synth_fill_device(self.ctx, ptr(d_q), n, stride, fixed_len, min_len, max_len,
+                                               ptr(d_len) if d_len is not None else None, seed, first_read))
+
+    # ---- measurement ----------------------------------------------------------------------------
+    def timing(self, on=True):
+        L.check(self.lib.mpb_timing_enable(self.ctx, 1 if on else 0))
+
+    def timing_reset(self):
+        L.check(self.lib.mpb_timing_reset(self.ctx))
+
+    def kernel_times(self):
+        """{name: (total_ms, launches)} since the last reset (synchronises)."""
+        out = {}
+        for kid, name in L.KERNEL_NAMES.items():
+            ms, cnt = C.c_double(), C.c_int64()
+            L.check(self.lib.mpb_kernel_time(self.ctx, kid, C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+    def class_histogram(self):
+        caps = np.zeros(64, np.int32)
+        cnts = np.zeros(64, np.int64)
+        k = self.lib.mpb_last_class_histogram(self.ctx, caps.ctypes.data, cnts.ctypes.data, 64)
+        if k < 0:
+            L.check(k)
+        return {int(caps[i]): int(cnts[i]) for i in range(k)}
+
+
+_default_engine = None
+
+
+def default_engine():
+    """Process-wide engine on device LOCAL_RANK (or 0)."""
+    global _default_engine
+    if _default_engine is None:
+        import os
+        _default_engine = Engine(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_engine

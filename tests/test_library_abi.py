@@ -1,0 +1,100 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header declares,
+validates arguments, packs reads like the oracle, and refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from moira_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "moira_pb.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpb_[a-z_A-Z0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(L.PROTOTYPES) == syms          # the ctypes table covers the whole header
+    assert b"gfx950" in lib.mpb_version()
+
+
+def test_no_cpu_fallback_without_device():
+    lib = L.load()
+    if lib.mpb_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from moira_amd.engine import Engine
+    with pytest.raises(L.NoDeviceError):
+        Engine(0)
+
+
+def test_product_does_not_reference_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "moira_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "pb_oracle" not in text and "oracle/" not in text.replace("the oracle", ""), f
+
+
+def test_pack_matches_oracle(oracle):
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        n = int(rng.integers(0, 70))
+        quals = rng.integers(0, 60, n).astype(np.int32)
+        seq = "".join(rng.choice(list("ACGTNn"), n)) if n else ""
+        row = np.full(80, 7, np.uint8)
+        assert lib.mpb_pack_read(seq.encode(), quals.ctypes.data, n, row.ctypes.data, 80) == 0
+        assert np.array_equal(row, oracle.pack_read(seq, quals, 80))
+        asc = bytes(int(q) + 33 for q in quals)
+        row2 = np.full(80, 9, np.uint8)
+        assert lib.mpb_pack_read_ascii(seq.encode(), asc, n, 33, row2.ctypes.data, 80) == 0
+        assert np.array_equal(row, row2)
+
+
+def test_pack_rejects_bad_scores():
+    lib = L.load()
+    row = np.zeros(16, np.uint8)
+    q = np.array([5, -1, 3], np.int32)
+    assert lib.mpb_pack_read(b"ACG", q.ctypes.data, 3, row.ctypes.data, 16) == L.E_RANGE
+    assert b"positive" in lib.mpb_last_error()
+    q = np.array([5, 255, 3], np.int32)
+    assert lib.mpb_pack_read(b"ACG", q.ctypes.data, 3, row.ctypes.data, 16) == L.E_RANGE
+    q = np.arange(20, dtype=np.int32)
+    assert lib.mpb_pack_read(None, q.ctypes.data, 20, row.ctypes.data, 16) == L.E_INVALID
+
+
+def test_no_fma_in_exact_dp_kernel():
+    """The bit-exact DP must not contain fused multiply-adds except inside the IEEE division
+    expansion (3 v_fma_f64 + 2 v_fmac_f64 per division, one division per class body)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off",
+                               "-fno-fast-math", "-x", "hip", "--cuda-device-only", "-S", "-o", out,
+                               os.path.join(ROOT, "moira_amd", "csrc", "mpb_kernels.hip")],
+                              stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    # split into functions; exact-mode class bodies are dp_tile<R,G,false> = ...Lb0EEE in the mangled name
+    bodies = re.split(r"\n(?=_ZN\S+:)", text)
+    exact = [b for b in bodies if re.match(r"_ZN\S*dp_tileILi\d+ELi\d+ELb0EE", b)]
+    fast = [b for b in bodies if re.match(r"_ZN\S*dp_tileILi\d+ELi\d+ELb1EE", b)]
+    assert len(exact) == 25 and len(fast) == 25
+    for b in exact:
+        assert b.count("v_fma_f64") == 3 and b.count("v_fmac_f64") == 2, b.split(":")[0]
+        assert b.count("v_div_fixup_f64") == 1
+        assert "scratch_" not in b
+    assert all(b.count("v_fma_f64") + b.count("v_fmac_f64") > 5 for b in fast)
