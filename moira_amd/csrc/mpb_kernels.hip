@@ -43,19 +43,11 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // ------------------------------------------------------------------------------------------
 // k_prepass
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pre_byte(uint32_t qb, float &mu, float &var, float &k3,
-                                         int &nzero, int &n255)
-{
-    const bool z = qb == 0u, f = qb == 255u;
-    float p = __builtin_amdgcn_exp2f(-0.33219281f * (float)qb);   // 10^(-q/10)
-    p = (z || f) ? 0.0f : p;
-    const float pq = p * (1.0f - p);
-    mu += p;
-    var += pq;
-    k3 += pq * (1.0f - 2.0f * p);
-    nzero += z ? 1 : 0;
-    n255 += f ? 1 : 0;
-}
+// The matrix is walked as a flat stream of 16-byte chunks, one chunk per lane per iteration, so
+// every wave-instruction loads 1 KiB of consecutive bytes.  Per byte: one ds_read_b128 from a
+// 256-entry float4 LUT {p, p(1-p), p(1-p)(1-2p), ambiguity weight} and two packed f32 adds.
+// Chunk partials go through LDS and are summed per read in a fixed order (deterministic).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t mask_dword(uint32_t w, int nvalid_bytes)
 {
@@ -65,67 +57,105 @@ __device__ __forceinline__ uint32_t mask_dword(uint32_t w, int nvalid_bytes)
     return w & ((1u << (8 * nvalid_bytes)) - 1u);
 }
 
+#define MPB_PRE_SUB 320      // chunks per wave sub-batch (5 KiB of float4 partials per wave)
+
 __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, int64_t n,
                                                  int64_t stride, const int32_t *__restrict__ len,
                                                  MpbDevParams prm, uint8_t *__restrict__ cls,
                                                  int32_t *__restrict__ blockhist,
                                                  int32_t *__restrict__ ns_out)
 {
+    __shared__ float4 s_tab[256];
+    __shared__ float4 s_part[4][MPB_PRE_SUB];
     __shared__ int s_hist[MPB_NCLS];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    {
+        const bool amb0 = tid == 0, amb255 = tid == 255;
+        float p = __builtin_amdgcn_exp2f(-0.33219281f * (float)tid);      // 10^(-q/10)
+        p = (amb0 || amb255) ? 0.0f : p;
+        const float pq = p * (1.0f - p);
+        s_tab[tid] = make_float4(p, pq, pq * (1.0f - 2.0f * p), amb0 ? 1.0f : amb255 ? 1024.0f : 0.0f);
+    }
     if (tid < MPB_NCLS) s_hist[tid] = 0;
     __syncthreads();
 
-    const int hw = tid >> 5, l32 = tid & 31;
-    const int64_t base = (int64_t)blockIdx.x * MPB_PRE_READS;
-    for (int r = hw; r < MPB_PRE_READS; r += 8) {
-        const int64_t i = base + r;
-        if (i >= n) break;
-        const int li = len ? len[i] : prm.fixed_len;
-        const uint8_t *row = q + i * stride;
-        float mu = 0.f, var = 0.f, k3 = 0.f;
-        int nzero = 0, n255 = 0;
-        for (int c = l32; c * 16 < li; c += 32) {
-            uint4 w = *reinterpret_cast<const uint4 *>(row + c * 16);
-            const int nv = li - c * 16;           // >= 1 here
-            w.x = mask_dword(w.x, nv);
-            w.y = mask_dword(w.y, nv - 4);
-            w.z = mask_dword(w.z, nv - 8);
-            w.w = mask_dword(w.w, nv - 12);
-            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    const int cpr = (int)(stride >> 4);                                   // chunks per row
+    const int rs = min(16, max(1, MPB_PRE_SUB / cpr));                     // rows per sub-batch
+    const uint32_t inv = (uint32_t)(((1u << 20) + cpr - 1) / cpr);        // g / cpr == (g*inv) >> 20 for g*cpr < 2^20
+    const int cpp = (cpr + 3) >> 2;                                       // chunks per reducing lane
+    const int64_t wave_row0 = (int64_t)blockIdx.x * MPB_PRE_READS + w * 64;
+
+    for (int rb = 0; rb < 64; rb += rs) {
+        const int rows_here = min(rs, 64 - rb);
+        const int nchunks = rows_here * cpr;
+        for (int g = lane; g < nchunks; g += 64) {
+            const int r = (int)(((uint32_t)g * inv) >> 20);
+            const int c = g - r * cpr;
+            const int64_t i = wave_row0 + rb + r;
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+            if (i < n) {
+                const int li = len ? len[i] : prm.fixed_len;
+                const int nv = li - c * 16;
+                if (nv > 0) {
+                    uint4 x = *reinterpret_cast<const uint4 *>(q + i * stride + c * 16);
+                    const uint32_t ww[4] = {mask_dword(x.x, nv), mask_dword(x.y, nv - 4),
+                                            mask_dword(x.z, nv - 8), mask_dword(x.w, nv - 12)};
 #pragma unroll
-            for (int d = 0; d < 4; d++)
+                    for (int d = 0; d < 4; d++)
 #pragma unroll
-                for (int t = 0; t < 4; t++) pre_byte((ww[d] >> (8 * t)) & 0xffu, mu, var, k3, nzero, n255);
-            nzero -= (nv < 16) ? (16 - nv) : 0;   // masked-off bytes are not 'N'
+                        for (int t = 0; t < 4; t++) {
+                            const float4 e = s_tab[(ww[d] >> (8 * t)) & 0xffu];
+                            a01 += (f32x2){e.x, e.y};
+                            a23 += (f32x2){e.z, e.w};
+                        }
+                    if (nv < 16) a23.y -= (float)(16 - nv);               // masked-off bytes are not 'N'
+                }
+            }
+            s_part[w][g] = make_float4(a01.x, a01.y, a23.x, a23.y);
         }
+        __syncthreads();
+        // 4 lanes per read sum its chunk partials in a fixed order
+        {
+            const int r = lane >> 2, part = lane & 3;
+            float mu = 0.f, var = 0.f, k3 = 0.f, amb = 0.f;
+            if (r < rows_here) {
+                const int c0 = part * cpp, c1 = min(cpr, c0 + cpp);
+                for (int c = c0; c < c1; c++) {
+                    const float4 e = s_part[w][r * cpr + c];
+                    mu += e.x; var += e.y; k3 += e.z; amb += e.w;
+                }
+            }
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-            mu += __shfl_xor(mu, off, 32);
-            var += __shfl_xor(var, off, 32);
-            k3 += __shfl_xor(k3, off, 32);
-            nzero += __shfl_xor(nzero, off, 32);
-            n255 += __shfl_xor(n255, off, 32);
-        }
-        if (l32 == 0) {
-            // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
-            // rows 0..j* where j* is the first row whose CDF exceeds 1-alpha.
-            const float v = fmaxf(var, 1e-12f);
-            const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;
-            int rows = (int)floorf(x + 0.5f) + 1;
-            if (prm.flags & 4u) rows = rows / 2;      // MPB_FLAG_TEST_UNDERPREDICT
-            const int scored = li - nzero - n255;
-            rows = min(rows, scored + 1);
-            rows = max(rows, 1);
-            int c = 0;
+            for (int off = 1; off <= 2; off <<= 1) {
+                mu += __shfl_xor(mu, off);
+                var += __shfl_xor(var, off);
+                k3 += __shfl_xor(k3, off);
+                amb += __shfl_xor(amb, off);
+            }
+            const int64_t i = wave_row0 + rb + r;
+            if (part == 0 && r < rows_here && i < n) {
+                const int li = len ? len[i] : prm.fixed_len;
+                const int ambi = (int)amb;                                // exact: integer-valued float < 2^24
+                const int nzero = ambi & 1023, n255 = ambi >> 10;
+                // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
+                // rows 0..j* where j* is the first row whose CDF exceeds 1-alpha.
+                const float v = fmaxf(var, 1e-12f);
+                const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;
+                int rows = (int)floorf(x + 0.5f) + 1;
+                if (prm.flags & 4u) rows = rows / 2;                      // MPB_FLAG_TEST_UNDERPREDICT
+                const int scored = li - nzero - n255;
+                rows = min(rows, scored + 1);
+                rows = max(rows, 1);
+                int c = 0;
 #pragma unroll
-            for (int k = 0; k < MPB_NCLS - 1; k++) c += (rows > c_classes[k].cap) ? 1 : 0;
-            cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
-            ns_out[i] = nzero + n255;
-            atomicAdd(&s_hist[c], 1);
+                for (int k = 0; k < MPB_NCLS - 1; k++) c += (rows > c_classes[k].cap) ? 1 : 0;
+                cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
+                ns_out[i] = nzero + n255;
+                atomicAdd(&s_hist[c], 1);
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid < MPB_NCLS) blockhist[(int64_t)blockIdx.x * MPB_NCLS + tid] = s_hist[tid];
 }
 
@@ -274,6 +304,11 @@ __device__ __forceinline__ void dp_dword(double (&v)[R], uint32_t w, bool leader
     for (int t = 0; t < 4; t++) dp_step<R, G, FMA>(v, mpb_s_lut[(w >> (8 * t)) & 0xffu], leader);
 }
 
+// Register budget of the DP kernel: 4 waves per SIMD = at most 128 VGPRs per lane.
+#ifndef MPB_DP_WAVES_PER_EU
+#define MPB_DP_WAVES_PER_EU 4
+#endif
+
 struct DpArgs {
     const uint8_t *q;
     int64_t stride;
@@ -315,17 +350,41 @@ __device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_
     for (int r = 0; r < R; r++) v[r] = 0.0;
     if (leader) v[0] = 1.0;
 
-    uint4 cur = make_uint4(0, 0, 0, 0);
-    if (nch > 0) cur = *reinterpret_cast<const uint4 *>(row);
-    for (int c = 0; c < nch; c++) {
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (c + 1 < nch) nxt = *reinterpret_cast<const uint4 *>(row + (c + 1) * 16);
-        const int nv = li - c * 16;       // may be <= 0 for reads shorter than the tile's longest
-        uint32_t ww[4] = {mask_dword(cur.x, nv), mask_dword(cur.y, nv - 4),
-                          mask_dword(cur.z, nv - 8), mask_dword(cur.w, nv - 12)};
+    // Each lane pulls its row 64 bytes at a time (4 x dwordx4, issued together, one 64-byte
+    // segment of one line) and one super-chunk ahead of the arithmetic, so a cache line is
+    // consumed while it is still resident instead of being re-fetched 16 bytes at a time.
+    const int my_nch = (li + 15) >> 4;             // this lane's own 16-byte chunks
+    const int nsc = (nch + 3) >> 2;                // wave-uniform 64-byte super-chunks
+    uint4 cur[4], nxt[4];
 #pragma unroll
-        for (int d = 0; d < 4; d++) dp_dword<R, G, FMA>(v, ww[d], leader);
-        cur = nxt;
+    for (int p = 0; p < 4; p++) {
+        cur[p] = make_uint4(0, 0, 0, 0);
+        if (p < my_nch) cur[p] = *reinterpret_cast<const uint4 *>(row + p * 16);
+    }
+    for (int sc = 0; sc < nsc; sc++) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int c = (sc + 1) * 4 + p;
+            nxt[p] = make_uint4(0, 0, 0, 0);
+            if (c < my_nch) nxt[p] = *reinterpret_cast<const uint4 *>(row + c * 16);
+        }
+        const int pmax = min(4, nch - sc * 4);     // wave-uniform
+#pragma unroll 1
+        for (int p = 0; p < pmax; p++) {
+            const uint4 x = cur[0];
+            cur[0] = cur[1]; cur[1] = cur[2]; cur[2] = cur[3];   // rotate: keeps every index static
+            const int nv = li - (sc * 4 + p) * 16; // may be <= 0 for reads shorter than the tile's longest
+            uint32_t w0 = mask_dword(x.x, nv), w1 = mask_dword(x.y, nv - 4),
+                     w2 = mask_dword(x.z, nv - 8), w3 = mask_dword(x.w, nv - 12);
+            // 4 bases per trip: bounds the LUT entries in flight (register budget) and the code size
+#pragma unroll 1
+            for (int d = 0; d < 4; d++) {
+                dp_dword<R, G, FMA>(v, w0, leader);
+                w0 = w1; w1 = w2; w2 = w3;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) cur[p] = nxt[p];
     }
 
     // ---- epilogue: sequential CDF (ref: bernoullimodule.c:233-251), first row above thr ----
@@ -381,8 +440,8 @@ __device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_
 // DpArgs travel through device memory so that the non-inlined class bodies can take a pointer
 __global__ void k_set_args(DpArgs a, DpArgs *__restrict__ dst) { if (threadIdx.x == 0) *dst = a; }
 
-template <bool FMA>
-__global__ __launch_bounds__(256) void k_dp(const DpArgs *__restrict__ A,
+template <bool FMA, bool OVERFLOW_PASS>
+__global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(const DpArgs *__restrict__ A,
                                             const double2 *__restrict__ lut_g,
                                             const MpbTables *__restrict__ tb,
                                             const int32_t *__restrict__ perm)
@@ -509,9 +568,9 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
     DpArgs *dA = reinterpret_cast<DpArgs *>(ws.dp_args);
     hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
     if (prm.flags & 2u)
-        hipLaunchKernelGGL(k_dp<true>, dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables, ws.perm);
+        hipLaunchKernelGGL((k_dp<true, false>), dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables, ws.perm);
     else
-        hipLaunchKernelGGL(k_dp<false>, dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables, ws.perm);
+        hipLaunchKernelGGL((k_dp<false, false>), dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables, ws.perm);
 }
 
 void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
@@ -529,9 +588,9 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
     hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
     const int blocks = 512;
     if (prm.flags & 2u)
-        hipLaunchKernelGGL(k_dp<true>, dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables2, ws.ovf_list);
+        hipLaunchKernelGGL((k_dp<true, true>), dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables2, ws.ovf_list);
     else
-        hipLaunchKernelGGL(k_dp<false>, dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables2, ws.ovf_list);
+        hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables2, ws.ovf_list);
 }
 
 void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hipStream_t s)
