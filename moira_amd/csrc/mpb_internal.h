@@ -11,16 +11,23 @@
 // cap >= J.  cap = G * R: G lanes cooperate on one read, each keeps R consecutive rows of the
 // running probability vector in registers.  G == 1 is one read per lane.  R <= 16 everywhere so
 // the whole kernel fits a small VGPR budget (many waves per SIMD hide the LUT-read latency).
-#define MPB_NCLS 25
+#define MPB_NCLS 32
 #define MPB_MAX_LEN 1023          // cap of the widest class is 1024 = max_len + 1 rows
 
 struct MpbClass { int cap, G, R; };
 
-#define MPB_CLASS_TABLE                                                                     \
-    { {2,1,2},{3,1,3},{4,1,4},{5,1,5},{6,1,6},{7,1,7},{8,1,8},{9,1,9},{10,1,10},            \
-      {12,1,12},{14,1,14},{16,1,16},{20,2,10},{24,2,12},{32,2,16},                          \
-      {48,4,12},{64,4,16},{96,8,12},{128,8,16},{192,16,12},{256,16,16},                     \
-      {384,32,12},{512,32,16},{768,64,12},{1024,64,16} }
+// X(id, R, G): the single list the class table AND the kernel's dispatch switch are generated from
+#define MPB_CLASSES(X)                                                                       \
+    X(0, 2, 1) X(1, 3, 1) X(2, 4, 1) X(3, 5, 1) X(4, 6, 1) X(5, 7, 1) X(6, 8, 1) X(7, 9, 1)  \
+    X(8, 10, 1) X(9, 12, 1) X(10, 14, 1) X(11, 16, 1)                                        \
+    X(12, 10, 2) X(13, 12, 2) X(14, 14, 2) X(15, 16, 2)                                      \
+    X(16, 10, 4) X(17, 12, 4) X(18, 14, 4) X(19, 16, 4)                                      \
+    X(20, 9, 8) X(21, 10, 8) X(22, 11, 8) X(23, 12, 8) X(24, 14, 8) X(25, 16, 8)             \
+    X(26, 10, 16) X(27, 12, 16) X(28, 16, 16)                                                \
+    X(29, 12, 32) X(30, 16, 32) X(31, 16, 64)
+
+#define MPB_CLASS_ENTRY(ID, RR, GG) {(RR) * (GG), GG, RR},
+#define MPB_CLASS_TABLE { MPB_CLASSES(MPB_CLASS_ENTRY) }
 
 // reads handled by one prepass / scatter block (one thread per read in the ranking step)
 #define MPB_PRE_READS 256

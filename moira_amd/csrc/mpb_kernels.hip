@@ -31,8 +31,9 @@
 
 #pragma clang fp contract(off)
 
-// 4 KB {1-p, p'} LUT in LDS (dynamic shared memory, filled by k_dp, read by the class bodies)
-extern __shared__ double2 mpb_s_lut[];
+// 4 KB {1-p, p'} LUT in LDS.  Module-scope static LDS: the class bodies (non-inlined functions)
+// address it at a link-time constant, so a lookup is one SDWA shift (byte select * 16) + ds_read_b128.
+__shared__ double2 mpb_s_lut[256];
 
 namespace {
 
@@ -304,6 +305,32 @@ __device__ __forceinline__ void dp_dword(double (&v)[R], uint32_t w, bool leader
     for (int t = 0; t < 4; t++) dp_step<R, G, FMA>(v, mpb_s_lut[(w >> (8 * t)) & 0xffu], leader);
 }
 
+// 16 bases.  Narrow bodies are unrolled completely; wide ones loop over the 4 dwords so that the
+// LUT entries in flight (registers) and the code size stay bounded.
+template <int R, int G, bool FMA>
+__device__ __forceinline__ void dp_chunk_compact(double (&v)[R], const uint4 x, bool leader)
+{
+    uint32_t w0 = x.x, w1 = x.y, w2 = x.z, w3 = x.w;
+#pragma unroll 1
+    for (int d = 0; d < 4; d++) {
+        dp_dword<R, G, FMA>(v, w0, leader);
+        w0 = w1; w1 = w2; w2 = w3;
+    }
+}
+
+template <int R, int G, bool FMA>
+__device__ __forceinline__ void dp_chunk(double (&v)[R], const uint4 x, bool leader)
+{
+    if (R <= 8) {
+        dp_dword<R, G, FMA>(v, x.x, leader);
+        dp_dword<R, G, FMA>(v, x.y, leader);
+        dp_dword<R, G, FMA>(v, x.z, leader);
+        dp_dword<R, G, FMA>(v, x.w, leader);
+    } else {
+        dp_chunk_compact<R, G, FMA>(v, x, leader);
+    }
+}
+
 // Register budget of the DP kernel: 4 waves per SIMD = at most 128 VGPRs per lane.
 #ifndef MPB_DP_WAVES_PER_EU
 #define MPB_DP_WAVES_PER_EU 4
@@ -355,6 +382,10 @@ __device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_
     // consumed while it is still resident instead of being re-fetched 16 bytes at a time.
     const int my_nch = (li + 15) >> 4;             // this lane's own 16-byte chunks
     const int nsc = (nch + 3) >> 2;                // wave-uniform 64-byte super-chunks
+    int nfull = li >> 4;                           // chunks with all 16 bases valid ...
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nfull = min(nfull, __shfl_xor(nfull, off));
+    nfull = __builtin_amdgcn_readfirstlane(nfull); // ... in EVERY lane of the wave: no masking needed
     uint4 cur[4], nxt[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -368,19 +399,20 @@ __device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_
             nxt[p] = make_uint4(0, 0, 0, 0);
             if (c < my_nch) nxt[p] = *reinterpret_cast<const uint4 *>(row + c * 16);
         }
-        const int pmax = min(4, nch - sc * 4);     // wave-uniform
+        if (sc * 4 + 4 <= nfull) {
+            // fast path: 64 valid bases in every lane
+#pragma unroll
+            for (int p = 0; p < 4; p++) dp_chunk<R, G, FMA>(v, cur[p], leader);
+        } else {
+            const int pmax = min(4, nch - sc * 4); // wave-uniform
 #pragma unroll 1
-        for (int p = 0; p < pmax; p++) {
-            const uint4 x = cur[0];
-            cur[0] = cur[1]; cur[1] = cur[2]; cur[2] = cur[3];   // rotate: keeps every index static
-            const int nv = li - (sc * 4 + p) * 16; // may be <= 0 for reads shorter than the tile's longest
-            uint32_t w0 = mask_dword(x.x, nv), w1 = mask_dword(x.y, nv - 4),
-                     w2 = mask_dword(x.z, nv - 8), w3 = mask_dword(x.w, nv - 12);
-            // 4 bases per trip: bounds the LUT entries in flight (register budget) and the code size
-#pragma unroll 1
-            for (int d = 0; d < 4; d++) {
-                dp_dword<R, G, FMA>(v, w0, leader);
-                w0 = w1; w1 = w2; w2 = w3;
+            for (int p = 0; p < pmax; p++) {
+                uint4 x = cur[0];
+                cur[0] = cur[1]; cur[1] = cur[2]; cur[2] = cur[3];   // rotate: keeps every index static
+                const int nv = li - (sc * 4 + p) * 16;   // may be <= 0 for reads shorter than the tile's longest
+                x.x = mask_dword(x.x, nv); x.y = mask_dword(x.y, nv - 4);
+                x.z = mask_dword(x.z, nv - 8); x.w = mask_dword(x.w, nv - 12);
+                dp_chunk_compact<R, G, FMA>(v, x, leader);
             }
         }
 #pragma unroll
@@ -464,12 +496,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(const DpArgs *_
         const int cnt = tb->count[c];
         switch (c) {
 #define MPB_CASE(ID, RR, GG) case ID: dp_tile<RR, GG, FMA>(A, pc, cnt, lt); break;
-            MPB_CASE(0, 2, 1) MPB_CASE(1, 3, 1) MPB_CASE(2, 4, 1) MPB_CASE(3, 5, 1) MPB_CASE(4, 6, 1)
-            MPB_CASE(5, 7, 1) MPB_CASE(6, 8, 1) MPB_CASE(7, 9, 1) MPB_CASE(8, 10, 1) MPB_CASE(9, 12, 1)
-            MPB_CASE(10, 14, 1) MPB_CASE(11, 16, 1) MPB_CASE(12, 10, 2) MPB_CASE(13, 12, 2)
-            MPB_CASE(14, 16, 2) MPB_CASE(15, 12, 4) MPB_CASE(16, 16, 4) MPB_CASE(17, 12, 8)
-            MPB_CASE(18, 16, 8) MPB_CASE(19, 12, 16) MPB_CASE(20, 16, 16) MPB_CASE(21, 12, 32)
-            MPB_CASE(22, 16, 32) MPB_CASE(23, 12, 64) MPB_CASE(24, 16, 64)
+            MPB_CLASSES(MPB_CASE)
 #undef MPB_CASE
         default: break;
         }
@@ -568,9 +595,9 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
     DpArgs *dA = reinterpret_cast<DpArgs *>(ws.dp_args);
     hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
     if (prm.flags & 2u)
-        hipLaunchKernelGGL((k_dp<true, false>), dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables, ws.perm);
+        hipLaunchKernelGGL((k_dp<true, false>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables, ws.perm);
     else
-        hipLaunchKernelGGL((k_dp<false, false>), dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables, ws.perm);
+        hipLaunchKernelGGL((k_dp<false, false>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables, ws.perm);
 }
 
 void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
@@ -588,9 +615,9 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
     hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
     const int blocks = 512;
     if (prm.flags & 2u)
-        hipLaunchKernelGGL((k_dp<true, true>), dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables2, ws.ovf_list);
+        hipLaunchKernelGGL((k_dp<true, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list);
     else
-        hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), MPB_LUT_BYTES, s, dA, ws.lut, ws.tables2, ws.ovf_list);
+        hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list);
 }
 
 void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hipStream_t s)
