@@ -218,3 +218,28 @@ def test_config2_full_size_properties(eng, oracle):
         assert same(ee1[sl], ee) and np.array_equal(ns1[sl], ns) and np.array_equal(ps1[sl], ps)
     for b in (d_q, d_ee, d_ns, d_pass):
         b.free()
+
+
+def test_length_bucketed_layout_config5(eng, oracle):
+    """BASELINE config 5: mixed 50-600 bp, length-bucketed (one padded matrix per 64-bp bucket)."""
+    from moira_amd.buckets import filter_matrix_bucketed, filter_bucketed, bucket_of
+    q, lens = oracle.synth_fill(40000, 608, min_len=50, max_len=600, seed=5)
+    ee, ns, ps, _ = oracle.filter_batch(q, lens=lens, threads=8)
+    e2, n2, p2 = filter_matrix_bucketed(eng, q, lens)
+    assert same(e2, ee) and np.array_equal(n2, ns) and np.array_equal(p2, ps.astype(bool))
+    assert set(np.unique(bucket_of(lens))) == set(range(64, 641, 64))
+    # list-of-reads entry (what a parser hands over)
+    sub = range(0, 600)
+    seqs = ["".join("N" if v == 0 else "A" for v in q[i, :lens[i]]) for i in sub]
+    quals = [[int(v) if v else 20 for v in q[i, :lens[i]]] for i in sub]
+    e3, n3, p3 = filter_bucketed(eng, seqs, quals)
+    assert same(e3, ee[:600]) and np.array_equal(n3, ns[:600]) and np.array_equal(p3, ps[:600].astype(bool))
+
+
+def test_sharded_entry_single_rank(eng, oracle):
+    from moira_amd.shard import filter_sharded, engine_filter_fn
+    q, lens = oracle.synth_fill(5000, 256, fixed_len=250, seed=1)
+    ee, ns, ps, _ = oracle.filter_batch(q, lens=lens, threads=8)
+    e, n_, p, totals = filter_sharded(q, lens, engine_filter_fn(eng), dist=None)
+    assert same(e, ee) and np.array_equal(n_, ns) and np.array_equal(p, ps.astype(bool))
+    assert totals == (int(ps.sum()), 5000 - int(ps.sum()))
