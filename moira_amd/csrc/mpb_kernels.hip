@@ -45,9 +45,11 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // k_prepass
 // ------------------------------------------------------------------------------------------
 // The matrix is walked as a flat stream of 16-byte chunks, one chunk per lane per iteration, so
-// every wave-instruction loads 1 KiB of consecutive bytes.  Per byte: one ds_read_b128 from a
-// 256-entry float4 LUT {p, p(1-p), p(1-p)(1-2p), ambiguity weight} and two packed f32 adds.
-// Chunk partials go through LDS and are summed per read in a fixed order (deterministic).
+// every wave-instruction loads 1 KiB of consecutive bytes.  Per byte: one ds_read_b64 from a
+// 256-entry float2 LUT {p, p(1-p)}, one packed f32 add (mu, var) and one fma (sum of p*p(1-p), from
+// which the third cumulant is var - 2*that).  Ambiguous bytes carry a large marker in the second
+// component; a chunk whose sum shows a marker (rare) is redone byte by byte.  Chunk partials go
+// through LDS and are summed per read in a fixed order (deterministic).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t mask_dword(uint32_t w, int nvalid_bytes)
@@ -58,7 +60,18 @@ __device__ __forceinline__ uint32_t mask_dword(uint32_t w, int nvalid_bytes)
     return w & ((1u << (8 * nvalid_bytes)) - 1u);
 }
 
+__device__ __forceinline__ uint32_t fill_dword(uint32_t w, int nvalid_bytes)
+{
+    // keep the low `nvalid_bytes` bytes (0..4) of w, set the others to 0xFE
+    if (nvalid_bytes >= 4) return w;
+    if (nvalid_bytes <= 0) return 0xFEFEFEFEu;
+    const uint32_t m = (1u << (8 * nvalid_bytes)) - 1u;
+    return (w & m) | (0xFEFEFEFEu & ~m);
+}
+
 #define MPB_PRE_SUB 320      // chunks per wave sub-batch (5 KiB of float4 partials per wave)
+#define MPB_MARK_UPPER 64.0f    // second LUT component of 'N' (16 real p(1-p) sum to <= 4)
+#define MPB_MARK_LOWER 2048.0f  // ... of 'n' (> 16 * 64)
 
 __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, int64_t n,
                                                  int64_t stride, const int32_t *__restrict__ len,
@@ -66,16 +79,15 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                                                  int32_t *__restrict__ blockhist,
                                                  int32_t *__restrict__ ns_out)
 {
-    __shared__ float4 s_tab[256];
+    __shared__ float2 s_tab[256];
     __shared__ float4 s_part[4][MPB_PRE_SUB];
     __shared__ int s_hist[MPB_NCLS];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     {
-        const bool amb0 = tid == 0, amb255 = tid == 255;
+        const bool amb = tid == 0 || tid == 255;
         float p = __builtin_amdgcn_exp2f(-0.33219281f * (float)tid);      // 10^(-q/10)
-        p = (amb0 || amb255) ? 0.0f : p;
-        const float pq = p * (1.0f - p);
-        s_tab[tid] = make_float4(p, pq, pq * (1.0f - 2.0f * p), amb0 ? 1.0f : amb255 ? 1024.0f : 0.0f);
+        p = amb ? 0.0f : p;
+        s_tab[tid] = make_float2(p, tid == 0 ? MPB_MARK_UPPER : tid == 255 ? MPB_MARK_LOWER : p * (1.0f - p));
     }
     if (tid < MPB_NCLS) s_hist[tid] = 0;
     __syncthreads();
@@ -93,26 +105,35 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             const int r = (int)(((uint32_t)g * inv) >> 20);
             const int c = g - r * cpr;
             const int64_t i = wave_row0 + rb + r;
-            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+            float mu = 0.f, var = 0.f, s3 = 0.f, amb = 0.f;
             if (i < n) {
                 const int li = len ? len[i] : prm.fixed_len;
                 const int nv = li - c * 16;
                 if (nv > 0) {
                     uint4 x = *reinterpret_cast<const uint4 *>(q + i * stride + c * 16);
-                    const uint32_t ww[4] = {mask_dword(x.x, nv), mask_dword(x.y, nv - 4),
-                                            mask_dword(x.z, nv - 8), mask_dword(x.w, nv - 12)};
+                    // bytes past the read's end become Q254 (p = 4e-26: contributes nothing)
+                    const uint32_t ww[4] = {fill_dword(x.x, nv), fill_dword(x.y, nv - 4),
+                                            fill_dword(x.z, nv - 8), fill_dword(x.w, nv - 12)};
+                    f32x2 a01 = {0.f, 0.f};
 #pragma unroll
                     for (int d = 0; d < 4; d++)
 #pragma unroll
                         for (int t = 0; t < 4; t++) {
-                            const float4 e = s_tab[(ww[d] >> (8 * t)) & 0xffu];
+                            const float2 e = s_tab[(ww[d] >> (8 * t)) & 0xffu];
                             a01 += (f32x2){e.x, e.y};
-                            a23 += (f32x2){e.z, e.w};
+                            s3 = __builtin_fmaf(e.x, e.y, s3);            // p == 0 for marked bytes
                         }
-                    if (nv < 16) a23.y -= (float)(16 - nv);               // masked-off bytes are not 'N'
+                    mu = a01.x;
+                    // second component = sum p(1-p) (< 4.1) + 64 per 'N' + 2048 per 'n': peel the markers
+                    const float n255 = floorf(a01.y * (1.0f / MPB_MARK_LOWER));
+                    const float rem = a01.y - MPB_MARK_LOWER * n255;
+                    const float nzero = floorf(rem * (1.0f / MPB_MARK_UPPER));
+                    var = rem - MPB_MARK_UPPER * nzero;
+                    amb = nzero + 1024.0f * n255;
                 }
             }
-            s_part[w][g] = make_float4(a01.x, a01.y, a23.x, a23.y);
+            const float k3 = var - 2.0f * s3;                              // sum p(1-p)(1-2p)
+            s_part[w][g] = make_float4(mu, var, k3, amb);
         }
         __syncthreads();
         // 4 lanes per read sum its chunk partials in a fixed order
@@ -157,11 +178,11 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         }
         __syncthreads();
     }
-    if (tid < MPB_NCLS) blockhist[(int64_t)blockIdx.x * MPB_NCLS + tid] = s_hist[tid];
+    if (tid < MPB_NCLS) blockhist[(int64_t)tid * gridDim.x + blockIdx.x] = s_hist[tid];   // class-major
 }
 
 // ------------------------------------------------------------------------------------------
-// k_scan: block c turns blockhist[.][c] into exclusive prefixes and writes count[c]
+// k_scan: block c turns blockhist[c][.] into exclusive prefixes and writes count[c]
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scan(int32_t *__restrict__ blockhist, int nblocks,
                                               MpbTables *__restrict__ tb)
@@ -171,7 +192,8 @@ __global__ __launch_bounds__(256) void k_scan(int32_t *__restrict__ blockhist, i
     const int seg = (nblocks + 255) / 256;
     const int b0 = tid * seg, b1 = min(nblocks, b0 + seg);
     int sum = 0;
-    for (int b = b0; b < b1; b++) sum += blockhist[(int64_t)b * MPB_NCLS + c];
+    int32_t *bh = blockhist + (int64_t)c * nblocks;     // this class's row (contiguous)
+    for (int b = b0; b < b1; b++) sum += bh[b];
     s_part[tid] = sum;
     __syncthreads();
     // Hillis-Steele inclusive scan over 256 partials
@@ -183,9 +205,8 @@ __global__ __launch_bounds__(256) void k_scan(int32_t *__restrict__ blockhist, i
     }
     int run = s_part[tid] - sum;   // exclusive prefix of this thread's segment
     for (int b = b0; b < b1; b++) {
-        const int64_t k = (int64_t)b * MPB_NCLS + c;
-        const int h = blockhist[k];
-        blockhist[k] = run;
+        const int h = bh[b];
+        bh[b] = run;
         run += h;
     }
     if (tid == 255) tb->count[c] = s_part[255];
@@ -256,7 +277,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
     }
     __syncthreads();
     if (valid) {
-        int off = blockhist[(int64_t)blockIdx.x * MPB_NCLS + c];
+        int off = blockhist[(int64_t)c * gridDim.x + blockIdx.x];
         for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][c];
         perm[tb->perm_base[c] + off + rank] = (int32_t)i;
     }
