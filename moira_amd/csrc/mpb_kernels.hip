@@ -286,12 +286,14 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
 // ------------------------------------------------------------------------------------------
 // k_dp
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double dpp_wave_shr1(double x)
+__device__ __forceinline__ double dpp_prev_row(double x, int keep)
 {
-    // value of lane-1 (lane 0 receives 0): two 32-bit DPP moves, wave_shr:1
+    // value of lane-1 (wave_shr:1, lane 0 reads 0 through bound_ctrl), ANDed with `keep`
+    // (0 in the first lane of every read, ~0 elsewhere).  Written so that the DPP-combine pass can
+    // fold shift and mask into one v_and_b32_dpp per 32-bit half.
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true) & keep;
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true) & keep;
     return __hiloint2double(hi, lo);
 }
 
@@ -306,13 +308,10 @@ __device__ __forceinline__ double cell(double a, double v, double b, double w)
 
 // one base: advance the running vector by (a,b)
 template <int R, int G, bool FMA>
-__device__ __forceinline__ void dp_step(double (&v)[R], const double2 ab, const bool leader)
+__device__ __forceinline__ void dp_step(double (&v)[R], const double2 ab, const int keep)
 {
     double cin = 0.0;
-    if (G > 1) {
-        cin = dpp_wave_shr1(v[R - 1]);
-        cin = leader ? 0.0 : cin;
-    }
+    if (G > 1) cin = dpp_prev_row(v[R - 1], keep);
 #pragma unroll
     for (int r = R - 1; r >= 1; r--) v[r] = cell<FMA>(ab.x, v[r], ab.y, v[r - 1]);
     if (G > 1) v[0] = cell<FMA>(ab.x, v[0], ab.y, cin);
@@ -320,35 +319,36 @@ __device__ __forceinline__ void dp_step(double (&v)[R], const double2 ab, const 
 }
 
 template <int R, int G, bool FMA>
-__device__ __forceinline__ void dp_dword(double (&v)[R], uint32_t w, bool leader)
+__device__ __forceinline__ void dp_dword(double (&v)[R], uint32_t w, int keep)
 {
 #pragma unroll
-    for (int t = 0; t < 4; t++) dp_step<R, G, FMA>(v, mpb_s_lut[(w >> (8 * t)) & 0xffu], leader);
+    for (int t = 0; t < 4; t++) dp_step<R, G, FMA>(v, mpb_s_lut[(w >> (8 * t)) & 0xffu], keep);
 }
 
 // 16 bases.  Narrow bodies are unrolled completely; wide ones loop over the 4 dwords so that the
 // LUT entries in flight (registers) and the code size stay bounded.
 template <int R, int G, bool FMA>
-__device__ __forceinline__ void dp_chunk_compact(double (&v)[R], const uint4 x, bool leader)
+__device__ __forceinline__ void dp_chunk_compact(double (&v)[R], const uint4 x, int keep)
 {
     uint32_t w0 = x.x, w1 = x.y, w2 = x.z, w3 = x.w;
 #pragma unroll 1
-    for (int d = 0; d < 4; d++) {
-        dp_dword<R, G, FMA>(v, w0, leader);
-        w0 = w1; w1 = w2; w2 = w3;
+    for (int d = 0; d < 2; d++) {          // 8 bases per trip
+        dp_dword<R, G, FMA>(v, w0, keep);
+        dp_dword<R, G, FMA>(v, w1, keep);
+        w0 = w2; w1 = w3;
     }
 }
 
 template <int R, int G, bool FMA>
-__device__ __forceinline__ void dp_chunk(double (&v)[R], const uint4 x, bool leader)
+__device__ __forceinline__ void dp_chunk(double (&v)[R], const uint4 x, int keep)
 {
     if (R <= 8) {
-        dp_dword<R, G, FMA>(v, x.x, leader);
-        dp_dword<R, G, FMA>(v, x.y, leader);
-        dp_dword<R, G, FMA>(v, x.z, leader);
-        dp_dword<R, G, FMA>(v, x.w, leader);
+        dp_dword<R, G, FMA>(v, x.x, keep);
+        dp_dword<R, G, FMA>(v, x.y, keep);
+        dp_dword<R, G, FMA>(v, x.z, keep);
+        dp_dword<R, G, FMA>(v, x.w, keep);
     } else {
-        dp_chunk_compact<R, G, FMA>(v, x, leader);
+        dp_chunk_compact<R, G, FMA>(v, x, keep);
     }
 }
 
@@ -382,16 +382,25 @@ __device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_
     const int lane = lane_id();
     const int lig = lane & (G - 1);
     const bool leader = lig == 0;
+    int keep = leader ? 0 : -1;
+    asm volatile("" : "+v"(keep));        // opaque: keeps `& keep` a v_and (foldable into the DPP op), not a select
     const int slot = local_tile * RPT + lane / G;
     const bool valid = slot < count;
     const int idx = perm_cls[valid ? slot : count - 1];
     const int li = A.len ? A.len[idx] : A.prm.fixed_len;
     const uint8_t *row = A.q + (int64_t)idx * A.stride;
 
-    int nch = (li + 15) >> 4;
+    int nch = (li + 15) >> 4;             // 16-byte chunks to walk: the longest read of the tile
+    int nfull = li >> 4;                  // chunks that are complete in EVERY lane: no masking needed
+    if (A.len) {                          // (fixed-length batches: every lane has the same li)
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) nch = max(nch, __shfl_xor(nch, off));
-    nch = __builtin_amdgcn_readfirstlane(nch);      // wave-uniform trip count
+        for (int off = 32; off >= 1; off >>= 1) {
+            nch = max(nch, __shfl_xor(nch, off));
+            nfull = min(nfull, __shfl_xor(nfull, off));
+        }
+    }
+    nch = __builtin_amdgcn_readfirstlane(nch);      // wave-uniform trip counts
+    nfull = __builtin_amdgcn_readfirstlane(nfull);
 
     double v[R];
 #pragma unroll
@@ -403,10 +412,6 @@ __device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_
     // consumed while it is still resident instead of being re-fetched 16 bytes at a time.
     const int my_nch = (li + 15) >> 4;             // this lane's own 16-byte chunks
     const int nsc = (nch + 3) >> 2;                // wave-uniform 64-byte super-chunks
-    int nfull = li >> 4;                           // chunks with all 16 bases valid ...
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) nfull = min(nfull, __shfl_xor(nfull, off));
-    nfull = __builtin_amdgcn_readfirstlane(nfull); // ... in EVERY lane of the wave: no masking needed
     uint4 cur[4], nxt[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -423,17 +428,19 @@ __device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_
         if (sc * 4 + 4 <= nfull) {
             // fast path: 64 valid bases in every lane
 #pragma unroll
-            for (int p = 0; p < 4; p++) dp_chunk<R, G, FMA>(v, cur[p], leader);
+            for (int p = 0; p < 4; p++) dp_chunk<R, G, FMA>(v, cur[p], keep);
         } else {
             const int pmax = min(4, nch - sc * 4); // wave-uniform
 #pragma unroll 1
             for (int p = 0; p < pmax; p++) {
                 uint4 x = cur[0];
                 cur[0] = cur[1]; cur[1] = cur[2]; cur[2] = cur[3];   // rotate: keeps every index static
-                const int nv = li - (sc * 4 + p) * 16;   // may be <= 0 for reads shorter than the tile's longest
-                x.x = mask_dword(x.x, nv); x.y = mask_dword(x.y, nv - 4);
-                x.z = mask_dword(x.z, nv - 8); x.w = mask_dword(x.w, nv - 12);
-                dp_chunk_compact<R, G, FMA>(v, x, leader);
+                if (sc * 4 + p >= nfull) {               // wave-uniform: only ragged tail chunks are masked
+                    const int nv = li - (sc * 4 + p) * 16;   // may be <= 0 for reads shorter than the tile's longest
+                    x.x = mask_dword(x.x, nv); x.y = mask_dword(x.y, nv - 4);
+                    x.z = mask_dword(x.z, nv - 8); x.w = mask_dword(x.w, nv - 12);
+                }
+                dp_chunk_compact<R, G, FMA>(v, x, keep);
             }
         }
 #pragma unroll
