@@ -26,6 +26,30 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
          "-x", "hip"]
 
 
+CONTIG_LIB = os.path.join(HERE, "libmoira_contig.so")
+CONTIG_SRC = os.path.join(CSRC, "contig.cpp")
+CXX = os.environ.get("CXX", "g++")
+
+
+def contig_stale():
+    if not os.path.exists(CONTIG_LIB):
+        return True
+    t = os.path.getmtime(CONTIG_LIB)
+    return any(os.path.getmtime(d) > t for d in (CONTIG_SRC, os.path.join(ROOT, "include", "moira_contig.h")))
+
+
+def build_contig(force=False, verbose=False):
+    """CPU-only contig construction library (g++, no HIP): north_star keeps NW on the CPU."""
+    if not force and not contig_stale():
+        return CONTIG_LIB
+    cmd = [CXX, "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-pthread", "-Wall",
+           CONTIG_SRC, "-o", CONTIG_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CONTIG_LIB
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
@@ -45,4 +69,6 @@ def build(force=False, verbose=False, extra=()):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_contig(force="--force" in sys.argv, verbose=True)
     print(LIB)
+    print(CONTIG_LIB)

@@ -1,0 +1,126 @@
+"""ctypes front-end of libmoira_contig.so (include/moira_contig.h): CPU contig construction.
+
+Mirrors the reference's Python-level interfaces (same names, argument meaning, return shapes):
+  reverse_complement(sequence, quals=None)                     moira/moira.py:1207-1235
+  nw_align(seq_1, seq_2, match, mismatch, gap)                 moira/nw_align.pyx:49 / moira.py:1238
+  make_contig(forward_aligned, forward_quals, reverse_aligned, reverse_quals, insert, deltaq,
+              consensus_qscore, qscore_cap, trim_overlap)      moira/moira.py:1376-1558
+plus contigs_batch(): the paired half of process_data for a whole chunk on all host cores.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmoira_contig.so")
+CONSENSUS = {"best": 0, "sum": 1, "posterior": 2}
+_lib = None
+
+
+class LengthMismatchError(Exception):
+    def __str__(self):
+        return "Sequence and qualities are of different lengths."
+
+
+def load():
+    global _lib
+    if _lib is None:
+        from . import build as _build
+        if _build.contig_stale():
+            _build.build_contig()
+        L = C.CDLL(LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int32
+        L.mct_last_error.restype = C.c_char_p
+        L.mct_reverse_complement.argtypes = [C.c_char_p, vp, i32, vp, vp]
+        L.mct_nw_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.mct_make_contig.argtypes = [C.c_char_p, vp, C.c_char_p, vp, i32, i32, i32, i32, i32, i32,
+                                      vp, vp, vp, vp, vp, vp]
+        L.mct_contigs_batch.argtypes = [C.c_int64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
+                                        i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc:
+        raise ValueError(load().mct_last_error().decode())
+
+
+def reverse_complement(sequence, quals=None):
+    L = load()
+    s = str(sequence).encode()
+    out = C.create_string_buffer(len(s) + 1)
+    if quals:
+        q = np.ascontiguousarray(list(quals), dtype=np.int32)
+        if len(q) != len(s.replace(b"-", b"").replace(b".", b"")):
+            raise LengthMismatchError()
+        oq = np.empty(len(q), np.int32)
+        _check(L.mct_reverse_complement(s, q.ctypes.data, len(s), C.addressof(out), oq.ctypes.data))
+        return out.value.decode(), [int(x) for x in oq]
+    _check(L.mct_reverse_complement(s, None, len(s), C.addressof(out), None))
+    return out.value.decode()
+
+
+def nw_align(seq_1, seq_2, match, mismatch, gap):
+    L = load()
+    a, b = str(seq_1).encode(), str(seq_2).encode()
+    n = len(a) + len(b) + 1
+    o1, o2 = C.create_string_buffer(n), C.create_string_buffer(n)
+    alen, score = C.c_int32(), C.c_int32()
+    _check(L.mct_nw_align(a, len(a), b, len(b), int(match), int(mismatch), int(gap),
+                          C.addressof(o1), C.addressof(o2), C.addressof(alen), C.addressof(score)))
+    return o1.value.decode(), o2.value.decode(), score.value
+
+
+def make_contig(forward_aligned, forward_quals, reverse_aligned, reverse_quals, insert, deltaq,
+                consensus_qscore, qscore_cap, trim_overlap):
+    L = load()
+    if consensus_qscore not in CONSENSUS:
+        raise ValueError('consensus_qscore must be "best", "sum" or "posterior".')
+    fa, ra = str(forward_aligned).encode(), str(reverse_aligned).encode()
+    fq = np.ascontiguousarray(list(forward_quals), dtype=np.int32)
+    rq = np.ascontiguousarray(list(reverse_quals), dtype=np.int32)
+    if len(fa.replace(b"-", b"")) != len(fq) or len(ra.replace(b"-", b"")) != len(rq):
+        raise LengthMismatchError()
+    if len(fa) != len(ra):
+        raise ValueError("aligned reads differ in length")
+    n = len(fa)
+    contig = C.create_string_buffer(n + 1)
+    cq = np.empty(max(n, 1), np.int32)
+    clen, ov, gaps, mism = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    _check(L.mct_make_contig(fa, fq.ctypes.data, ra, rq.ctypes.data, n, int(insert), int(deltaq),
+                             CONSENSUS[consensus_qscore], int(qscore_cap), 1 if trim_overlap else 0,
+                             C.addressof(contig), cq.ctypes.data, C.addressof(clen), C.addressof(ov),
+                             C.addressof(gaps), C.addressof(mism)))
+    m = clen.value
+    return contig.raw[:m].decode(), [int(x) for x in cq[:m]], ov.value, gaps.value, mism.value
+
+
+def contigs_batch(fwd_seqs, fwd_quals, rev_seqs, rev_quals, match=1, mismatch=-1, gap=-2, insert=20,
+                  deltaq=6, consensus_qscore="best", qscore_cap=40, trim_overlap=False, threads=None):
+    """Paired half of process_data (moira/moira.py:789-801) for a chunk.
+    Returns (contigs list[str], quals int32[n, cap], lens, overlap, gaps, mismatches)."""
+    L = load()
+    n = len(fwd_seqs)
+    threads = threads or (os.cpu_count() or 1)
+
+    def cat(seqs, quals):
+        off = np.zeros(n + 1, np.int64)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        s = "".join(seqs).encode()
+        q = np.fromiter((v for ql in quals for v in ql), dtype=np.int32, count=int(off[-1]))
+        return s, q, off
+    fs, fq, fo = cat(fwd_seqs, fwd_quals)
+    rs, rq, ro = cat(rev_seqs, rev_quals)
+    cap = int(max((fo[1:] - fo[:-1]) + (ro[1:] - ro[:-1]), default=0)) + 1
+    contigs = np.zeros((n, cap), np.uint8)
+    cq = np.zeros((n, cap), np.int32)
+    clen, ov, gaps, mism = (np.zeros(n, np.int32) for _ in range(4))
+    _check(L.mct_contigs_batch(n, fs, fq.ctypes.data, fo.ctypes.data, rs, rq.ctypes.data, ro.ctypes.data,
+                               match, mismatch, gap, insert, deltaq, CONSENSUS[consensus_qscore],
+                               qscore_cap, 1 if trim_overlap else 0, threads, cap,
+                               contigs.ctypes.data, cq.ctypes.data, clen.ctypes.data, ov.ctypes.data,
+                               gaps.ctypes.data, mism.ctypes.data))
+    seqs = [contigs[i, :clen[i]].tobytes().decode() for i in range(n)]
+    return seqs, cq, clen, ov, gaps, mism

@@ -1,0 +1,268 @@
+// contig.cpp -- CPU contig construction (libmoira_contig.so, C ABI in include/moira_contig.h).
+//
+// The build's own implementation of the reference's paired-read front end, which north_star
+// keeps on the CPU: reverse complement (moira/moira.py:1207-1235), mothur-style Needleman-Wunsch
+// (moira/nw_align.pyx:49-201) and consensus building (moira/moira.py:1376-1558).  Results must be
+// identical to the reference's (pinned by its KATs and golden paired outputs), so tie-breaking
+// order, the 3' overlap fix-up and the odd "score = sum of path cells" definition are kept.
+
+#include "../../include/moira_contig.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+
+extern "C" const char *mct_last_error(void) { return g_err; }
+
+// ref: moira/moira.py:1210-1213
+static char complement_of(char b)
+{
+    switch (b) {
+    case 'A': return 'T'; case 'C': return 'G'; case 'T': return 'A'; case 'G': return 'C';
+    case 'N': return 'N'; case 'W': return 'W'; case 'S': return 'S'; case 'R': return 'Y';
+    case 'Y': return 'R'; case 'M': return 'K'; case 'K': return 'M'; case 'B': return 'V';
+    case 'V': return 'B'; case 'D': return 'H'; case 'H': return 'D'; case '-': return '-';
+    case '.': return '.';
+    default: return 0;
+    }
+}
+
+extern "C" int mct_reverse_complement(const char *seq, const int32_t *quals, int32_t len,
+                                      char *out_seq, int32_t *out_quals)
+{
+    if (len < 0 || (len > 0 && (!seq || !out_seq))) return fail(MCT_E_INVALID, "bad arguments");
+    for (int i = 0; i < len; i++) {
+        const char c = complement_of(seq[len - 1 - i]);
+        if (!c) return fail(MCT_E_BASE, "\"%c\" is not a recognizable IUPAC-coded base.", seq[len - 1 - i]);
+        out_seq[i] = c;
+    }
+    if (quals && out_quals)
+        for (int i = 0; i < len; i++) out_quals[i] = quals[len - 1 - i];
+    return MCT_OK;
+}
+
+namespace {
+
+enum : uint8_t { PTR_DIAG = 0, PTR_UP = 1, PTR_LEFT = 2 };   // (-1,-1), (-1,0), (0,-1)
+
+struct NwScratch {
+    std::vector<int32_t> score;
+    std::vector<uint8_t> ptr;
+};
+
+// ref: moira/nw_align.pyx:49-201.  Row index i walks seq1 (with the leading pad), column j seq2.
+int nw_align_impl(const char *s1, int n1, const char *s2, int n2, int match, int mismatch, int gap,
+                  char *aln1, char *aln2, int32_t *aln_len, int32_t *score_out, NwScratch &sc)
+{
+    const int L1 = n1 + 1, L2 = n2 + 1;
+    sc.score.assign((size_t)L1 * L2, 0);
+    sc.ptr.assign((size_t)L1 * L2, PTR_UP);
+    int32_t *S = sc.score.data();
+    uint8_t *P = sc.ptr.data();
+    // first column points up, first row points left, both scored 0 (refine_overlap, :64-76)
+    for (int j = 1; j < L2; j++) P[j] = PTR_LEFT;
+    for (int i = 1; i < L1; i++) {
+        const char a = s1[i - 1];
+        int32_t *row = S + (size_t)i * L2;
+        const int32_t *prev = row - L2;
+        uint8_t *prow = P + (size_t)i * L2;
+        for (int j = 1; j < L2; j++) {
+            const int diag = prev[j - 1] + (a == s2[j - 1] ? match : mismatch);
+            const int up = prev[j] + gap;
+            const int left = row[j - 1] + gap;
+            // tie-break order of :96-113: diag >= up, diag >= left, up >= left
+            if (diag >= up) {
+                if (diag >= left) { row[j] = diag; prow[j] = PTR_DIAG; }
+                else { row[j] = left; prow[j] = PTR_LEFT; }
+            } else {
+                if (up >= left) { row[j] = up; prow[j] = PTR_UP; }
+                else { row[j] = left; prow[j] = PTR_LEFT; }
+            }
+        }
+    }
+    // 3' overlap fix-up (:155-201): last maximum (>=) of the last column and of the last row
+    int best_col_score = -10000, best_col_idx = 0;
+    for (int i = 0; i < L1; i++) {
+        const int c = S[(size_t)i * L2 + (L2 - 1)];
+        if (c >= best_col_score) { best_col_score = c; best_col_idx = i; }
+    }
+    int best_row_score = -10000, best_row_idx = 0;
+    for (int j = 0; j < L2; j++) {
+        const int c = S[(size_t)(L1 - 1) * L2 + j];
+        if (c >= best_row_score) { best_row_score = c; best_row_idx = j; }
+    }
+    if (best_col_idx == L1 - 1 && best_row_idx == L2 - 1) {
+        // nothing to do
+    } else if (best_col_score > best_row_score) {
+        for (int i = L1 - 1; i > best_col_idx; i--) P[(size_t)i * L2 + (L2 - 1)] = PTR_UP;
+    } else {
+        for (int j = L2 - 1; j > best_row_idx; j--) P[(size_t)(L1 - 1) * L2 + j] = PTR_LEFT;
+    }
+    // traceback (:129-150), filled backwards then reversed
+    int i = L1 - 1, j = L2 - 1, k = 0;
+    int32_t score = 0;
+    while (i > 0 || j > 0) {
+        const uint8_t p = P[(size_t)i * L2 + j];
+        score += S[(size_t)i * L2 + j];
+        const bool mv_i = (p == PTR_DIAG || p == PTR_UP), mv_j = (p == PTR_DIAG || p == PTR_LEFT);
+        aln1[k] = mv_i ? s1[i - 1] : '-';
+        aln2[k] = mv_j ? s2[j - 1] : '-';
+        k++;
+        if (mv_i) i--;
+        if (mv_j) j--;
+    }
+    for (int a = 0, b = k - 1; a < b; a++, b--) {
+        char t = aln1[a]; aln1[a] = aln1[b]; aln1[b] = t;
+        t = aln2[a]; aln2[a] = aln2[b]; aln2[b] = t;
+    }
+    aln1[k] = 0; aln2[k] = 0;
+    *aln_len = k;
+    *score_out = score;
+    return MCT_OK;
+}
+
+inline double qual2prob(int q) { return pow(10, q / (-10.0)); }                       // moira.py:1392-1393
+inline int prob2qual(double p) { return (int)floor(-10 * log10(p)); }                 // moira.py:1395-1396
+
+// ref: moira/moira.py:1376-1558
+int make_contig_impl(const char *fa, const int32_t *fq, const char *ra, const int32_t *rq, int n,
+                     int insert, int deltaq, int consensus, int qcap, int trim,
+                     char *contig, int32_t *cq, int32_t *clen, int32_t *overlap, int32_t *gaps_out,
+                     int32_t *mism_out, std::vector<int32_t> &fqa, std::vector<int32_t> &rqa)
+{
+    if (insert <= 0) return fail(MCT_E_INVALID, "insert must be a positive integer");
+    if (deltaq <= 0) return fail(MCT_E_INVALID, "deltaq must be a positive integer");
+    if (qcap < 0) return fail(MCT_E_INVALID, "qscore_cap must be a non-negative integer");
+    if (consensus < 0 || consensus > 2) return fail(MCT_E_INVALID, "consensus_qscore must be \"best\", \"sum\" or \"posterior\".");
+    // qualities laid onto the alignment (-1 marks a gap column), :1421-1440
+    fqa.assign(n, -1); rqa.assign(n, -1);
+    int u = 0;
+    for (int k = 0; k < n; k++) if (fa[k] != '-') fqa[k] = fq[u++];
+    u = 0;
+    for (int k = 0; k < n; k++) if (ra[k] != '-') rqa[k] = rq[u++];
+    int fstart = -1, rstart = -1, fend = -1, rend = -1;
+    for (int k = 0; k < n; k++) { if (fa[k] != '-') { if (fstart < 0) fstart = k; fend = k; } }
+    for (int k = 0; k < n; k++) { if (ra[k] != '-') { if (rstart < 0) rstart = k; rend = k; } }
+    if (fstart < 0 || rstart < 0) return fail(MCT_E_INVALID, "an aligned read has no bases");
+    int ostart, oend; bool reversed;
+    if (fstart < rstart) { ostart = rstart; oend = fend; reversed = false; }     // :1463-1470
+    else { ostart = fstart; oend = rend; reversed = true; }
+    int m = 0, gaps = 0, mism = 0;
+    auto push = [&](char b, int q) { contig[m] = b; cq[m] = q; m++; };
+    for (int k = 0; k < n; k++) {
+        if (k < ostart) {
+            if (!trim) { if (reversed) push(ra[k], rqa[k]); else push(fa[k], fqa[k]); }
+        } else if (k > oend) {
+            if (!trim) { if (reversed) push(fa[k], fqa[k]); else push(ra[k], rqa[k]); }
+        } else if (fa[k] == '-') {                                                 // :1498-1507
+            gaps++;
+            if (consensus == MCT_CONSENSUS_POSTERIOR) push('N', 2);
+            else if (rqa[k] > insert) push(ra[k], rqa[k]);
+        } else if (ra[k] == '-') {                                                 // :1509-1518
+            gaps++;
+            if (consensus == MCT_CONSENSUS_POSTERIOR) push('N', 2);
+            else if (fqa[k] > insert) push(fa[k], fqa[k]);
+        } else if (fa[k] == ra[k]) {                                               // :1520-1531
+            int q;
+            if (consensus == MCT_CONSENSUS_SUM) q = fqa[k] + rqa[k];
+            else if (consensus == MCT_CONSENSUS_POSTERIOR) {
+                const double p1 = qual2prob(fqa[k]), p2 = qual2prob(rqa[k]);
+                q = prob2qual((p1 * p2 / 3) / (1 - p1 - p2 + (4 * p1 * p2 / 3)));
+            } else q = fqa[k] >= rqa[k] ? fqa[k] : rqa[k];
+            push(fa[k], q);
+        } else {                                                                   // :1533-1556
+            mism++;
+            if (consensus != MCT_CONSENSUS_POSTERIOR) {
+                const int d = fqa[k] - rqa[k];
+                if ((d < 0 ? -d : d) < deltaq) push('N', 2);
+                else if (fqa[k] >= rqa[k]) push(fa[k], fqa[k]);
+                else push(ra[k], rqa[k]);
+            } else if (fqa[k] == rqa[k]) {
+                push('N', 2);
+            } else {
+                double p1, p2; char b;
+                if (fqa[k] > rqa[k]) { p1 = qual2prob(fqa[k]); p2 = qual2prob(rqa[k]); b = fa[k]; }
+                else { p2 = qual2prob(fqa[k]); p1 = qual2prob(rqa[k]); b = ra[k]; }
+                push(b, prob2qual(p1 * (1 - p2 / 3) / (p1 + p2 - (4 * p1 * p2 / 3))));
+            }
+        }
+    }
+    if (qcap) for (int k = 0; k < m; k++) if (!(cq[k] < qcap)) cq[k] = qcap;      // :1555-1556
+    *clen = m; *overlap = oend - ostart; *gaps_out = gaps; *mism_out = mism;
+    return MCT_OK;
+}
+
+}  // namespace
+
+extern "C" int mct_nw_align(const char *seq1, int32_t len1, const char *seq2, int32_t len2,
+                            int32_t match, int32_t mismatch, int32_t gap, char *aln1, char *aln2,
+                            int32_t *aln_len, int32_t *score)
+{
+    if (len1 < 0 || len2 < 0 || !aln1 || !aln2 || !aln_len || !score) return fail(MCT_E_INVALID, "bad arguments");
+    NwScratch sc;
+    return nw_align_impl(seq1, len1, seq2, len2, match, mismatch, gap, aln1, aln2, aln_len, score, sc);
+}
+
+extern "C" int mct_make_contig(const char *fa, const int32_t *fq, const char *ra, const int32_t *rq,
+                               int32_t aln_len, int32_t insert, int32_t deltaq, int32_t consensus,
+                               int32_t qscore_cap, int32_t trim_overlap, char *contig,
+                               int32_t *contig_quals, int32_t *contig_len, int32_t *overlap_length,
+                               int32_t *gaps, int32_t *mismatches)
+{
+    if (aln_len < 0 || !fa || !ra || !contig || !contig_quals) return fail(MCT_E_INVALID, "bad arguments");
+    std::vector<int32_t> a, b;
+    return make_contig_impl(fa, fq, ra, rq, aln_len, insert, deltaq, consensus, qscore_cap, trim_overlap,
+                            contig, contig_quals, contig_len, overlap_length, gaps, mismatches, a, b);
+}
+
+extern "C" int mct_contigs_batch(int64_t n, const char *fwd_seq, const int32_t *fwd_qual, const int64_t *fwd_off,
+                                 const char *rev_seq, const int32_t *rev_qual, const int64_t *rev_off,
+                                 int32_t match, int32_t mismatch, int32_t gap, int32_t insert, int32_t deltaq,
+                                 int32_t consensus, int32_t qscore_cap, int32_t trim_overlap, int32_t threads,
+                                 int32_t cap, char *contigs, int32_t *contig_quals, int32_t *contig_len,
+                                 int32_t *overlap_length, int32_t *gaps, int32_t *mismatches)
+{
+    if (n < 0 || cap <= 0) return fail(MCT_E_INVALID, "bad arguments");
+    if (threads < 1) threads = 1;
+    if (threads > n && n > 0) threads = (int32_t)n;
+    std::vector<int> rc(threads, MCT_OK);
+    std::vector<std::string> msgs(threads);
+    auto work = [&](int t) {
+        NwScratch sc;
+        std::vector<char> rseq, a1, a2;
+        std::vector<int32_t> rq, qa, qb;
+        for (int64_t i = t; i < n; i += threads) {
+            const int l1 = (int)(fwd_off[i + 1] - fwd_off[i]), l2 = (int)(rev_off[i + 1] - rev_off[i]);
+            rseq.resize(l2 + 1); rq.resize(l2 + 1); a1.resize(l1 + l2 + 2); a2.resize(l1 + l2 + 2);
+            int r = mct_reverse_complement(rev_seq + rev_off[i], rev_qual + rev_off[i], l2, rseq.data(), rq.data());
+            int32_t alen = 0, score = 0, clen = 0;
+            if (!r) r = nw_align_impl(fwd_seq + fwd_off[i], l1, rseq.data(), l2, match, mismatch, gap,
+                                      a1.data(), a2.data(), &alen, &score, sc);
+            if (!r && alen > cap) r = fail(MCT_E_BUFFER, "contig %lld needs %d > %d slots", (long long)i, alen, cap);
+            if (!r) r = make_contig_impl(a1.data(), fwd_qual + fwd_off[i], a2.data(), rq.data(), alen, insert,
+                                         deltaq, consensus, qscore_cap, trim_overlap,
+                                         contigs + i * (int64_t)cap, contig_quals + i * (int64_t)cap, &clen,
+                                         &overlap_length[i], &gaps[i], &mismatches[i], qa, qb);
+            if (r) { rc[t] = r; msgs[t] = g_err; return; }
+            contig_len[i] = clen;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    for (int t = 0; t < threads; t++)
+        if (rc[t]) return fail(rc[t], "%s", msgs[t].c_str());
+    return MCT_OK;
+}

@@ -159,6 +159,13 @@ def main():
             "kat3_paired_truncate200": {"seq": prd[1], "quals": prd[2], "alpha": 0.005,
                                         "ee_plus_ns": prd[3], "overlap_gaps_mismatches": list(prd[4:7])},
         }
+        kat["contig"] = {
+            "source": "moira/test/test_moira.py:50-59,119-126",
+            "seq2": ns["testSeq2"], "qual2": ns["testQual2"],
+            "rc2": [ns["testRC2"][0], ns["testRC2"][1]], "aligned": list(ns["test_aligned"]),
+            "contig": list(ns["test_contig"]),
+            "args": {"match": 1, "mismatch": -1, "gap": -2, "insert": 20, "deltaq": 6,
+                     "consensus_qscore": "best", "qscore_cap": 40, "trim_overlap": False}}
         assert fwd[3] == 0.9685179556745876 and prd[3] == 0.9643903629780557
         for k in ("kat1",):
             assert ref.calculate_errors_PB(kat[k]["seq"], kat[k]["quals"], 0.005) == (kat[k]["ee"], 0)
