@@ -1,0 +1,678 @@
+#!/usr/bin/env python3
+"""moira-compatible command line on top of the MI355X filter.
+
+    python -m moira_amd.cli --forward_fastq reads.fastq [--paired --reverse_fastq mates.fastq] ...
+
+Keeps moira.py's flags, defaults, validation messages, input handling and output files
+(moira/moira.py:581-675 parse_arguments, :678-781 check_arguments, :1058-1204 readers,
+:842-970 write_results, :264-578 main), so it is a drop-in for the script.  What changes is the
+shape of the hot loop: instead of one `process_data` task per read through a multiprocessing
+Pool (moira/moira.py:431-454), records are read in chunks, contigs for paired reads are built on
+the CPU by libmoira_contig.so (all host cores), the chunk is packed into per-length-bucket
+quality matrices and filtered on the GPU by libmoira_pb.so, and the per-read results flow into the
+same collapse / write logic.
+
+`--error_calc poisson_binomial` and `poisson_binomial_py` both run the HIP path (they are the same
+arithmetic; the reference's two names select its C or Python implementation).  `poisson` and
+`bootstrap` are evaluated on the host exactly as moira.py does (moira/moira.py:1637-1720); they
+are not the accelerated path.  `--processors` sets the CPU threads used for contig construction.
+
+Output order: with --collapse moira writes groups sorted by abundance and, inside one abundance,
+in Python-2 dict order.  That order is reproduced (moira_amd/py2dict.py) so the output files are
+byte-identical to the reference's.
+"""
+import argparse
+import bz2
+import gzip
+import io
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+from .py2dict import Py2Dict
+
+__version__ = "1.3.2-mi355x"
+CHUNK_READS = 262144
+
+
+# ---------------------------------------------------------------------------------------------
+# exceptions (names and messages of moira/moira.py:973-1055)
+# ---------------------------------------------------------------------------------------------
+class ReturnedNaNError(Exception):
+    def __init__(self, header):
+        self.header = header
+
+    def __str__(self):
+        return ("Error calculation returned NaN for sequence %s. If using a C implementation, "
+                "try switching to the python one instead." % self.header)
+
+
+class UnpairedFilesError(Exception):
+    def __init__(self, lf, lq, rf=None, rq=None):
+        self.rf, self.rq = rf, rq
+
+    def __str__(self):
+        if not self.rf and not self.rq:
+            return "You must provide at least a forward fasta and quality file"
+        return ("If reading from paired-end files, you must provide fasta and quality files for both "
+                "the forward and the reverse reads")
+
+
+class NameMismatchError(Exception):
+    def __init__(self, lfheader, lqheader, rfheader=None, rqheader=None):
+        self.h = (lfheader, lqheader, rfheader, rqheader)
+
+    def __str__(self):
+        lf, lq, rf, rq = self.h
+        if not rf:
+            return "Fasta header does not match Qfile header. Offending headers were: FASTA: %s   QFILE: %s" % (repr(lf), repr(lq))
+        if not lq:
+            return "Header mismatch. Offending headers were: forward_fastq: %s,   reverse_fastq %s" % (repr(lf), repr(rf))
+        return ("Header mismatch. Offending headers were: forward_fasta: %s   forward_qual %s   "
+                "reverse_fasta %s   reverse_qual %s" % (repr(lf), repr(lq), repr(rf), repr(rq)))
+
+
+class LengthMismatchError(Exception):
+    def __init__(self, fheader=None, ffilename=None, qfilename=None):
+        self.a = (fheader, ffilename, qfilename)
+
+    def __str__(self):
+        h, f, q = self.a
+        if None not in (h, f, q):
+            return ("Error reading sequence %s in files %s and %s. Sequence length and quality length "
+                    "do not match" % (repr(h), repr(f), repr(q)))
+        if not q:
+            return "Error reading sequence %s in file %s. Sequence length and quality length do not match" % (repr(h), repr(f))
+        return "Sequence and qualities are of different lengths."
+
+
+class EmptySeqError(Exception):
+    def __init__(self, fheader, filename):
+        self.a = (fheader, filename)
+
+    def __str__(self):
+        return "Error reading file %s. Sequence %s was empty" % (repr(self.a[1]), repr(self.a[0]))
+
+
+class EmptyQualError(Exception):
+    def __init__(self, qheader, filename):
+        self.a = (qheader, filename)
+
+    def __str__(self):
+        return "Error reading file %s. Quality %s was empty" % (repr(self.a[1]), repr(self.a[0]))
+
+
+# ---------------------------------------------------------------------------------------------
+# arguments
+# ---------------------------------------------------------------------------------------------
+def build_parser():
+    def str2bool(value):
+        return value.lower() in ("yes", "true", "t", "1")
+
+    p = argparse.ArgumentParser(description="Perform quality filtering on a set of sequences.")
+    g = p.add_argument_group("General options")
+    g.add_argument("-ff", "--forward_fasta", type=str, help="Forward fasta file (can be gzip or bzip2 compressed).")
+    g.add_argument("-fq", "--forward_qual", type=str, help="Forward qual file (can be gzip or bzip2 compressed).")
+    g.add_argument("-rf", "--reverse_fasta", type=str, help="Reverse fasta file (can be gzip or bzip2 compressed).")
+    g.add_argument("-rq", "--reverse_qual", type=str, help="Reverse qual file (can be gzip or bzip2 compressed).")
+    g.add_argument("-ffq", "--forward_fastq", type=str, help="Forward fastq file (can be gzip or bzip2 compressed).")
+    g.add_argument("-rfq", "--reverse_fastq", type=str, help="Reverse fastq file (can be gzip or bzip2 compressed).")
+    g.add_argument("-l", "--relabel", type=str,
+                   help="Generate sequential labels for the ordered sequences, with the specified string at the beginning.")
+    g.add_argument("-o", "--output_format", type=str, default="fasta", choices=("fasta", "fastq"),
+                   help="Output format: fasta with qual (and mothur name file if --collapse) or fastq.")
+    g.add_argument("-pi", "--pipeline", type=str, default="mothur", choices=("mothur", "USEARCH"),
+                   help="Make the output format compatible with the indicated analysis pipeline.")
+    g.add_argument("-op", "--output_prefix", type=str, help="Prefix for the output files")
+    g.add_argument("-oc", "--output_compression", type=str, default="none", choices=("none", "gz", "bz2"),
+                   help="Compression of the output files")
+    g.add_argument("-p", "--processors", type=int, default=1,
+                   help="Number of CPU threads for contig construction (the filter itself runs on the GPU).")
+    g.add_argument("--paired", action="store_true",
+                   help="Assemble paired-end reads and perform quality control on the resulting contig.")
+    g.add_argument("-fo", "--fastq_offset", type=int, default=33)
+    g.add_argument("--only_contig", action="store_true", help="Assemble contigs but don't perform quality control.")
+    g.add_argument("--silent", action="store_true",
+                   help="Do not print welcome, progress and goodbye messages. Warnings will still be printed.")
+    g.add_argument("--nowarnings", action="store_true", help="Do not print warning messages.")
+    g.add_argument("--doc", action="store_true", help="Print full documentation.")
+
+    c = p.add_argument_group("Contig construction options")
+    c.add_argument("-m", "--match", type=int, default=1, help="Needleman-Wunsch aligner match score.")
+    c.add_argument("-x", "--mismatch", type=int, default=-1, help="Needleman-Wunsch aligner mismatch penalty.")
+    c.add_argument("-g", "--gap", type=int, default=-2, help="Needleman-Wunsch aligner gap penalty.")
+    c.add_argument("--trim_overlap", action="store_true", help="Trim the contig to the overlapping region.")
+    c.add_argument("-i", "--insert", type=int, default=20, help="Contig constructor insert threshold.")
+    c.add_argument("-d", "--deltaq", type=int, default=6, help="Contig constructor mismatch correction deltaq threshold.")
+    c.add_argument("-q", "--consensus_qscore", type=str, default="best", choices=("best", "sum", "posterior"),
+                   help="Contig constructor consensus qscore.")
+    c.add_argument("-z", "--qscore_cap", type=int, default=40,
+                   help="Maximum consensus quality score reported by the contig constructor. Use 0 for no cap.")
+
+    f = p.add_argument_group("Sequence filtering options")
+    f.add_argument("-c", "--collapse", type=str2bool, default="True",
+                   help="Collapse identical sequences before quality control.")
+    f.add_argument("-t", "--truncate", type=int,
+                   help="Truncate sequences to a fixed length before quality control. Discard smaller sequences.")
+    f.add_argument("-mo", "--min_overlap", type=int, help="Discard contigs with less than the specified overlap length.")
+    f.add_argument("-e", "--error_calc", type=str, default="poisson_binomial",
+                   choices=("poisson_binomial", "poisson_binomial_py", "poisson", "bootstrap"),
+                   help="Error calculation method.")
+    f.add_argument("-n", "--ambigs", type=str, default="treat_as_errors",
+                   choices=("disallow", "ignore", "treat_as_errors"), help="Treatment of ambiguities.")
+    f.add_argument("-r", "--round", action="store_true",
+                   help="Round down the predicted number of errors to their nearest integer prior to filtering.")
+    eu = f.add_mutually_exclusive_group()
+    eu.add_argument("-u", "--uncert", type=float, default=0.01,
+                    help="Maximum allowed uncertainty (errors / sequence length).")
+    eu.add_argument("-me", "--maxerrors", type=float, help="Maximum allowed errors per sequence.")
+    f.add_argument("-a", "--alpha", type=float, default=0.005, help="Alpha cutoff value for the error distributions.")
+    f.add_argument("-b", "--bootstrap", type=int, default=100, help="Number of replicates to use with the bootstrap method")
+    f.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK or 0).")
+    return p
+
+
+def parse_arguments(argv=None):
+    args = build_parser().parse_args(argv)
+    if isinstance(args.collapse, str):            # argparse does not pass a str default through `type`... it does; be safe
+        args.collapse = args.collapse.lower() in ("yes", "true", "t", "1")
+    return args
+
+
+def check_arguments(args, out=None):
+    """ref: moira/moira.py:678-781 (same checks, same messages)."""
+    def say(msg=""):
+        print(msg, file=out or sys.stdout)
+
+    say()
+    if args.doc:
+        say(__doc__)
+        return False
+    ok = True
+    warn = not args.nowarnings
+    if args.only_contig:
+        args.paired = True
+    else:
+        if not args.forward_fastq and (not args.forward_fasta or not args.forward_qual):
+            if warn:
+                say("- You must at least provide one fastq file, or a fasta and quality files.")
+            ok = False
+        if args.paired:
+            if not args.reverse_fastq and (not args.reverse_fasta or not args.reverse_qual):
+                if warn:
+                    say("- You must provide one reverse fastq file, or reverse fasta and quality files.")
+                ok = False
+    checks = (
+        (args.match < 0, "- Needleman-Wunsch match score must be a non-negative integer."),
+        (args.mismatch > 0, "- Needleman-Wunsch mismatch penalty must be a non-positive integer."),
+        (args.gap > 0, "- Needleman-Wunsch gap penalty must be a non-positive integer."),
+        (args.insert < 1, "- The contig constructor insert parameter must be a positive integer."),
+        (args.deltaq < 1, "- The contig constructor deltaq parameter must be a positive integer."),
+        (not 0 < args.uncert <= 1, "- The uncert parameter must be between 0 (not included) and 1."),
+        (args.maxerrors is not None and args.maxerrors <= 0, "- The maxerrors parameter must be greater than 0."),
+        (not 0 < args.alpha < 1, "- The alpha parameter must be between 0 (not included) and 1."),
+        (bool(args.truncate) and args.truncate <= 0, "- The truncate parameter must be greater than 0."),
+        (args.min_overlap is not None and args.min_overlap <= 0, "- The min_overlap parameter must be greater than 0."),
+    )
+    for bad, msg in checks:
+        if bad:
+            if warn:
+                say(msg)
+            ok = False
+    if not ok:
+        if warn:
+            say("\nFor more info type moira.py -h or moira.py --doc.\n")
+        return False
+    if args.processors < 1:
+        if warn:
+            say("- Processors must be a non-zero positive integer. The default value of 1 will be used.")
+        args.processors = 1
+    if (args.reverse_fasta or args.reverse_fastq) and not args.paired and warn:
+        say("You provided a reverse sequence file, but not the --paired flag. Note that only the forward file will be processed.")
+        say()
+    if args.min_overlap and not args.paired and warn:
+        say("You specified a value for --min_overlap, but not the --paired flag. Note that contigs will not be assembled.")
+        say()
+    if args.error_calc == "bootstrap" and warn:
+        say("The bootstrap method is only included for testing and nostalgia. Mainly the second, at this point.")
+        say('If your purpose falls outside of these two categories, please consider switching to "-e poisson_binomial" or "-e poisson".')
+        say()
+    return True
+
+
+# ---------------------------------------------------------------------------------------------
+# input (ref: moira/moira.py:1058-1204)
+# ---------------------------------------------------------------------------------------------
+def open_input(filename):
+    """Sniff gzip / bzip2 by magic bytes; text mode, one line at a time."""
+    with io.open(filename, "rb") as fh:
+        start = fh.read(3)
+    if start.startswith(b"\x42\x5a\x68"):
+        f = bz2.open(filename, "rt", newline=None)
+    elif start.startswith(b"\x1f\x8b\x08"):
+        f = gzip.open(filename, "rt", newline=None)
+    else:
+        f = io.open(filename, "rt", buffering=1 << 20)
+    f.moira_name = filename
+    return f
+
+
+def _norm(header, mark):
+    # strip, tabs -> spaces, first token, drop the leading mark(s), ':' -> '_'   (moira.py:1121,1175)
+    return header.strip().replace("\t", " ").split(" ")[0].lstrip(mark).replace(":", "_")
+
+
+def parse_fastq(fwd, rev=None, fastq_offset=33):
+    fb, rb = [], []
+    it = zip(fwd, rev) if rev is not None else ((l, None) for l in fwd)
+    for fl, rl in it:
+        fb.append(fl.strip())
+        if rev is not None:
+            rb.append(rl.strip())
+        if len(fb) == 4:
+            fh = _norm(fb[0], "@")
+            fs = fb[1]
+            fq = [ord(x) - fastq_offset for x in fb[3]]
+            if not fs:
+                raise EmptySeqError(fh, fwd.moira_name)
+            if not fq:
+                raise EmptyQualError(fh, fwd.moira_name)
+            if len(fs) != len(fq):
+                raise LengthMismatchError(fh, fwd.moira_name)
+            fb = []
+            if rev is not None:
+                rh = _norm(rb[0], "@")
+                rs = rb[1]
+                rq = [ord(x) - fastq_offset for x in rb[3]]
+                if not rs:
+                    raise EmptySeqError(fh, fwd.moira_name)
+                if not rq:
+                    raise EmptyQualError(fh, fwd.moira_name)
+                if len(rs) != len(rq):
+                    raise LengthMismatchError(rh, rev.moira_name)
+                if fh != rh:
+                    raise NameMismatchError(fh, None, rh, None)
+                rb = []
+                yield fh, fs, fq, rs, rq
+            else:
+                yield fh, fs, fq, None, None
+
+
+def parse_fasta_and_qual(ff, fq, rf=None, rq=None):
+    if not ff or not fq:
+        raise UnpairedFilesError(ff, fq, rf, rq)
+    if (not rf and rq) or (rf and not rq):
+        raise UnpairedFilesError(ff, fq, rf, rq)
+
+    def quals_of(line):
+        toks = line.strip().replace("\t", " ").split(" ")
+        return [int(t) for t in toks] if toks != [""] else []
+
+    while True:
+        fh, qh = ff.readline(), fq.readline()
+        rh = rf.readline() if rf else ""
+        rqh = rq.readline() if rq else ""
+        if rf and rq:
+            if not fh and not rh and not qh and not rqh:
+                break
+        elif not fh and not qh:
+            break
+        fh, qh = _norm(fh, ">"), _norm(qh, ">")
+        fseq = ff.readline().strip()
+        fquals = quals_of(fq.readline())
+        if rf:
+            rh, rseq = _norm(rh, ">"), rf.readline().strip()
+            rqh, rquals = _norm(rqh, ">"), quals_of(rq.readline())
+            if len({fh, rh, qh, rqh}) != 1:
+                raise NameMismatchError(fh, qh, rh, rqh)
+        elif len({fh, qh}) != 1:
+            raise NameMismatchError(fh, qh)
+        if not fseq:
+            raise EmptySeqError(fh, ff.moira_name)
+        if not fquals:
+            raise EmptyQualError(qh, fq.moira_name)
+        if rf and not rseq:
+            raise EmptySeqError(rh, rf.moira_name)
+        if rq and not rquals:
+            raise EmptyQualError(rqh, rq.moira_name)
+        if len(fseq) != len(fquals):
+            raise LengthMismatchError(fh, ff.moira_name, fq.moira_name)
+        if rf and len(rseq) != len(rquals):
+            raise LengthMismatchError(rh, ff.moira_name, fq.moira_name)
+        yield (fh, fseq, fquals, rseq, rquals) if rf else (fh, fseq, fquals, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side error calculators that are NOT the accelerated path (ref: moira/moira.py:1637-1733)
+# ---------------------------------------------------------------------------------------------
+def interpolate(e1, p1, e2, p2, alpha):
+    r = e1 + ((e2 - e1) * ((1 - alpha) - p1) / (p2 - p1))
+    return 0 if r < 0 else r
+
+
+def calculate_errors_poisson(sequence, quals, alpha):
+    lam, ns = 0, 0
+    for base, q in zip(sequence, quals):
+        if q < 0:
+            raise ValueError("Qualities must have positive values.")
+        if base == "N":
+            ns += 1
+        else:
+            lam += 10 ** (q / -10.0)
+    acc, j = [0], 0
+    while True:
+        acc.append(acc[-1] + (math.exp(-lam) * (lam ** j)) / math.factorial(j))
+        if acc[-1] > (1 - alpha):
+            break
+        j += 1
+    return interpolate(j - 1, acc[-2], j, acc[-1], alpha), ns
+
+
+def calculate_errors_bootstrap(sequence, quals, alpha, bootstrap):
+    from numpy.random import random
+    results, ns = [], 0
+    for _ in range(int(bootstrap)):
+        errors, ns = 0, 0
+        for base, q in zip(sequence, quals):
+            if base == "N":
+                ns += 1
+            elif random() <= 10 ** (q / -10.0):
+                errors += 1
+        results.append(errors)
+    return float(np.percentile(results, (1 - alpha) * 100)), ns
+
+
+# ---------------------------------------------------------------------------------------------
+# the filter half of process_data for a chunk (ref: moira/moira.py:784-833)
+# ---------------------------------------------------------------------------------------------
+def make_gpu_backend(device=None):
+    """Default (and only product) backend: the HIP library.  Fails loudly without a GPU."""
+    from .buckets import filter_bucketed
+    from .engine import Engine
+    eng = Engine(int(os.environ.get("LOCAL_RANK", "0")) if device is None else device)
+
+    def backend(seqs, quals, alpha, ambigs, round_):
+        ee, ns, _ = filter_bucketed(eng, seqs, quals, alpha=alpha, ambigs=ambigs, round_=round_, uncert=1.0)
+        return ee
+    backend.engine = eng
+    return backend
+
+
+def process_chunk(records, args, backend):
+    """records: list of (header, fseq, fquals, rseq, rquals) -> list of
+    (header, contig, contig_quals, expected_errors, overlap_length, gaps, mismatches)."""
+    n = len(records)
+    if args.paired:
+        from . import contig as CT
+        seqs, cq, clen, ov, gaps, mism = CT.contigs_batch(
+            [r[1] for r in records], [r[2] for r in records], [r[3] for r in records], [r[4] for r in records],
+            args.match, args.mismatch, args.gap, args.insert, args.deltaq, args.consensus_qscore,
+            args.qscore_cap, args.trim_overlap, threads=args.processors)
+        quals = [[int(v) for v in cq[i, :clen[i]]] for i in range(n)]
+        ov, gaps, mism = ov.tolist(), gaps.tolist(), mism.tolist()
+    else:
+        seqs = [r[1] for r in records]
+        quals = [r[2] for r in records]
+        ov = gaps = mism = [0] * n
+    if args.truncate:
+        seqs = [s[:args.truncate] for s in seqs]
+        quals = [q[:args.truncate] for q in quals]
+    if args.only_contig:
+        ee = [0] * n
+    else:
+        quals = [[q if q > 0 else 1 for q in ql] for ql in quals]                       # moira.py:814
+        if args.error_calc in ("poisson_binomial", "poisson_binomial_py"):
+            ee = backend(seqs, quals, args.alpha, args.ambigs, args.round)             # includes +Ns / floor
+            ee = [float(x) for x in ee]
+        else:
+            ee = []
+            for s, ql in zip(seqs, quals):
+                if args.error_calc == "poisson":
+                    e, ns = calculate_errors_poisson(s, ql, args.alpha)
+                else:
+                    e, ns = calculate_errors_bootstrap(s, ql, args.alpha, args.bootstrap)
+                if args.ambigs == "treat_as_errors":
+                    e = e + ns
+                if args.round:
+                    e = math.floor(e)
+                ee.append(e)
+    return [(records[i][0], seqs[i], quals[i], ee[i], ov[i], gaps[i], mism[i]) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------
+# output (ref: moira/moira.py:842-970)
+# ---------------------------------------------------------------------------------------------
+class Outputs:
+    def __init__(self):
+        self.contig = self.qual = self.names = None
+        self.bad_contig = self.bad_qual = self.bad_names = None
+        self.report = None
+        self.files = []
+
+
+def write_results(index, header, sequence, quals, expected_errors, names_info, overlap_length, gaps,
+                  mismatches, args, o):
+    """Returns (discarded_errors, discarded_minlength, discarded_minoverlap)."""
+    if args.relabel:
+        header = "%s%d" % (args.relabel, index)
+    if args.pipeline == "USEARCH":
+        size = len(names_info) if names_info else 1
+        header = header + ";ee=%.2f;size=%d;" % (expected_errors, size)
+    if args.paired:
+        o.report.write("%s\t%s\t%s\t%s\t%s\n" % (header, len(names_info) if args.collapse else 1,
+                                                 overlap_length, gaps, mismatches))
+    fq = args.output_format == "fastq"
+
+    def qstr():
+        return "".join([chr(q + args.fastq_offset) for q in quals])
+
+    def bad(label, names_header, counts):
+        if fq:
+            o.bad_contig.write("@%s\t%s\n%s\n+\n%s\n" % (header, label, sequence, qstr()))
+        else:
+            o.bad_contig.write(">%s\t%s\n%s\n" % (header, label, sequence))
+            o.bad_qual.write(">%s\t%s\n%s\n" % (header, label, " ".join(map(str, quals))))
+        if args.collapse:
+            if args.pipeline == "mothur":
+                o.bad_names.write("%s\t%s\n" % (names_header, ",".join(names_info)))
+            n = len(names_info)
+            return tuple(n if c else 0 for c in counts)
+        return counts
+
+    def good():
+        if fq:
+            o.contig.write("@%s\n%s\n+\n%s\n" % (header, sequence, qstr()))
+        else:
+            o.contig.write(">%s\n%s\n" % (header, sequence))
+            o.qual.write(">%s\n%s\n" % (header, " ".join(map(str, quals))))
+        return (0, 0, 0)
+
+    if args.truncate and len(sequence) < args.truncate:
+        return bad("length below %s" % args.truncate, header.lstrip(">"), (0, 1, 0))
+    if args.min_overlap and overlap_length < args.min_overlap:
+        # the reference's fastq branch prints args.truncate here (moira.py:890); kept
+        return bad("overlap length below %s" % (args.truncate if fq else args.min_overlap),
+                   header.lstrip(">"), (0, 0, 1))
+    if args.only_contig:
+        r = good()
+        if args.collapse and args.pipeline == "mothur":
+            o.names.write("%s\t%s\n" % (header.lstrip(">"), ",".join(names_info)))
+        return r
+    if "N" in sequence and args.ambigs == "disallow":
+        return bad("contains ambiguities", header, (1, 0, 0))
+    if args.maxerrors:
+        keep, label, nh = expected_errors <= args.maxerrors, "errors > %.2f" % args.maxerrors, header.lstrip(">")
+    else:
+        keep, label, nh = expected_errors <= len(sequence) * args.uncert, "uncert > %.3f" % args.uncert, header
+    if keep:
+        r = good()
+        if args.collapse and args.pipeline == "mothur":
+            o.names.write("%s\t%s\n" % (header, ",".join(names_info)))
+        return r
+    return bad(label, nh, (1, 0, 0))
+
+
+def _open_outputs(args, output_name):
+    if args.output_compression == "gz":
+        opener, suffix = (lambda p: gzip.open(p, "wt")), ".gz"
+    elif args.output_compression == "bz2":
+        opener, suffix = (lambda p: bz2.open(p, "wt")), ".bz2"
+    else:
+        opener, suffix = (lambda p: open(p, "w")), ""
+    o = Outputs()
+
+    def mk(stem):
+        path = "%s.%s%s" % (output_name, stem, suffix)
+        o.files.append(path)
+        return opener(path)
+    fq = args.output_format == "fastq"
+    names = args.collapse and args.pipeline == "mothur"
+    if args.only_contig:
+        o.contig = mk("contigs.fastq" if fq else "contigs.fasta")
+        o.qual = None if fq else mk("contigs.qual")
+        o.names = mk("contigs.names") if names else None
+        if args.truncate or args.min_overlap:
+            o.bad_contig = mk("bad.contigs.fastq" if fq else "bad.contigs.fasta")
+            o.bad_qual = None if fq else mk("bad.contigs.qual")
+            o.bad_names = mk("bad.contigs.names") if names else None
+    else:
+        o.contig = mk("qc.good.fastq" if fq else "qc.good.fasta")
+        o.qual = None if fq else mk("qc.good.qual")
+        o.bad_contig = mk("qc.bad.fastq" if fq else "qc.bad.fasta")
+        o.bad_qual = None if fq else mk("qc.bad.qual")
+        if names:
+            o.names, o.bad_names = mk("qc.good.names"), mk("qc.bad.names")
+    if args.paired:
+        o.report = mk("contigs.report")
+        o.report.write("header\tn_seqs\toverlap_length\tgaps\tmismatches\n")
+    return o
+
+
+def _close(o):
+    for f in (o.contig, o.qual, o.names, o.bad_contig, o.bad_qual, o.bad_names, o.report):
+        if f is not None:
+            try:
+                f.close()
+            except Exception:
+                pass
+
+
+# ---------------------------------------------------------------------------------------------
+# main (ref: moira/moira.py:264-578)
+# ---------------------------------------------------------------------------------------------
+def main(args, backend=None, out=None):
+    """`backend(seqs, quals, alpha, ambigs, round) -> ee` defaults to the HIP library; the parameter
+    exists so the host logic can be unit-tested on machines without a GPU."""
+    def say(msg=""):
+        print(msg, file=out or sys.stdout)
+
+    if not args.silent:
+        say()
+        say("-" * 79)
+        say()
+        say("moira (MI355X build) v%s" % __version__)
+        say("Poisson-binomial read filtering after Puente-Sanchez F, Aguirre J, Parro V (2016), NAR 44(4): e40.")
+        say()
+        say("-" * 79)
+        say()
+    if not check_arguments(args, out):
+        return 1
+    if args.output_prefix:
+        output_name = args.output_prefix
+    elif args.forward_fastq:
+        output_name = ".".join(args.forward_fastq.split(".")[:-1])
+    else:
+        output_name = ".".join(args.forward_fasta.split(".")[:-1])
+    try:
+        if args.forward_fastq:
+            fwd = open_input(args.forward_fastq)
+            rev = open_input(args.reverse_fastq) if args.paired else None
+            parse = parse_fastq(fwd, rev, args.fastq_offset)
+        else:
+            ff, fqf = open_input(args.forward_fasta), open_input(args.forward_qual)
+            rf = open_input(args.reverse_fasta) if args.paired else None
+            rq = open_input(args.reverse_qual) if args.paired else None
+            parse = parse_fasta_and_qual(ff, fqf, rf, rq)
+        o = _open_outputs(args, output_name)
+    except IOError as e:
+        say(str(e))
+        say()
+        return 1
+    needs_gpu = (not args.only_contig) and args.error_calc in ("poisson_binomial", "poisson_binomial_py")
+    if backend is None and needs_gpu:
+        backend = make_gpu_backend(getattr(args, "device", None))
+    try:
+        processed = 0
+        disc_err = disc_len = disc_ov = 0.0
+        uniques = Py2Dict() if args.collapse else None
+        t0 = time.time()
+        chunk = []
+
+        def flush(chunk):
+            nonlocal processed, disc_err, disc_len, disc_ov
+            for header, contig, cquals, ee, ov, gaps, mism in process_chunk(chunk, args, backend):
+                if isinstance(ee, float) and math.isnan(ee):
+                    raise ReturnedNaNError(header)
+                if args.collapse:
+                    if contig not in uniques:
+                        uniques[contig] = {"rep_header": header, "rep_errors": ee, "rep_quals": cquals,
+                                           "names_info": [header], "overlap_length": ov, "gaps": gaps,
+                                           "mismatches": mism}
+                    else:
+                        u = uniques[contig]
+                        if ee < u["rep_errors"]:                                # strict: first seen wins ties
+                            u.update(rep_header=header, rep_errors=ee, rep_quals=cquals, overlap_length=ov,
+                                     gaps=gaps, mismatches=mism)
+                            u["names_info"].insert(0, header)
+                        else:
+                            u["names_info"].append(header)
+                else:
+                    r = write_results(processed, header, contig, cquals, ee, None, ov, gaps, mism, args, o)
+                    disc_err += r[0]; disc_len += r[1]; disc_ov += r[2]
+                processed += 1
+            if not args.silent:
+                say("%d sequences processed in %.1f seconds." % (processed, time.time() - t0))
+
+        for rec in parse:
+            chunk.append(rec)
+            if len(chunk) >= CHUNK_READS:
+                flush(chunk)
+                chunk = []
+        if chunk:
+            flush(chunk)
+        if args.collapse:
+            order = sorted(uniques, key=lambda s: len(uniques[s]["names_info"]), reverse=True)   # stable
+            for index, sequence in enumerate(order, start=1):
+                v = uniques[sequence]
+                r = write_results(index, v["rep_header"], sequence, v["rep_quals"], v["rep_errors"],
+                                  v["names_info"], v["overlap_length"], v["gaps"], v["mismatches"], args, o)
+                disc_err += r[0]; disc_len += r[1]; disc_ov += r[2]
+        if not args.silent and processed:
+            remaining = processed - disc_err - disc_len - disc_ov
+            say("- Kept %d (%.2f%%) of the original sequences." % (remaining, remaining / processed * 100))
+            if args.truncate:
+                say("- %d (%.2f%%) of the original sequences were discarded due to length < %s."
+                    % (disc_len, disc_len / processed * 100, args.truncate))
+            if args.paired and args.min_overlap:
+                say("- %d (%.2f%%) of the original sequences were discarded due to paired-end reads having "
+                    "an overlap length < %s." % (disc_ov, disc_ov / processed * 100, args.min_overlap))
+            say("- %d (%.2f%%) of the original sequences were discarded due to low quality.\n"
+                % (disc_err, disc_err / processed * 100))
+            say("The following output files were generated:")
+            for p in o.files:
+                say(p)
+            say()
+    finally:
+        _close(o)
+    return 0
+
+
+def cli(argv=None):
+    return main(parse_arguments(argv))
+
+
+if __name__ == "__main__":
+    sys.exit(cli())

@@ -1,0 +1,125 @@
+"""End-to-end: the moira-compatible CLI must reproduce the reference's golden output files
+byte for byte (moira/test/test_moira.py:73-113: forward dataset, paired dataset, compression).
+
+The CPU variants inject the oracle as the per-chunk filter so the host logic (parsers, contig
+construction, collapse rule, Python-2 dict order, writers) is tested without a GPU; the -m gpu
+variants run the product path (HIP library) end to end.
+"""
+import bz2
+import gzip
+import os
+import types
+
+import numpy as np
+import pytest
+
+from moira_amd import cli
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+RES = os.path.join(GOLD, "reference_test_results")
+
+
+def reference_args(**kw):
+    """The argument namespace of the reference's tests (moira/test/test_moira.py:130-135)."""
+    d = dict(alpha=0.005, match=1, gap=-2, mismatch=-1, insert=20, deltaq=6, consensus_qscore="best",
+             paired=True, truncate=None, only_contig=False, error_calc="poisson_binomial",
+             ambigs="treat_as_errors", round=False, silent=True, nowarnings=False, doc=False, uncert=0.01,
+             maxerrors=None, processors=4, forward_fasta=None, forward_qual=None, reverse_fasta=None,
+             reverse_qual=None, forward_fastq=None, reverse_fastq=None, output_format="fasta", collapse=True,
+             pipeline="mothur", fastq_offset=33, relabel=None, output_compression="none", qscore_cap=40,
+             min_overlap=None, trim_overlap=False, bootstrap=100, output_prefix=None, device=None)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def oracle_backend(oracle):
+    def backend(seqs, quals, alpha, ambigs, round_):
+        stride = 16 * ((max(len(s) for s in seqs) + 15) // 16)
+        q = np.stack([oracle.pack_read(s, ql, stride) for s, ql in zip(seqs, quals)])
+        lens = np.array([len(s) for s in seqs], np.int32)
+        ee, _, _, _ = oracle.filter_batch(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, threads=4)
+        return ee
+    return backend
+
+
+def same_files(out_prefix, gold_prefix, kinds=("good.fasta", "good.qual", "good.names", "bad.fasta", "bad.qual", "bad.names")):
+    for k in kinds:
+        got = open("%s.qc.%s" % (out_prefix, k)).read()
+        want = open(os.path.join(RES, "%s.qc.%s" % (gold_prefix, k))).read()
+        assert got == want, k
+
+
+def run_forward(tmp_path, backend):
+    out = str(tmp_path / "forward")
+    a = reference_args(paired=False, forward_fastq=os.path.join(GOLD, "test1.fastq.gz"), output_prefix=out)
+    assert cli.main(a, backend=backend, out=open(os.devnull, "w")) == 0
+    same_files(out, "forward")
+
+
+def run_paired(tmp_path, backend, compression="none"):
+    out = str(tmp_path / "paired")
+    a = reference_args(paired=True, forward_fastq=os.path.join(GOLD, "test1.fastq.gz"),
+                       reverse_fastq=os.path.join(GOLD, "test2.fastq.bz2"), output_prefix=out,
+                       output_compression=compression)
+    assert cli.main(a, backend=backend, out=open(os.devnull, "w")) == 0
+    if compression == "none":
+        same_files(out, "paired")
+        rep = open(out + ".contigs.report").read().split("\n")
+        assert rep[0] == "header\tn_seqs\toverlap_length\tgaps\tmismatches" and len(rep) == 402
+    else:
+        opener = gzip.open if compression == "gz" else bz2.open
+        got = opener("%s.qc.good.fasta.%s" % (out, compression), "rt").read()
+        assert got == open(os.path.join(RES, "paired.qc.good.fasta")).read()
+
+
+def test_forward_dataset_host_logic(tmp_path, oracle):
+    run_forward(tmp_path, oracle_backend(oracle))
+
+
+def test_paired_dataset_host_logic(tmp_path, oracle):
+    run_paired(tmp_path, oracle_backend(oracle))
+
+
+@pytest.mark.parametrize("comp", ["gz", "bz2"])
+def test_compressed_output_host_logic(tmp_path, oracle, comp):
+    run_paired(tmp_path, oracle_backend(oracle), comp)
+
+
+def test_argument_validation_messages(capsys):
+    a = reference_args(paired=False, forward_fastq=None)
+    assert cli.main(a, backend=lambda *x: None) == 1
+    assert "You must at least provide one fastq file" in capsys.readouterr().out
+    a = reference_args(paired=False, forward_fastq="x.fastq", alpha=1.5, uncert=0)
+    assert cli.main(a, backend=lambda *x: None) == 1
+    out = capsys.readouterr().out
+    assert "The alpha parameter must be between 0 (not included) and 1." in out
+    assert "The uncert parameter must be between 0 (not included) and 1." in out
+    ns = cli.parse_arguments(["-ffq", "a.fastq", "-c", "false", "-me", "3", "-n", "disallow", "-t", "200"])
+    assert ns.collapse is False and ns.maxerrors == 3 and ns.ambigs == "disallow" and ns.truncate == 200
+    assert cli.parse_arguments(["-ffq", "a.fastq"]).collapse is True
+
+
+def test_modes_without_collapse_and_fastq_output(tmp_path, oracle):
+    out = str(tmp_path / "nc")
+    a = reference_args(paired=False, forward_fastq=os.path.join(GOLD, "test1.fastq.gz"), output_prefix=out,
+                       collapse=False, output_format="fastq", pipeline="USEARCH", truncate=200, maxerrors=1.0,
+                       uncert=0.01)
+    assert cli.main(a, backend=oracle_backend(oracle), out=open(os.devnull, "w")) == 0
+    good = open(out + ".qc.good.fastq").read().split("\n")
+    bad = open(out + ".qc.bad.fastq").read().split("\n")
+    assert (len(good) - 1) % 4 == 0 and (len(bad) - 1) % 4 == 0
+    assert (len(good) - 1) // 4 + (len(bad) - 1) // 4 == 1000
+    assert all(len(good[i + 1]) == 200 for i in range(0, len(good) - 1, 4))
+    assert ";ee=" in good[0] and good[0].endswith(";size=1;")
+    assert all("errors > 1.00" in bad[i] for i in range(0, len(bad) - 1, 4))
+
+
+@pytest.mark.gpu
+def test_forward_dataset_gpu(tmp_path):
+    run_forward(tmp_path, None)
+
+
+@pytest.mark.gpu
+def test_paired_dataset_gpu(tmp_path):
+    run_paired(tmp_path, None)
