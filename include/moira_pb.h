@@ -64,7 +64,8 @@ extern "C" {
 #define MPB_K_SCATTER   2   /* stable scatter of read indices by class        */
 #define MPB_K_DP        3   /* the Poisson-binomial DP + epilogue (dominant)  */
 #define MPB_K_OVERFLOW  4   /* re-run of reads whose predicted row count was too small */
-#define MPB_K_COUNT     5
+#define MPB_K_LAMBDA    5   /* Poisson approximation: per-read sum of error probabilities */
+#define MPB_K_COUNT     6
 
 typedef struct mpb_ctx mpb_ctx;
 
@@ -177,6 +178,33 @@ int mpb_filter_host(mpb_ctx *ctx,
 int mpb_calculate_errors_PB(mpb_ctx *ctx, const char *contig,
                             const int32_t *contig_quals, int32_t len,
                             double alpha, double *ee, int32_t *ns);
+
+/* ---- --error_calc poisson -------------------------------------- */
+/*
+ * Poisson approximation, ref: moira/moira.py:1637-1679 (calculate_errors_poisson).
+ * Device part (a pure streaming reduction, the one variant that is HBM-bound):
+ *   d_lambda[i] = sum over non-'N' bases, IN BASE ORDER, of pow(10, q / -10.0) (host-built LUT),
+ *   bit-identical to the reference's sequential `Lambda += 10**(qscore / -10.0)`; d_ns[i] = #'N'.
+ * NOTE the Python reference treats only upper-case 'N' as ambiguous here (moira.py:1660); a
+ * byte 255 ('n') is therefore rejected by this entry point -- pack such a base as a normal one.
+ */
+int mpb_poisson_lambda_device(mpb_ctx *ctx, const uint8_t *d_q, int64_t n, int64_t row_stride,
+                              const int32_t *d_len, int32_t fixed_len,
+                              double *d_lambda, int32_t *d_ns);
+/*
+ * Host tail, exactly the reference's scalar loop with the same libm calls (exp, pow) and the
+ * correctly rounded factorials Python's int->float conversion yields: CDF until > 1-alpha,
+ * interpolate, then +Ns / floor / predicate as for the Poisson-binomial path.  lambda/ns are host
+ * arrays (e.g. copied back from mpb_poisson_lambda_device).  ee is NaN where the reference would
+ * raise OverflowError (more than 170 terms or pow overflow).
+ */
+int mpb_poisson_finish_host(const double *lambda, const int32_t *ns, const int32_t *len,
+                            int32_t fixed_len, int64_t n, const mpb_filter_params *params,
+                            double *ee, uint8_t *pass);
+/* Both steps for a batch in host memory. */
+int mpb_filter_poisson_host(mpb_ctx *ctx, const uint8_t *q, int64_t n, int64_t row_stride,
+                            const int32_t *len, int32_t fixed_len, const mpb_filter_params *params,
+                            double *ee, int32_t *ns, uint8_t *pass, mpb_filter_counts *counts);
 
 /* ---- synthetic workload (BASELINE.json configs; integer-only generator) ---- */
 /* Fill a device quality matrix with the counter-based synthetic model of

@@ -13,8 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libmoira_pb.so")
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_RANGE = 0, -1, -2, -3, -4, -5
 AMBIG = {"treat_as_errors": 0, "ignore": 1, "disallow": 2}
 FLAG_ROUND, FLAG_FAST_FMA, FLAG_TEST_UNDERPREDICT = 1, 2, 4
-K_PREPASS, K_SCAN, K_SCATTER, K_DP, K_OVERFLOW = 0, 1, 2, 3, 4
-KERNEL_NAMES = {K_PREPASS: "prepass", K_SCAN: "scan", K_SCATTER: "scatter", K_DP: "dp", K_OVERFLOW: "overflow"}
+K_PREPASS, K_SCAN, K_SCATTER, K_DP, K_OVERFLOW, K_LAMBDA = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = {K_PREPASS: "prepass", K_SCAN: "scan", K_SCATTER: "scatter", K_DP: "dp", K_OVERFLOW: "overflow", K_LAMBDA: "lambda"}
 
 
 class MoiraPBError(RuntimeError):
@@ -58,6 +58,10 @@ PROTOTYPES = {
                                   C.POINTER(FilterParams), _VP, _VP, _VP, C.POINTER(FilterCounts)]),
     "mpb_calculate_errors_PB": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int32, C.c_double,
                                           C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "mpb_poisson_lambda_device": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int32, _VP, _VP]),
+    "mpb_poisson_finish_host": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int64, C.POINTER(FilterParams), _VP, _VP]),
+    "mpb_filter_poisson_host": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int32,
+                                          C.POINTER(FilterParams), _VP, _VP, _VP, C.POINTER(FilterCounts)]),
     "mpb_synth_fill_device": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                         C.c_int32, _VP, C.c_uint64, C.c_int64]),
     "mpb_timing_enable": (C.c_int, [_VP, C.c_int]),

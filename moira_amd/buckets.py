@@ -12,8 +12,9 @@ def bucket_of(lens, quantum=64):
     return np.maximum((lens + quantum - 1) // quantum * quantum, quantum).astype(np.int64)
 
 
-def filter_bucketed(engine, seqs, quals, quantum=64, **params):
+def filter_bucketed(engine, seqs, quals, quantum=64, method="poisson_binomial", **params):
     """Pack + filter a ragged list of reads bucket by bucket.  Returns (ee, ns, passed)."""
+    run = engine.filter_poisson if method == "poisson" else engine.filter
     n = len(quals)
     lens = np.array([len(x) for x in quals], np.int64)
     strides = bucket_of(lens, quantum)
@@ -24,7 +25,7 @@ def filter_bucketed(engine, seqs, quals, quantum=64, **params):
         idx = np.nonzero(strides == stride)[0]
         q, ln = engine.pack([seqs[i] for i in idx] if seqs is not None else None,
                             [quals[i] for i in idx], stride=int(stride))
-        r = engine.filter(q, lens=ln, **params)
+        r = run(q, lens=ln, **params)
         ee[idx], ns[idx], passed[idx] = r.ee, r.ns, r.passed
     return ee, ns, passed
 

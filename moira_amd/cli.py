@@ -13,9 +13,10 @@ quality matrices and filtered on the GPU by libmoira_pb.so, and the per-read res
 same collapse / write logic.
 
 `--error_calc poisson_binomial` and `poisson_binomial_py` both run the HIP path (they are the same
-arithmetic; the reference's two names select its C or Python implementation).  `poisson` and
-`bootstrap` are evaluated on the host exactly as moira.py does (moira/moira.py:1637-1720); they
-are not the accelerated path.  `--processors` sets the CPU threads used for contig construction.
+arithmetic; the reference's two names select its C or Python implementation).  `poisson` sums the
+per-read lambda on the GPU and finishes the scalar CDF on the host with the reference's libm calls
+(moira/moira.py:1637-1679).  `bootstrap` (deprecated, random) is evaluated on the host as moira.py
+does (moira/moira.py:1682-1720).  `--processors` sets the CPU threads used for contig construction.
 
 Output order: with --collapse moira writes groups sorted by abundance and, inside one abundance,
 in Python-2 dict order.  That order is reproduced (moira_amd/py2dict.py) so the output files are
@@ -394,10 +395,15 @@ def make_gpu_backend(device=None):
     from .engine import Engine
     eng = Engine(int(os.environ.get("LOCAL_RANK", "0")) if device is None else device)
 
-    def backend(seqs, quals, alpha, ambigs, round_):
-        ee, ns, _ = filter_bucketed(eng, seqs, quals, alpha=alpha, ambigs=ambigs, round_=round_, uncert=1.0)
+    def backend(seqs, quals, alpha, ambigs, round_, method="poisson_binomial"):
+        if method == "poisson":
+            # the Python reference scores a lower-case n as a normal base (moira.py:1660)
+            seqs = [s.replace("n", "A") if "n" in s else s for s in seqs]
+        ee, ns, _ = filter_bucketed(eng, seqs, quals, method=method, alpha=alpha, ambigs=ambigs,
+                                    round_=round_, uncert=1.0)
         return ee
     backend.engine = eng
+    backend.methods = ("poisson_binomial", "poisson")
     return backend
 
 
@@ -427,6 +433,8 @@ def process_chunk(records, args, backend):
         if args.error_calc in ("poisson_binomial", "poisson_binomial_py"):
             ee = backend(seqs, quals, args.alpha, args.ambigs, args.round)             # includes +Ns / floor
             ee = [float(x) for x in ee]
+        elif args.error_calc == "poisson" and "poisson" in getattr(backend, "methods", ()):
+            ee = [float(x) for x in backend(seqs, quals, args.alpha, args.ambigs, args.round, method="poisson")]
         else:
             ee = []
             for s, ql in zip(seqs, quals):
@@ -601,7 +609,7 @@ def main(args, backend=None, out=None):
         say(str(e))
         say()
         return 1
-    needs_gpu = (not args.only_contig) and args.error_calc in ("poisson_binomial", "poisson_binomial_py")
+    needs_gpu = (not args.only_contig) and args.error_calc in ("poisson_binomial", "poisson_binomial_py", "poisson")
     if backend is None and needs_gpu:
         backend = make_gpu_backend(getattr(args, "device", None))
     try:

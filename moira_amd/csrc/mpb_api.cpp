@@ -529,6 +529,154 @@ int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *conti
     return mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
 }
 
+// ---- Poisson approximation (SURVEY f-3) ------------------------------------------------------
+
+int mpb_poisson_lambda_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride,
+                              const int32_t *d_len, int32_t fixed_len, double *d_lambda, int32_t *d_ns)
+{
+    CTXCHK(c);
+    if (n < 0 || row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "bad matrix shape");
+    if (((uintptr_t)d_q & 15) != 0) return fail(MPB_E_INVALID, "quality matrix must be 16-byte aligned");
+    if (!d_len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len does not fit row_stride");
+    if (n == 0) return MPB_OK;
+    if (!d_q || !d_lambda || !d_ns) return fail(MPB_E_INVALID, "NULL device buffer");
+    int rc = ensure_workspace(c, 1);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(c->ws.ovf_count, 0, sizeof(int32_t), c->stream));
+    { Span t(c, MPB_K_LAMBDA);
+      mpb_launch_lambda(d_q, n, row_stride, d_len, fixed_len, c->d_lut, d_lambda, d_ns, c->ws.ovf_count, c->stream); }
+    HIPCHK(hipGetLastError());
+    int32_t bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, c->ws.ovf_count, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (bad) return fail(MPB_E_INVALID, "%d read(s) contain byte 255 ('n'): the Poisson path follows the Python reference, "
+                         "which scores lower-case n as a normal base -- pack it as one", bad);
+    return MPB_OK;
+}
+
+// float(math.factorial(j)) for j = 0..170: exact up to 22!, correctly rounded above (built from
+// the exact integer with round-half-even on first use).
+static const double *factorial_table()
+{
+    static double tab[171];
+    static bool init = false;
+    if (!init) {
+        // exact big-integer product in base 2^32, then correctly rounded conversion
+        std::vector<uint32_t> big(1, 1u);
+        tab[0] = 1.0;
+        for (int j = 1; j <= 170; j++) {
+            uint64_t carry = 0;
+            for (size_t k = 0; k < big.size(); k++) {
+                uint64_t v = (uint64_t)big[k] * (uint64_t)j + carry;
+                big[k] = (uint32_t)v; carry = v >> 32;
+            }
+            if (carry) big.push_back((uint32_t)carry);
+            // top 64+ bits -> double with round-half-even
+            int top = (int)big.size() - 1;
+            int hb = 31; while (!((big[top] >> hb) & 1u)) hb--;
+            const long nbits = (long)top * 32 + hb + 1;
+            auto bit = [&](long pos) -> int { return pos < 0 ? 0 : (int)((big[pos / 32] >> (pos % 32)) & 1u); };
+            uint64_t mant = 0;
+            for (int k = 0; k < 53; k++) mant = (mant << 1) | (uint64_t)bit(nbits - 1 - k);
+            if (nbits > 53) {
+                const int guard = bit(nbits - 54);
+                bool sticky = false;
+                for (long pos = nbits - 55; pos >= 0 && !sticky; pos--) sticky = bit(pos) != 0;
+                if (guard && (sticky || (mant & 1u))) mant++;
+            }
+            tab[j] = ldexp((double)mant, nbits > 53 ? (int)(nbits - 53) : 0);
+            if (nbits <= 53) tab[j] = (double)mant / ldexp(1.0, (int)(53 - nbits));
+        }
+        init = true;
+    }
+    return tab;
+}
+
+// ref: moira/moira.py:1666-1679 -- one read
+static double poisson_tail(double lam, double alpha, const double *fact)
+{
+    double acc_prev = 0, acc = 0;
+    int j = 0;
+    for (;;) {
+        if (j > 170) return NAN;                                  // Python: int too large to convert to float
+        const double pw = pow(lam, (double)j);
+        if (std::isinf(pw)) return NAN;                           // Python: OverflowError from float pow
+        const double prob = (exp(-lam) * pw) / fact[j];
+        acc_prev = acc;
+        acc = acc_prev + prob;
+        if (acc > (1 - alpha)) break;
+        j++;
+    }
+    double r = (j - 1) + ((j - (j - 1)) * ((1 - alpha) - acc_prev) / (acc - acc_prev));
+    if (r < 0) r = 0;
+    return r;
+}
+
+int mpb_poisson_finish_host(const double *lambda, const int32_t *ns, const int32_t *len, int32_t fixed_len,
+                            int64_t n, const mpb_filter_params *p, double *ee, uint8_t *pass)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!lambda || !ns || !ee || !pass))) return fail(MPB_E_INVALID, "bad arguments");
+    const double *fact = factorial_table();
+    const bool has_me = p->maxerrors == p->maxerrors;
+    for (int64_t i = 0; i < n; i++) {
+        double e = poisson_tail(lambda[i], p->alpha, fact);
+        if (p->ambig_mode == MPB_AMBIG_TREAT_AS_ERRORS) e = e + ns[i];          // moira.py:827-828
+        if (p->flags & MPB_FLAG_ROUND) e = floor(e);                              // moira.py:830-831
+        const int li = len ? len[i] : fixed_len;
+        bool keep;
+        if (p->ambig_mode == MPB_AMBIG_DISALLOW && ns[i] > 0) keep = false;       // moira.py:911
+        else if (has_me) keep = e <= p->maxerrors;
+        else keep = e <= li * p->uncert;
+        ee[i] = e;
+        pass[i] = keep ? 1 : 0;
+    }
+    return MPB_OK;
+}
+
+int mpb_filter_poisson_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
+                            int32_t fixed_len, const mpb_filter_params *params, double *ee, int32_t *ns,
+                            uint8_t *pass, mpb_filter_counts *counts)
+{
+    CTXCHK(c);
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (n < 0 || row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "bad matrix shape");
+    if (n > 0 && (!q || !ee || !ns || !pass)) return fail(MPB_E_INVALID, "NULL host buffer");
+    mpb_filter_counts total = {n, 0, 0, 0};
+    int64_t chunk = (int64_t)(1ll << 30) / row_stride;
+    if (chunk < 1024) chunk = 1024;
+    if (chunk > n) chunk = n;
+    std::vector<double> lam((size_t)(chunk > 0 ? chunk : 1));
+    if (n > 0) {
+        rc = ensure_stage(c, align_up(chunk * (row_stride + 16) + 8 * 256, 256));
+        if (rc) return rc;
+    }
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = (n - off < chunk) ? n - off : chunk;
+        char *p = (char *)c->stage_dev;
+        uint8_t *d_q = (uint8_t *)p;   p += align_up(m * row_stride, 256);
+        double *d_lam = (double *)p;   p += align_up(m * 8, 256);
+        int32_t *d_len = (int32_t *)p; p += align_up(m * 4, 256);
+        int32_t *d_ns = (int32_t *)p;
+        HIPCHK(hipMemcpyAsync(d_q, q + off * row_stride, (size_t)(m * row_stride), hipMemcpyHostToDevice, c->stream));
+        if (len) HIPCHK(hipMemcpyAsync(d_len, len + off, (size_t)(m * 4), hipMemcpyHostToDevice, c->stream));
+        rc = mpb_poisson_lambda_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, d_lam, d_ns);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(lam.data(), d_lam, (size_t)(m * 8), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(ns + off, d_ns, (size_t)(m * 4), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rc = mpb_poisson_finish_host(lam.data(), ns + off, len ? len + off : nullptr, fixed_len, m, params,
+                                     ee + off, pass + off);
+        if (rc) return rc;
+        for (int64_t i = 0; i < m; i++) total.n_pass += pass[off + i];
+    }
+    total.n_fail = n - total.n_pass;
+    if (counts) *counts = total;
+    return MPB_OK;
+}
+
 int mpb_synth_fill_device(mpb_ctx *c, uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,
                           int32_t min_len, int32_t max_len, int32_t *d_len, uint64_t seed, int64_t first_read)
 {

@@ -547,6 +547,46 @@ __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict__ pass,
 }
 
 // ------------------------------------------------------------------------------------------
+// k_lambda (--error_calc poisson): one lane per read walks its row in base order, so the sum has
+// the reference's association (moira/moira.py:1663  Lambda += 10**(qscore / -10.0)).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lambda(const uint8_t *__restrict__ q, int64_t n, int64_t stride,
+                                                const int32_t *__restrict__ len, int32_t fixed_len,
+                                                const double2 *__restrict__ lut_ap,
+                                                double *__restrict__ lambda, int32_t *__restrict__ ns,
+                                                int32_t *__restrict__ bad)
+{
+    __shared__ double s_p[256];
+    // the DP LUT holds {1-p, p'}; p' == p bit for bit (tests/test_oracle_golden.py::test_lut_pins)
+    s_p[threadIdx.x] = lut_ap[threadIdx.x].y;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int li = len ? len[i] : fixed_len;
+    const uint8_t *row = q + i * stride;
+    double lam = 0.0;
+    int nzero = 0, n255 = 0;
+    for (int c = 0; c * 16 < li; c++) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(row + c * 16);
+        const int nv = li - c * 16;
+        const uint32_t ww[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (d * 4 + t < nv) {
+                    const uint32_t b = (ww[d] >> (8 * t)) & 0xffu;
+                    if (b == 0u) nzero++;
+                    else { lam = lam + s_p[b]; n255 += b == 255u ? 1 : 0; }
+                }
+            }
+    }
+    lambda[i] = lam;
+    ns[i] = nzero;
+    if (n255) atomicAdd(bad, 1);
+}
+
+// ------------------------------------------------------------------------------------------
 // synthetic fill: one thread per 16-byte chunk of the matrix
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t n, int64_t stride,
@@ -646,6 +686,13 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
         hipLaunchKernelGGL((k_dp<true, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list);
     else
         hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list);
+}
+
+void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, int32_t fixed_len,
+                       const double2 *lut_ap, double *lambda, int32_t *ns, int32_t *bad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lambda, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q, n, stride, len,
+                       fixed_len, lut_ap, lambda, ns, bad);
 }
 
 void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hipStream_t s)

@@ -164,6 +164,26 @@ class Engine:
                                          ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, C.byref(counts)))
         return FilterResult(ee, ns, ps.astype(bool), counts.n_pass, counts.n_overflow)
 
+    def filter_poisson(self, q, lens=None, fixed_len=None, **kw):
+        """--error_calc poisson (moira/moira.py:1637-1679): lambda summed on the GPU in base order,
+        scalar CDF tail on the host with the reference's libm calls.  Returns FilterResult."""
+        params = kw.pop("params", None) or self.params(**kw)
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        n, stride = q.shape
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.int32)
+        elif fixed_len is None:
+            raise ValueError("give lens or fixed_len")
+        ee = np.empty(n, np.float64)
+        ns = np.empty(n, np.int32)
+        ps = np.empty(n, np.uint8)
+        counts = L.FilterCounts()
+        L.check(self.lib.mpb_filter_poisson_host(self.ctx, q.ctypes.data, n, stride,
+                                                 lens.ctypes.data if lens is not None else None,
+                                                 0 if lens is not None else int(fixed_len), C.byref(params),
+                                                 ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, C.byref(counts)))
+        return FilterResult(ee, ns, ps.astype(bool), counts.n_pass, 0)
+
     def calculate_errors_PB(self, contig, contig_quals, alpha):
         """Exact twin of bernoulli.calculate_errors_PB -> (expected_errors, Ns).
         ref: moira/bernoullimodule.c:66-114 (argument and error behaviour)."""

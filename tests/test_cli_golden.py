@@ -123,3 +123,16 @@ def test_forward_dataset_gpu(tmp_path):
 @pytest.mark.gpu
 def test_paired_dataset_gpu(tmp_path):
     run_paired(tmp_path, None)
+
+
+@pytest.mark.gpu
+def test_cli_poisson_method_gpu(tmp_path):
+    """--error_calc poisson through the GPU lambda reduction equals the host evaluation."""
+    outs = []
+    for name, be in (("gpu", None), ("host", lambda *a, **k: (_ for _ in ()).throw(AssertionError("unused")))):
+        out = str(tmp_path / name)
+        a = reference_args(paired=False, forward_fastq=os.path.join(GOLD, "test1.fastq.gz"), output_prefix=out,
+                           error_calc="poisson", collapse=False)
+        assert cli.main(a, backend=be, out=open(os.devnull, "w")) == 0
+        outs.append([open("%s.qc.%s" % (out, k)).read() for k in ("good.fasta", "bad.fasta", "good.qual")])
+    assert outs[0] == outs[1]

@@ -1,0 +1,79 @@
+"""--error_calc poisson (SURVEY f-3): exact host tail on CPU; lambda reduction on the GPU."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import golden_io as G
+from moira_amd import _lib as L
+from moira_amd.cli import calculate_errors_poisson
+
+
+def finish(lams, ns, lens, **kw):
+    lib = L.load()
+    from moira_amd.engine import Engine
+    prm = Engine.params(**kw)
+    lams = np.ascontiguousarray(lams, np.float64)
+    ns = np.ascontiguousarray(ns, np.int32)
+    lens = np.ascontiguousarray(lens, np.int32)
+    ee = np.empty(len(lams))
+    ps = np.empty(len(lams), np.uint8)
+    L.check(lib.mpb_poisson_finish_host(lams.ctypes.data, ns.ctypes.data, lens.ctypes.data, 0, len(lams),
+                                        C.byref(prm), ee.ctypes.data, ps.ctypes.data))
+    return ee, ps
+
+
+def py_lambda(seq, quals):
+    lam = 0
+    for b, q in zip(seq, quals):
+        if b != "N":
+            lam += 10 ** (q / -10.0)
+    return float(lam)
+
+
+def test_poisson_kat_host_tail():
+    k = G.load_kat()["kat1"]
+    assert calculate_errors_poisson(k["seq"], k["quals"], 0.005) == (6.932519986616133, 0)   # test_moira.py:45
+    ee, _ = finish([py_lambda(k["seq"], k["quals"])], [0], [len(k["seq"])], alpha=0.005, ambigs="ignore")
+    assert ee[0] == 6.932519986616133
+
+
+def test_poisson_tail_matches_python_on_random_lambdas():
+    rng = np.random.default_rng(4)
+    lams = np.concatenate([[0.0, 1e-300, 1e-9, 0.005, 0.0050125], rng.uniform(0, 5, 500), rng.uniform(5, 120, 300)])
+    for alpha in (0.005, 0.05, 1e-4):
+        ee, _ = finish(lams, np.zeros(len(lams)), np.full(len(lams), 300), alpha=alpha, ambigs="ignore")
+        for lam, e in zip(lams, ee):
+            lam = float(lam)                      # Python float semantics (np.float64 ** int gives inf, not an error)
+            acc, j = [0], 0
+            try:
+                while True:
+                    acc.append(acc[-1] + (math.exp(-lam) * (lam ** j)) / math.factorial(j))
+                    if acc[-1] > (1 - alpha):
+                        break
+                    j += 1
+            except OverflowError:                 # the reference crashes here; the library reports NaN
+                assert math.isnan(e), (lam, alpha)
+                continue
+            want = (j - 1) + ((j - (j - 1)) * ((1 - alpha) - acc[-2]) / (acc[-1] - acc[-2]))
+            assert e == (0 if want < 0 else want), (lam, alpha)
+
+
+@pytest.mark.gpu
+def test_poisson_gpu_matches_python_reference_function():
+    from moira_amd.engine import Engine
+    s = G.load_set("rand_mixed")
+    q, lens = s["q"][:600].copy(), s["lens"][:600]
+    q[q == 255] = 17                       # the Python reference scores 'n' as a normal base
+    with Engine(0) as eng:
+        r = eng.filter_poisson(q, lens=lens, alpha=0.005, ambigs="treat_as_errors")
+        with pytest.raises(ValueError, match="255"):
+            eng.filter_poisson(s["q"][:600], lens=lens)
+    for i in range(600):
+        row = q[i, :lens[i]]
+        seq = "".join("N" if v == 0 else "A" for v in row)
+        quals = [20 if v == 0 else int(v) for v in row]
+        e, ns = calculate_errors_poisson(seq, quals, 0.005)
+        assert r.ee[i] == e + ns and r.ns[i] == ns
+        assert bool(r.passed[i]) == (e + ns <= lens[i] * 0.01)
