@@ -132,6 +132,23 @@ int mpb_pack_read(const char *seq, const int32_t *quals, int32_t len,
 int mpb_pack_read_ascii(const char *seq, const char *qual_ascii, int32_t len,
                         int32_t offset, uint8_t *row_out, int32_t row_bytes);
 
+/* Batch form for a parser: n reads concatenated (read i = bytes [off[i], off[i+1]) of seq_cat and
+ * qual_cat), FASTQ ASCII qualities, packed into n rows of row_stride bytes; at most `max_len`
+ * bases of each read are kept (--truncate, ref: moira/moira.py:806-807; <= 0: no limit).
+ * lens_out[i] = bases packed.  One C loop instead of one Python list per read
+ * (ref: moira/moira.py:1177 builds `[ord(x) - offset for x in ...]` per read). */
+int mpb_pack_batch_ascii(const char *seq_cat, const char *qual_cat, const int64_t *off, int64_t n,
+                         int32_t fastq_offset, int32_t max_len, int64_t row_stride,
+                         uint8_t *out, int32_t *lens_out);
+
+/* On-device decode: raw ASCII quality bytes and base letters already in HBM
+ * (two n x row_stride matrices) -> the packed quality matrix, elementwise, same rules as
+ * mpb_pack_read_ascii.  d_err (device int32, may be NULL) counts bytes that decode to Q < 0 or
+ * Q > 254 (those are written as Q1 / Q254). */
+int mpb_decode_ascii_device(mpb_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual_ascii, int64_t n,
+                            int64_t row_stride, const int32_t *d_len, int32_t fixed_len,
+                            int32_t fastq_offset, uint8_t *d_q_out, int32_t *d_err);
+
 /* ---- the hot path --------------------------------------------------------- */
 /*
  * Filter a batch that is RESIDENT IN HBM.

@@ -7,6 +7,33 @@ with its own stride, one library call per bucket, results scattered back to read
 import numpy as np
 
 
+class QualStr:
+    """A read's qualities kept as the raw FASTQ string (+ offset); integers only on demand.
+    `ints()` gives what process_data hands on: `ord(c) - offset` (moira/moira.py:1177) with the
+    Q0 -> Q1 clamp (moira/moira.py:814)."""
+    __slots__ = ("s", "offset")
+
+    def __init__(self, s, offset):
+        self.s, self.offset = s, offset
+
+    def __len__(self):
+        return len(self.s)
+
+    def __getitem__(self, sl):
+        return QualStr(self.s[sl], self.offset)
+
+    def ints(self):
+        a = np.frombuffer(self.s.encode("latin-1"), np.uint8).astype(np.int32) - self.offset
+        return np.maximum(a, 1).tolist()
+
+
+def pack_any(engine, seqs, quals, stride):
+    """Pack reads whose qualities are QualStr (one C loop) or integer sequences."""
+    if quals and all(isinstance(x, QualStr) for x in quals) and len({x.offset for x in quals}) == 1:
+        return engine.pack_batch_ascii(seqs, [x.s for x in quals], quals[0].offset, stride=stride)
+    return engine.pack(seqs, [x.ints() if isinstance(x, QualStr) else x for x in quals], stride=stride)
+
+
 def bucket_of(lens, quantum=64):
     lens = np.asarray(lens)
     return np.maximum((lens + quantum - 1) // quantum * quantum, quantum).astype(np.int64)
@@ -23,8 +50,8 @@ def filter_bucketed(engine, seqs, quals, quantum=64, method="poisson_binomial", 
     passed = np.empty(n, bool)
     for stride in np.unique(strides):
         idx = np.nonzero(strides == stride)[0]
-        q, ln = engine.pack([seqs[i] for i in idx] if seqs is not None else None,
-                            [quals[i] for i in idx], stride=int(stride))
+        q, ln = pack_any(engine, [seqs[i] for i in idx] if seqs is not None else None,
+                         [quals[i] for i in idx], int(stride))
         r = run(q, lens=ln, **params)
         ee[idx], ns[idx], passed[idx] = r.ee, r.ns, r.passed
     return ee, ns, passed

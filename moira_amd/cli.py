@@ -33,6 +33,7 @@ import time
 
 import numpy as np
 
+from .buckets import QualStr
 from .py2dict import Py2Dict
 
 __version__ = "1.3.2-mi355x"
@@ -266,7 +267,9 @@ def _norm(header, mark):
     return header.strip().replace("\t", " ").split(" ")[0].lstrip(mark).replace(":", "_")
 
 
-def parse_fastq(fwd, rev=None, fastq_offset=33):
+def parse_fastq(fwd, rev=None, fastq_offset=33, raw=False):
+    """raw=False: the reference's generator contract (int lists).  raw=True: qualities stay
+    FASTQ strings (QualStr) so the chunk can be packed by one C loop instead of per-base Python."""
     fb, rb = [], []
     it = zip(fwd, rev) if rev is not None else ((l, None) for l in fwd)
     for fl, rl in it:
@@ -276,7 +279,7 @@ def parse_fastq(fwd, rev=None, fastq_offset=33):
         if len(fb) == 4:
             fh = _norm(fb[0], "@")
             fs = fb[1]
-            fq = [ord(x) - fastq_offset for x in fb[3]]
+            fq = QualStr(fb[3], fastq_offset) if raw else [ord(x) - fastq_offset for x in fb[3]]
             if not fs:
                 raise EmptySeqError(fh, fwd.moira_name)
             if not fq:
@@ -287,7 +290,7 @@ def parse_fastq(fwd, rev=None, fastq_offset=33):
             if rev is not None:
                 rh = _norm(rb[0], "@")
                 rs = rb[1]
-                rq = [ord(x) - fastq_offset for x in rb[3]]
+                rq = QualStr(rb[3], fastq_offset) if raw else [ord(x) - fastq_offset for x in rb[3]]
                 if not rs:
                     raise EmptySeqError(fh, fwd.moira_name)
                 if not rq:
@@ -417,7 +420,7 @@ def process_chunk(records, args, backend):
             [r[1] for r in records], [r[2] for r in records], [r[3] for r in records], [r[4] for r in records],
             args.match, args.mismatch, args.gap, args.insert, args.deltaq, args.consensus_qscore,
             args.qscore_cap, args.trim_overlap, threads=args.processors)
-        quals = [[int(v) for v in cq[i, :clen[i]]] for i in range(n)]
+        quals = [cq[i, :clen[i]] for i in range(n)]                  # int32 views; lists only when written
         ov, gaps, mism = ov.tolist(), gaps.tolist(), mism.tolist()
     else:
         seqs = [r[1] for r in records]
@@ -429,7 +432,9 @@ def process_chunk(records, args, backend):
     if args.only_contig:
         ee = [0] * n
     else:
-        quals = [[q if q > 0 else 1 for q in ql] for ql in quals]                       # moira.py:814
+        quals = [ql if isinstance(ql, QualStr) else                                     # moira.py:814 (Q0 -> 1);
+                 (np.maximum(ql, 1) if isinstance(ql, np.ndarray) else [q if q > 0 else 1 for q in ql])
+                 for ql in quals]                                                       # QualStr clamps in ints()
         if args.error_calc in ("poisson_binomial", "poisson_binomial_py"):
             ee = backend(seqs, quals, args.alpha, args.ambigs, args.round)             # includes +Ns / floor
             ee = [float(x) for x in ee]
@@ -438,6 +443,7 @@ def process_chunk(records, args, backend):
         else:
             ee = []
             for s, ql in zip(seqs, quals):
+                ql = ql.ints() if isinstance(ql, QualStr) else ql
                 if args.error_calc == "poisson":
                     e, ns = calculate_errors_poisson(s, ql, args.alpha)
                 else:
@@ -464,6 +470,8 @@ class Outputs:
 def write_results(index, header, sequence, quals, expected_errors, names_info, overlap_length, gaps,
                   mismatches, args, o):
     """Returns (discarded_errors, discarded_minlength, discarded_minoverlap)."""
+    if isinstance(quals, QualStr):
+        quals = quals.ints()
     if args.relabel:
         header = "%s%d" % (args.relabel, index)
     if args.pipeline == "USEARCH":
@@ -598,7 +606,7 @@ def main(args, backend=None, out=None):
         if args.forward_fastq:
             fwd = open_input(args.forward_fastq)
             rev = open_input(args.reverse_fastq) if args.paired else None
-            parse = parse_fastq(fwd, rev, args.fastq_offset)
+            parse = parse_fastq(fwd, rev, args.fastq_offset, raw=True)
         else:
             ff, fqf = open_input(args.forward_fasta), open_input(args.forward_qual)
             rf = open_input(args.reverse_fasta) if args.paired else None

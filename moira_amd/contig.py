@@ -109,7 +109,13 @@ def contigs_batch(fwd_seqs, fwd_quals, rev_seqs, rev_quals, match=1, mismatch=-1
         off = np.zeros(n + 1, np.int64)
         off[1:] = np.cumsum([len(s) for s in seqs])
         s = "".join(seqs).encode()
-        q = np.fromiter((v for ql in quals for v in ql), dtype=np.int32, count=int(off[-1]))
+        if n and all(hasattr(x, "offset") for x in quals):          # raw FASTQ strings: one vector op
+            q = np.frombuffer("".join(x.s for x in quals).encode("latin-1"), np.uint8).astype(np.int32)
+            q -= np.int32(quals[0].offset) if len({x.offset for x in quals}) == 1 else \
+                np.repeat(np.array([x.offset for x in quals], np.int32), off[1:] - off[:-1])
+        else:
+            q = np.fromiter((v for ql in quals for v in (ql.ints() if hasattr(ql, "ints") else ql)),
+                            dtype=np.int32, count=int(off[-1]))
         return s, q, off
     fs, fq, fo = cat(fwd_seqs, fwd_quals)
     rs, rq, ro = cat(rev_seqs, rev_quals)

@@ -246,6 +246,29 @@ int mpb_pack_read_ascii(const char *seq, const char *qual_ascii, int32_t len, in
     return MPB_OK;
 }
 
+int mpb_pack_batch_ascii(const char *seq_cat, const char *qual_cat, const int64_t *off, int64_t n,
+                         int32_t fastq_offset, int32_t max_len, int64_t row_stride, uint8_t *out, int32_t *lens_out)
+{
+    if (n < 0 || row_stride <= 0 || (n > 0 && (!qual_cat || !off || !out))) return fail(MPB_E_INVALID, "mpb_pack_batch_ascii: bad arguments");
+    for (int64_t i = 0; i < n; i++) {
+        int64_t len = off[i + 1] - off[i];
+        if (max_len > 0 && len > max_len) len = max_len;
+        if (len < 0 || len > row_stride) return fail(MPB_E_INVALID, "read %lld of %lld bases does not fit a %lld-byte row", (long long)i, (long long)len, (long long)row_stride);
+        const char *sq = seq_cat ? seq_cat + off[i] : nullptr;
+        const unsigned char *ql = (const unsigned char *)qual_cat + off[i];
+        uint8_t *row = out + i * row_stride;
+        for (int64_t k = 0; k < len; k++) {
+            const int q = (int)ql[k] - fastq_offset;
+            if (q < 0) return fail(MPB_E_RANGE, "Qualities must have positive values.");
+            if (q > 254) return fail(MPB_E_RANGE, "quality %d exceeds the encodable maximum 254", q);
+            row[k] = pack_one(sq ? sq[k] : 'A', q);
+        }
+        memset(row + len, 0, (size_t)(row_stride - len));
+        if (lens_out) lens_out[i] = (int32_t)len;
+    }
+    return MPB_OK;
+}
+
 // ---- workspace ---------------------------------------------------------------------------------
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -527,6 +550,21 @@ int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *conti
     prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
     uint8_t pass = 0;
     return mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
+}
+
+int mpb_decode_ascii_device(mpb_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, int64_t n, int64_t row_stride,
+                            const int32_t *d_len, int32_t fixed_len, int32_t fastq_offset, uint8_t *d_out, int32_t *d_err)
+{
+    CTXCHK(c);
+    if (n < 0 || row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "bad matrix shape");
+    if ((((uintptr_t)d_seq | (uintptr_t)d_qual | (uintptr_t)d_out) & 15) != 0) return fail(MPB_E_INVALID, "matrices must be 16-byte aligned");
+    if (!d_len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len does not fit row_stride");
+    if (n == 0) return MPB_OK;
+    if (!d_seq || !d_qual || !d_out) return fail(MPB_E_INVALID, "NULL device buffer");
+    if (n * (row_stride / 16) / 256 > 0x7fffffffll) return fail(MPB_E_INVALID, "too large for one launch; split it");
+    mpb_launch_decode(d_seq, d_qual, n, row_stride, d_len, fixed_len, fastq_offset, d_out, d_err, c->stream);
+    HIPCHK(hipGetLastError());
+    return MPB_OK;
 }
 
 // ---- Poisson approximation (SURVEY f-3) ------------------------------------------------------

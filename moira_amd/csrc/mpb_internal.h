@@ -83,6 +83,8 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
                          double *ee, uint8_t *pass, hipStream_t s);
 void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, int32_t fixed_len,
                        const double2 *lut_ap, double *lambda, int32_t *ns, int32_t *bad, hipStream_t s);
+void mpb_launch_decode(const uint8_t *seq, const uint8_t *qual, int64_t n, int64_t stride, const int32_t *len,
+                       int32_t fixed_len, int32_t offset, uint8_t *out, int32_t *err, hipStream_t s);
 void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hipStream_t s);
 void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, int32_t min_len,
                       int32_t max_len, int32_t *len, uint64_t seed, int64_t first_read,

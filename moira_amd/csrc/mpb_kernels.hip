@@ -587,6 +587,45 @@ __global__ __launch_bounds__(256) void k_lambda(const uint8_t *__restrict__ q, i
 }
 
 // ------------------------------------------------------------------------------------------
+// k_decode_ascii: FASTQ quality bytes + base letters -> packed qscores, 16 bytes per lane
+// (ref: moira/moira.py:1177 `ord(x) - offset`, bernoullimodule.c:104-107 Q0->1, :196 N / n)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_decode_ascii(const uint8_t *__restrict__ seq,
+                                                      const uint8_t *__restrict__ qual, int64_t n,
+                                                      int64_t stride, const int32_t *__restrict__ len,
+                                                      int32_t fixed_len, int32_t offset,
+                                                      uint8_t *__restrict__ out, int32_t *__restrict__ err)
+{
+    const int64_t cpr = stride / 16;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n * cpr) return;
+    const int64_t i = g / cpr;
+    const int c = (int)(g - i * cpr);
+    const int li = len ? len[i] : fixed_len;
+    const uint4 sq = *reinterpret_cast<const uint4 *>(seq + i * stride + (int64_t)c * 16);
+    const uint4 ql = *reinterpret_cast<const uint4 *>(qual + i * stride + (int64_t)c * 16);
+    const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w}, qw[4] = {ql.x, ql.y, ql.z, ql.w};
+    uint32_t ow[4] = {0, 0, 0, 0};
+    int bad = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int pos = c * 16 + t;
+        const uint32_t b = (sw[t >> 2] >> (8 * (t & 3))) & 0xffu;
+        int qv = (int)((qw[t >> 2] >> (8 * (t & 3))) & 0xffu) - offset;
+        uint32_t o = 0;
+        if (pos < li) {
+            if (qv < 0) { bad++; qv = 1; }
+            if (qv > 254) { bad++; qv = 254; }
+            if (qv == 0) qv = 1;
+            o = b == 'N' ? 0u : b == 'n' ? 255u : (uint32_t)qv;
+        }
+        ow[t >> 2] |= o << (8 * (t & 3));
+    }
+    *reinterpret_cast<uint4 *>(out + i * stride + (int64_t)c * 16) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    if (bad && err) atomicAdd(err, bad);
+}
+
+// ------------------------------------------------------------------------------------------
 // synthetic fill: one thread per 16-byte chunk of the matrix
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t n, int64_t stride,
@@ -693,6 +732,14 @@ void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_
 {
     hipLaunchKernelGGL(k_lambda, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q, n, stride, len,
                        fixed_len, lut_ap, lambda, ns, bad);
+}
+
+void mpb_launch_decode(const uint8_t *seq, const uint8_t *qual, int64_t n, int64_t stride, const int32_t *len,
+                       int32_t fixed_len, int32_t offset, uint8_t *out, int32_t *err, hipStream_t s)
+{
+    const int64_t chunks = n * (stride / 16);
+    hipLaunchKernelGGL(k_decode_ascii, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, seq, qual, n,
+                       stride, len, fixed_len, offset, out, err);
 }
 
 void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hipStream_t s)

@@ -127,6 +127,34 @@ class Engine:
             L.check(self.lib.mpb_pack_read(s, qi.ctypes.data, len(qi), q[i].ctypes.data, stride))
         return q, lens
 
+    def pack_batch_ascii(self, seqs, qual_strs, fastq_offset=33, stride=None, max_len=0):
+        """Reads with raw FASTQ quality strings -> (q uint8[n, stride], lens): one C loop."""
+        n = len(qual_strs)
+        off = np.zeros(n + 1, np.int64)
+        if n:
+            off[1:] = np.cumsum([len(x) for x in qual_strs])
+        lens_full = off[1:] - off[:-1]
+        longest = int(min(lens_full.max(), max_len) if (n and max_len > 0) else (lens_full.max() if n else 1))
+        if stride is None:
+            stride = _round_up(max(longest, 1), 16)
+        q = np.empty((n, stride), np.uint8)
+        lens = np.empty(n, np.int32)
+        if seqs is not None and any(len(s) != len(x) for s, x in zip(seqs, qual_strs)):
+            raise ValueError("contig and contig_quals must have the same length")
+        L.check(self.lib.mpb_pack_batch_ascii("".join(seqs).encode() if seqs is not None else None,
+                                              "".join(qual_strs).encode("latin-1"), off.ctypes.data, n,
+                                              int(fastq_offset), int(max_len), stride, q.ctypes.data,
+                                              lens.ctypes.data))
+        return q, lens
+
+    def decode_ascii_device(self, d_seq, d_qual, n, stride, d_out, d_len=None, fixed_len=0, fastq_offset=33,
+                            d_err=None):
+        ptr = lambda b: (b.ptr if isinstance(b, DeviceBuffer) else b)
+        L.check(self.lib.mpb_decode_ascii_device(self.ctx, ptr(d_seq), ptr(d_qual), n, stride,
+                                                 ptr(d_len) if d_len is not None else None, int(fixed_len),
+                                                 int(fastq_offset), ptr(d_out),
+                                                 ptr(d_err) if d_err is not None else None))
+
     # ---- the hot path -------------------------------------------------------------------------
     def filter_device(self, d_q, n, stride, d_len=None, fixed_len=0, d_ee=None, d_ns=None, d_pass=None,
                       params=None, want_counts=True):

@@ -36,6 +36,7 @@ def reference_args(**kw):
 def oracle_backend(oracle):
     def backend(seqs, quals, alpha, ambigs, round_):
         stride = 16 * ((max(len(s) for s in seqs) + 15) // 16)
+        quals = [ql.ints() if hasattr(ql, "ints") else ql for ql in quals]
         q = np.stack([oracle.pack_read(s, ql, stride) for s, ql in zip(seqs, quals)])
         lens = np.array([len(s) for s in seqs], np.int32)
         ee, _, _, _ = oracle.filter_batch(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, threads=4)

@@ -243,3 +243,31 @@ def test_sharded_entry_single_rank(eng, oracle):
     e, n_, p, totals = filter_sharded(q, lens, engine_filter_fn(eng), dist=None)
     assert same(e, ee) and np.array_equal(n_, ns) and np.array_equal(p, ps.astype(bool))
     assert totals == (int(ps.sum()), 5000 - int(ps.sum()))
+
+
+def test_on_device_ascii_decode(eng, oracle):
+    """SURVEY f-4: FASTQ quality bytes + base letters in HBM -> packed matrix == host packer."""
+    rng = np.random.default_rng(12)
+    n, stride = 3000, 160
+    lens = rng.integers(0, 151, n).astype(np.int32)
+    seq = rng.choice(np.frombuffer(b"ACGTNn", np.uint8), (n, stride), p=[.24, .24, .24, .24, .03, .01])
+    qual = (rng.integers(0, 42, (n, stride)) + 33).astype(np.uint8)
+    want = np.zeros((n, stride), np.uint8)
+    for i in range(n):
+        s = seq[i, :lens[i]].tobytes().decode()
+        want[i] = oracle.pack_read(s, [int(v) - 33 for v in qual[i, :lens[i]]], stride)
+    d_seq, d_qual, d_out = eng.alloc(n * stride).upload(seq), eng.alloc(n * stride).upload(qual), eng.alloc(n * stride)
+    d_len, d_err = eng.alloc(n * 4).upload(lens), eng.alloc(4).upload(np.zeros(1, np.int32))
+    eng.decode_ascii_device(d_seq, d_qual, n, stride, d_out, d_len=d_len, fastq_offset=33, d_err=d_err)
+    assert np.array_equal(d_out.download(np.uint8, n * stride).reshape(n, stride), want)
+    assert d_err.download(np.int32, 1)[0] == 0
+    # and the decoded matrix feeds the filter directly, all on device
+    d_ee, d_ns, d_pass = eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
+    eng.filter_device(d_out, n, stride, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+    ee, ns, ps, _ = oracle.filter_batch(want, lens=lens, threads=4)
+    assert same(d_ee.download(np.float64, n), ee) and np.array_equal(d_pass.download(np.uint8, n), ps)
+    q2, l2 = eng.pack_batch_ascii([seq[i, :lens[i]].tobytes().decode() for i in range(n)],
+                                  [qual[i, :lens[i]].tobytes().decode("latin-1") for i in range(n)], stride=stride)
+    assert np.array_equal(q2, want) and np.array_equal(l2, lens)
+    for b in (d_seq, d_qual, d_out, d_len, d_err, d_ee, d_ns, d_pass):
+        b.free()

@@ -101,3 +101,31 @@ def test_no_fma_in_exact_dp_kernel():
         sc = [l for l in b.splitlines() if "scratch_" in l]
         assert all("Folded Spill" in l or "Folded Reload" in l for l in sc)
     assert all(b.count("v_fma_f64") + b.count("v_fmac_f64") > 5 for b in fast)
+
+
+def test_pack_batch_ascii_matches_per_read_packer(oracle):
+    lib = L.load()
+    rng = np.random.default_rng(8)
+    seqs, quals = [], []
+    for _ in range(200):
+        n = int(rng.integers(0, 90))
+        seqs.append("".join(rng.choice(list("ACGTNn"), n)) if n else "")
+        quals.append("".join(chr(int(v) + 33) for v in rng.integers(0, 42, n)))
+    off = np.zeros(len(seqs) + 1, np.int64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    for max_len in (0, 50):
+        out = np.full((len(seqs), 96), 7, np.uint8)
+        lens = np.zeros(len(seqs), np.int32)
+        rc = lib.mpb_pack_batch_ascii("".join(seqs).encode(), "".join(quals).encode(), off.ctypes.data, len(seqs),
+                                      33, max_len, 96, out.ctypes.data, lens.ctypes.data)
+        assert rc == 0
+        for i, (s, ql) in enumerate(zip(seqs, quals)):
+            if max_len:
+                s, ql = s[:max_len], ql[:max_len]
+            assert lens[i] == len(s)
+            assert np.array_equal(out[i], oracle.pack_read(s, [ord(c) - 33 for c in ql], 96))
+    bad = "".join(quals)[:-1] + chr(20) if off[-1] else ""
+    if bad:
+        out = np.zeros((len(seqs), 96), np.uint8)
+        assert lib.mpb_pack_batch_ascii("".join(seqs).encode(), bad.encode(), off.ctypes.data, len(seqs), 33, 0, 96,
+                                        out.ctypes.data, None) == L.E_RANGE
