@@ -26,6 +26,20 @@ class QualStr:
         a = np.frombuffer(self.s.encode("latin-1"), np.uint8).astype(np.int32) - self.offset
         return np.maximum(a, 1).tolist()
 
+    _tables = {}
+
+    def qual_line(self):
+        """' '.join(map(str, self.ints())) without building the integers (the .qual writer's hot spot)."""
+        tab = QualStr._tables.get(self.offset)
+        if tab is None:
+            tab = QualStr._tables[self.offset] = [str(max(b - self.offset, 1)) for b in range(256)]
+        return " ".join(map(tab.__getitem__, self.s.encode("latin-1")))
+
+    def fastq_line(self):
+        """''.join(chr(q + offset) for q in self.ints()): the input string with Q0 shown as Q1."""
+        z = chr(self.offset)
+        return self.s.replace(z, chr(self.offset + 1)) if z in self.s else self.s
+
 
 def pack_any(engine, seqs, quals, stride):
     """Pack reads whose qualities are QualStr (one C loop) or integer sequences."""

@@ -470,8 +470,6 @@ class Outputs:
 def write_results(index, header, sequence, quals, expected_errors, names_info, overlap_length, gaps,
                   mismatches, args, o):
     """Returns (discarded_errors, discarded_minlength, discarded_minoverlap)."""
-    if isinstance(quals, QualStr):
-        quals = quals.ints()
     if args.relabel:
         header = "%s%d" % (args.relabel, index)
     if args.pipeline == "USEARCH":
@@ -483,14 +481,19 @@ def write_results(index, header, sequence, quals, expected_errors, names_info, o
     fq = args.output_format == "fastq"
 
     def qstr():
-        return "".join([chr(q + args.fastq_offset) for q in quals])
+        if isinstance(quals, QualStr) and quals.offset == args.fastq_offset:
+            return quals.fastq_line()
+        return "".join([chr(q + args.fastq_offset) for q in (quals.ints() if isinstance(quals, QualStr) else quals)])
+
+    def qline():
+        return quals.qual_line() if isinstance(quals, QualStr) else " ".join(map(str, quals))
 
     def bad(label, names_header, counts):
         if fq:
             o.bad_contig.write("@%s\t%s\n%s\n+\n%s\n" % (header, label, sequence, qstr()))
         else:
             o.bad_contig.write(">%s\t%s\n%s\n" % (header, label, sequence))
-            o.bad_qual.write(">%s\t%s\n%s\n" % (header, label, " ".join(map(str, quals))))
+            o.bad_qual.write(">%s\t%s\n%s\n" % (header, label, qline()))
         if args.collapse:
             if args.pipeline == "mothur":
                 o.bad_names.write("%s\t%s\n" % (names_header, ",".join(names_info)))
@@ -503,7 +506,7 @@ def write_results(index, header, sequence, quals, expected_errors, names_info, o
             o.contig.write("@%s\n%s\n+\n%s\n" % (header, sequence, qstr()))
         else:
             o.contig.write(">%s\n%s\n" % (header, sequence))
-            o.qual.write(">%s\n%s\n" % (header, " ".join(map(str, quals))))
+            o.qual.write(">%s\n%s\n" % (header, qline()))
         return (0, 0, 0)
 
     if args.truncate and len(sequence) < args.truncate:
