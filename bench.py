@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--fast-fma", action="store_true", help="non-bit-exact FMA mode (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank dry run on a 1-GPU box: every rank uses device 0 and the (tiny) "
+                         "collectives go over gloo; exercises the N>1 code path, not a scaling number")
     args = ap.parse_args()
 
     import torch
@@ -100,9 +103,15 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
@@ -139,10 +148,10 @@ def main():
     hist = eng.class_histogram()
 
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        cc = torch.tensor([counts.n_pass, counts.n_fail, counts.n_overflow], dtype=torch.int64, device="cuda")
+        cc = torch.tensor([counts.n_pass, counts.n_fail, counts.n_overflow], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(cc, op=dist.ReduceOp.SUM)      # the one optional collective: 24 bytes of totals
         n_pass, n_fail, n_ovf = (int(x) for x in cc.tolist())
     else:
@@ -156,6 +165,16 @@ def main():
         alg_bytes = (L + 13) * n
         achieved = alg_bytes / dp_avg_s / 1e9 if dp_n else None
         cells = sum(cap * cnt for cap, cnt in hist.items()) * L        # DP cells one launch evaluates
+        # HBM bytes of one k_dp launch from the PMC counters (collected by tools/collect_profiles.sh in
+        # separate rocprofv3 passes, corrected as MI355X_MICROARCH.md prescribes); only valid for the
+        # workload it was measured on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and not args.fast_fma:
+            t = json.load(open(tpath))
+            w = t.get("workload", {})
+            if (w.get("reads"), w.get("length"), w.get("seed")) == (n, L, args.seed):
+                traffic = t["hbm_bytes_per_launch"]
         line = {
             "metric": "reads/sec filtered (300 bp synthetic)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +187,9 @@ def main():
                        "parallelism": "host-side split, %d rank(s), no data-path collective" % world,
                        "mode": "fast_fma (NOT bit-exact)" if args.fast_fma else "bit-exact (no FMA)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_unit": "bytes per k_dp launch (PMC, profiles/pmc_traffic.json)",
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel": "k_dp", "avg_launch_ms": dp_avg_s * 1e3, "launches": dp_n,
                          "algorithmic_bytes_per_read": L + 13},
             "fp64_valu": {"cells_per_launch": cells, "ops_per_cell": 2 if args.fast_fma else 3,
