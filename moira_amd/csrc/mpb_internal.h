@@ -38,8 +38,12 @@ struct MpbTables {
     int32_t perm_base[MPB_NCLS + 1];  // first slot of the class in perm[]
     int32_t tile_start[MPB_NCLS + 1]; // first tile of the class (tiles ordered widest class first)
     int32_t total_tiles;
-    int32_t pad;
+    int32_t next_chunk;               // reserved
 };
+
+// consecutive tiles one wave processes: almost always of one class, so a wave enters a class body
+// (a real call that saves callee-saved VGPRs to scratch) once per chunk
+#define MPB_DP_CHUNK 8
 
 struct MpbDevParams {
     double thr;            // 1 - alpha, computed on the host in double (ref: bernoullimodule.c:244)

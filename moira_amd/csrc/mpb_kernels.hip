@@ -27,6 +27,7 @@
 // off (see build.py: -ffp-contract=off, and the pragma below).
 
 #include "mpb_internal.h"
+#include <cstdlib>
 #include "../../include/mpb_synth.h"
 
 #pragma clang fp contract(off)
@@ -230,6 +231,7 @@ __global__ void k_tables(MpbTables *__restrict__ tb, int32_t *__restrict__ ovf_c
     }
     tb->tile_start[MPB_NCLS] = t;
     tb->total_tiles = t;
+    tb->next_chunk = 0;
     *ovf_count = 0;
     *pass_count = 0ull;
 }
@@ -248,6 +250,7 @@ __global__ void k_tables_overflow(MpbTables *__restrict__ tb, const int32_t *__r
         tb->tile_start[c] = 0;
     }
     tb->total_tiles = (cnt + rpt - 1) / rpt;
+    tb->next_chunk = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -371,11 +374,13 @@ struct DpArgs {
     int final_pass;
 };
 
-// One tile of one class.  Deliberately NOT inlined: each (R,G) body gets its own register
-// allocation, so the kernel's VGPR budget is the widest body's, not the sum of all of them.
+// A run of consecutive tiles of one class.  Deliberately NOT inlined: each (R,G) body gets its own
+// register allocation, so the kernel's VGPR budget is the widest body's, not the sum of all of them.
+// The call saves the callee-saved VGPRs it uses to scratch; taking a run of tiles per call keeps
+// that traffic negligible.
 template <int R, int G, bool FMA>
-__device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_t *perm_cls,
-                                     int count, int local_tile)
+__device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32_t *perm_cls,
+                                      int count, int first_tile, int n_tiles)
 {
     const DpArgs &A = *Ap;
     constexpr int RPT = 64 / G;
@@ -384,6 +389,8 @@ __device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_
     const bool leader = lig == 0;
     int keep = leader ? 0 : -1;
     asm volatile("" : "+v"(keep));        // opaque: keeps `& keep` a v_and (foldable into the DPP op), not a select
+#pragma unroll 1
+    for (int local_tile = first_tile; local_tile < first_tile + n_tiles; local_tile++) {
     const int slot = local_tile * RPT + lane / G;
     const bool valid = slot < count;
     const int idx = perm_cls[valid ? slot : count - 1];
@@ -487,46 +494,53 @@ __device__ __noinline__ void dp_tile(const DpArgs *__restrict__ Ap, const int32_
             const int nsv = A.ns[idx];
             if (A.prm.ambig_mode == 0) e = e + (double)nsv;              // moira.py:827-828
             if (A.prm.flags & 1u) e = floor(e);                          // moira.py:830-831
-            bool keep;
-            if (A.prm.ambig_mode == 2 && (A.cls[idx] & 0x80)) keep = false;           // moira.py:911
-            else if (A.prm.maxerrors == A.prm.maxerrors) keep = e <= A.prm.maxerrors; // moira.py:925-926
-            else keep = e <= (double)li * A.prm.uncert;                               // moira.py:949-950
+            bool keep_read;
+            if (A.prm.ambig_mode == 2 && (A.cls[idx] & 0x80)) keep_read = false;           // moira.py:911
+            else if (A.prm.maxerrors == A.prm.maxerrors) keep_read = e <= A.prm.maxerrors; // moira.py:925-926
+            else keep_read = e <= (double)li * A.prm.uncert;                               // moira.py:949-950
             A.ee[idx] = e;
-            A.pass[idx] = keep ? 1 : 0;
+            A.pass[idx] = keep_read ? 1 : 0;
         }
     }
+    }   // tiles of this run
 }
 
 // DpArgs travel through device memory so that the non-inlined class bodies can take a pointer
 __global__ void k_set_args(DpArgs a, DpArgs *__restrict__ dst) { if (threadIdx.x == 0) *dst = a; }
 
+// One wave takes `chunk_tiles` consecutive tiles (almost always one class: one call, one save of
+// callee-saved VGPRs); chunks are dealt to blocks by the hardware dispatcher, which balances the very
+// different tile costs dynamically.  Tiles are ordered widest class first = longest first, so the tail
+// is made of the cheapest tiles.  The chunk loop is grid-strided because the host sizes the grid
+// from an upper bound that assumes one read per lane; every wave's loop ends when its chunk index
+// passes the tile count.
 template <bool FMA, bool OVERFLOW_PASS>
 __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(const DpArgs *__restrict__ A,
                                             const double2 *__restrict__ lut_g,
-                                            const MpbTables *__restrict__ tb,
-                                            const int32_t *__restrict__ perm)
+                                            MpbTables *__restrict__ tb,
+                                            const int32_t *__restrict__ perm, int chunk_tiles)
 {
     mpb_s_lut[threadIdx.x] = lut_g[threadIdx.x];
     __syncthreads();
-    const int w = threadIdx.x >> 6;
     const int total = tb->total_tiles;
-    for (int t = blockIdx.x * 4 + w; t < total; t += gridDim.x * 4) {
-        int c = 0, lt = 0;
-        for (int cc = 0; cc < MPB_NCLS; cc++) {
-            const int rpt = 64 / c_classes[cc].G;
-            const int s = tb->tile_start[cc];
-            const int e = s + (tb->count[cc] + rpt - 1) / rpt;
-            if (t >= s && t < e) { c = cc; lt = t - s; }
-        }
-        c = __builtin_amdgcn_readfirstlane(c);
-        lt = __builtin_amdgcn_readfirstlane(lt);
-        const int32_t *pc = perm + tb->perm_base[c];
-        const int cnt = tb->count[c];
-        switch (c) {
-#define MPB_CASE(ID, RR, GG) case ID: dp_tile<RR, GG, FMA>(A, pc, cnt, lt); break;
-            MPB_CLASSES(MPB_CASE)
+    const int nchunks = (total + chunk_tiles - 1) / chunk_tiles;
+    for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunks; chunk += gridDim.x * 4) {
+        const int t0 = chunk * chunk_tiles;
+        const int t1 = min(total, t0 + chunk_tiles);
+        for (int c = MPB_NCLS - 1; c >= 0; c--) {          // tile order = descending class
+            const int cnt = tb->count[c];
+            const int rpt = 64 / c_classes[c].G;
+            const int s = tb->tile_start[c];
+            const int e = s + (cnt + rpt - 1) / rpt;
+            const int lo = max(t0, s), hi = min(t1, e);
+            if (lo >= hi) continue;
+            const int32_t *pc = perm + tb->perm_base[c];
+            switch (c) {
+#define MPB_CASE(ID, RR, GG) case ID: dp_tiles<RR, GG, FMA>(A, pc, cnt, lo - s, hi - lo); break;
+                MPB_CLASSES(MPB_CASE)
 #undef MPB_CASE
-        default: break;
+            default: break;
+            }
         }
     }
 }
@@ -678,6 +692,9 @@ void mpb_launch_scatter(int64_t n, const MpbWorkspace &ws, hipStream_t s)
                        ws.tables, ws.perm);
 }
 
+// cap of the DP grid (blocks of 4 waves); beyond it the chunk loop strides
+#define MPB_DP_GRID (1 << 20)
+
 static_assert(sizeof(DpArgs) <= MPB_DPARGS_SLOT, "DpArgs slot too small");
 
 static DpArgs make_args(const uint8_t *q, int64_t stride, const int32_t *len, const MpbDevParams &prm,
@@ -697,14 +714,17 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
     // (64 reads per tile) plus one partial tile per class.  Classes with G > 1 have more tiles
     // per read; the kernel's tile loop is grid-strided, so they are still covered.
     const int64_t tiles = (n + 63) / 64 + MPB_NCLS;
-    const int blocks = (int)((tiles + 3) / 4);
+    static const int chunk_tiles = getenv("MPB_DP_CHUNK") ? atoi(getenv("MPB_DP_CHUNK")) : MPB_DP_CHUNK;   // tuning knobs
+    static const int grid_cap = getenv("MPB_DP_GRID") ? atoi(getenv("MPB_DP_GRID")) : MPB_DP_GRID;
+    int64_t want = (tiles + 4 * chunk_tiles - 1) / (4 * chunk_tiles);   // blocks if every wave took one chunk
+    const int blocks = (int)(want < grid_cap ? (want > 0 ? want : 1) : grid_cap);
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 0);
     DpArgs *dA = reinterpret_cast<DpArgs *>(ws.dp_args);
     hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
     if (prm.flags & 2u)
-        hipLaunchKernelGGL((k_dp<true, false>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables, ws.perm);
+        hipLaunchKernelGGL((k_dp<true, false>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables, ws.perm, chunk_tiles);
     else
-        hipLaunchKernelGGL((k_dp<false, false>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables, ws.perm);
+        hipLaunchKernelGGL((k_dp<false, false>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables, ws.perm, chunk_tiles);
 }
 
 void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
@@ -720,11 +740,11 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 1);
     DpArgs *dA = reinterpret_cast<DpArgs *>(ws.dp_args + MPB_DPARGS_SLOT);
     hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
-    const int blocks = 512;
+    const int blocks = 256;
     if (prm.flags & 2u)
-        hipLaunchKernelGGL((k_dp<true, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list);
+        hipLaunchKernelGGL((k_dp<true, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list, MPB_DP_CHUNK);
     else
-        hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list);
+        hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list, MPB_DP_CHUNK);
 }
 
 void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, int32_t fixed_len,
