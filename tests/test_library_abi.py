@@ -90,8 +90,8 @@ def test_no_fma_in_exact_dp_kernel():
         text = open(out).read()
     # split into functions; exact-mode class bodies are dp_tile<R,G,false> = ...Lb0EEE in the mangled name
     bodies = re.split(r"\n(?=_ZN\S+:)", text)
-    exact = [b for b in bodies if re.match(r"_ZN\S*dp_tileILi\d+ELi\d+ELb0EE", b)]
-    fast = [b for b in bodies if re.match(r"_ZN\S*dp_tileILi\d+ELi\d+ELb1EE", b)]
+    exact = [b for b in bodies if re.match(r"_ZN\S*dp_tilesILi\d+ELi\d+ELb0EE", b)]
+    fast = [b for b in bodies if re.match(r"_ZN\S*dp_tilesILi\d+ELi\d+ELb1EE", b)]
     ncls = int(re.search(r"#define MPB_NCLS (\d+)", open(os.path.join(ROOT, "moira_amd", "csrc", "mpb_internal.h")).read()).group(1))
     assert len(exact) == ncls and len(fast) == ncls
     for b in exact:
