@@ -271,3 +271,18 @@ def test_on_device_ascii_decode(eng, oracle):
     assert np.array_equal(q2, want) and np.array_equal(l2, lens)
     for b in (d_seq, d_qual, d_out, d_len, d_err, d_ee, d_ns, d_pass):
         b.free()
+
+
+def test_host_entry_chunks_large_batches(eng, oracle):
+    """mpb_filter_host splits at 1 GiB of qualities: 1.2 M rows of stride 1024 take two chunks."""
+    n, stride = 1_200_000, 1024
+    q = np.zeros((n, stride), np.uint8)
+    base, _ = oracle.synth_fill(n, 64, fixed_len=60, seed=21)
+    q[:, :64] = base
+    lens = np.full(n, 60, np.int32)
+    r = eng.filter(q, lens=lens)
+    idx = np.random.default_rng(2).integers(0, n, 5000)
+    idx[:4] = (0, 1, n - 2, n - 1)
+    ee, ns, ps, _ = oracle.filter_batch(np.ascontiguousarray(base[idx]), lens=lens[idx], threads=8)
+    assert same(r.ee[idx], ee) and np.array_equal(r.ns[idx], ns) and np.array_equal(r.passed[idx], ps.astype(bool))
+    assert r.n_pass == int(r.passed.sum())
