@@ -193,11 +193,12 @@ def test_device_synth_matches_host_and_device_resident_filter(eng, oracle):
         b.free()
 
 
-def test_config2_full_size_properties(eng, oracle):
-    """BASELINE config 2: 10M x 300 bp resident in HBM.  The oracle cannot do 10M reads in
-    seconds, so at full size we check size-independent properties: (i) the run is deterministic,
-    (ii) the pass count equals the sum over the outputs, (iii) 300 random 64-read windows,
-    regenerated on the host from the counter-based generator, match the oracle bit for bit."""
+def test_config2_full_size(eng, oracle):
+    """BASELINE config 2: 10M x 300 bp resident in HBM.  Size-independent properties (determinism,
+    pass count == sum of flags == threshold test on ee, no NaN) and -- because the oracle's fast
+    shape does ~1e5 reads/s per core -- a bit-for-bit comparison of EVERY read when the host has
+    the cores for it (the GPU box has 128), of 300 random 64-read windows otherwise.  Inputs are
+    regenerated on the host from the counter-based generator, so nothing is copied back."""
     n, stride, L, seed = 10_000_000, 320, 300, 2
     d_q, d_ee, d_ns, d_pass = eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
     eng.synth_fill(d_q, n, stride, fixed_len=L, seed=seed)
@@ -210,12 +211,21 @@ def test_config2_full_size_properties(eng, oracle):
     assert not np.isnan(ee1).any()
     assert np.array_equal(ps1.astype(bool), ee1 <= L * 0.01)
     ns1 = d_ns.download(np.int32, n)
-    rng = np.random.default_rng(99)
-    for start in rng.integers(0, n - 64, 300):
-        hq, _ = oracle.synth_fill(64, stride, fixed_len=L, seed=seed, first_read=int(start))
-        ee, ns, ps, _ = oracle.filter_batch(hq, fixed_len=L)
-        sl = slice(int(start), int(start) + 64)
-        assert same(ee1[sl], ee) and np.array_equal(ns1[sl], ns) and np.array_equal(ps1[sl], ps)
+    threads = oracle.lib().pbo_max_threads()
+    if threads >= 32:
+        step = 2_000_000
+        for start in range(0, n, step):
+            hq, _ = oracle.synth_fill(step, stride, fixed_len=L, seed=seed, first_read=start)
+            ee, ns, ps, _ = oracle.filter_batch(hq, fixed_len=L, threads=threads)
+            sl = slice(start, start + step)
+            assert same(ee1[sl], ee) and np.array_equal(ns1[sl], ns) and np.array_equal(ps1[sl], ps)
+    else:
+        rng = np.random.default_rng(99)
+        for start in rng.integers(0, n - 64, 300):
+            hq, _ = oracle.synth_fill(64, stride, fixed_len=L, seed=seed, first_read=int(start))
+            ee, ns, ps, _ = oracle.filter_batch(hq, fixed_len=L)
+            sl = slice(int(start), int(start) + 64)
+            assert same(ee1[sl], ee) and np.array_equal(ns1[sl], ns) and np.array_equal(ps1[sl], ps)
     for b in (d_q, d_ee, d_ns, d_pass):
         b.free()
 
