@@ -42,6 +42,9 @@ __constant__ MpbClass c_classes[MPB_NCLS] = MPB_CLASS_TABLE;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// a length read from a caller-supplied device array never takes a kernel outside its row
+__device__ __forceinline__ int clamp_len(int li, int max_len) { return min(max(li, 0), max_len); }
+
 // ------------------------------------------------------------------------------------------
 // k_prepass
 // ------------------------------------------------------------------------------------------
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             const int64_t i = wave_row0 + rb + r;
             float mu = 0.f, var = 0.f, s3 = 0.f, amb = 0.f;
             if (i < n) {
-                const int li = len ? len[i] : prm.fixed_len;
+                const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
                 const int nv = li - c * 16;
                 if (nv > 0) {
                     uint4 x = *reinterpret_cast<const uint4 *>(q + i * stride + c * 16);
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             }
             const int64_t i = wave_row0 + rb + r;
             if (part == 0 && r < rows_here && i < n) {
-                const int li = len ? len[i] : prm.fixed_len;
+                const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
                 const int ambi = (int)amb;                                // exact: integer-valued float < 2^24
                 const int nzero = ambi & 1023, n255 = ambi >> 10;
                 // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
@@ -394,7 +397,7 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
     const int slot = local_tile * RPT + lane / G;
     const bool valid = slot < count;
     const int idx = perm_cls[valid ? slot : count - 1];
-    const int li = A.len ? A.len[idx] : A.prm.fixed_len;
+    const int li = A.len ? clamp_len(A.len[idx], A.prm.max_len) : A.prm.fixed_len;
     const uint8_t *row = A.q + (int64_t)idx * A.stride;
 
     int nch = (li + 15) >> 4;             // 16-byte chunks to walk: the longest read of the tile
@@ -456,35 +459,73 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
 
     // ---- epilogue: sequential CDF (ref: bernoullimodule.c:233-251), first row above thr ----
     const double thr = A.prm.thr;
-    double acc = 0.0, lo = 0.0, hi = 0.0;
+    double lo = 0.0, hi = 0.0;
     int js = -1;
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {
-        if (G > 1 && g > 0) {
-            const int src = (lane & ~(G - 1)) + g - 1;
-            const double acc_s = __shfl(acc, src), lo_s = __shfl(lo, src), hi_s = __shfl(hi, src);
-            const int js_s = __shfl(js, src);
-            if (lig == g) { acc = acc_s; lo = lo_s; hi = hi_s; js = js_s; }
-        }
-        if (lig == g) {
+    bool writer;                                   // the lane that reports this read
+    bool never_crossed = false;
+    if (G == 1) {
+        double acc = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const double na = acc + v[r];          // r==0,g==0: 0 + v0 is exact
-                const bool hit = (js < 0) && (na > thr);
-                lo = hit ? acc : lo;
-                hi = hit ? na : hi;
-                js = hit ? (g * R + r) : js;
-                acc = na;
+        for (int r = 0; r < R; r++) {
+            const double na = acc + v[r];          // r == 0: 0 + v0 is exact
+            const bool hit = (js < 0) && (na > thr);
+            lo = hit ? acc : lo;
+            hi = hit ? na : hi;
+            js = hit ? r : js;
+            acc = na;
+        }
+        writer = valid;
+        never_crossed = js < 0;
+    } else {
+        // Phase A: the running sum visits the G lanes of a read in order (same additions, same
+        // order as the reference); a lane only notes whether the crossing falls inside its rows.
+        // The CDF never decreases, so that is "sum after my rows > thr and nobody before me".
+        double acc = 0.0, acc_in_mine = 0.0;
+        int found = 0;
+        bool mine = false;
+#pragma unroll 1
+        for (int g = 0; g < G; g++) {
+            double acc_s = acc;
+            int found_s = found;
+            if (g > 0) {
+                const int src = (lane & ~(G - 1)) + g - 1;
+                acc_s = __shfl(acc, src);
+                found_s = __shfl(found, src);
+            }
+            if (lig == g) {
+                double a = acc_s;
+#pragma unroll
+                for (int r = 0; r < R; r++) a = a + v[r];
+                const bool cross = !found_s && (a > thr);
+                mine = cross;
+                acc_in_mine = acc_s;
+                acc = a;
+                found = found_s | (cross ? 1 : 0);
             }
         }
+        // Phase B: only the crossing lane walks its rows again to pick out the two CDF values.
+        if (mine) {
+            double a = acc_in_mine;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const double na = a + v[r];
+                const bool hit = (js < 0) && (na > thr);
+                lo = hit ? a : lo;
+                hi = hit ? na : hi;
+                js = hit ? (lig * R + r) : js;
+                a = na;
+            }
+        }
+        never_crossed = (lig == G - 1) && !found;  // the last lane has seen the whole CDF
+        writer = valid && (mine || never_crossed);
     }
-    if (lig == G - 1 && valid) {
-        if (js < 0 && !A.final_pass) {
+    if (writer) {
+        if (never_crossed && !A.final_pass) {
             const int pos = atomicAdd(A.ovf_count, 1);
             A.ovf_list[pos] = idx;
         } else {
             double e;
-            if (js < 0) {
+            if (never_crossed) {
                 e = __builtin_nan("");                 // CDF never crosses: reference runs off its table
             } else {
                 // ref: bernoullimodule.c:170-178  errors1 + ((errors2-errors1)*((1-alpha)-prob1)/(prob2-prob1))
@@ -576,7 +617,7 @@ __global__ __launch_bounds__(256) void k_lambda(const uint8_t *__restrict__ q, i
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int li = len ? len[i] : fixed_len;
+    const int li = len ? clamp_len(len[i], (int)stride) : fixed_len;
     const uint8_t *row = q + i * stride;
     double lam = 0.0;
     int nzero = 0, n255 = 0;
@@ -615,7 +656,7 @@ __global__ __launch_bounds__(256) void k_decode_ascii(const uint8_t *__restrict_
     if (g >= n * cpr) return;
     const int64_t i = g / cpr;
     const int c = (int)(g - i * cpr);
-    const int li = len ? len[i] : fixed_len;
+    const int li = len ? clamp_len(len[i], (int)stride) : fixed_len;
     const uint4 sq = *reinterpret_cast<const uint4 *>(seq + i * stride + (int64_t)c * 16);
     const uint4 ql = *reinterpret_cast<const uint4 *>(qual + i * stride + (int64_t)c * 16);
     const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w}, qw[4] = {ql.x, ql.y, ql.z, ql.w};
