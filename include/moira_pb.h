@@ -55,6 +55,12 @@ extern "C" {
 /* flags for mpb_filter_params.flags */
 #define MPB_FLAG_ROUND      1u   /* --round: floor(ee) before the compare, ref: moira/moira.py:830-831 */
 #define MPB_FLAG_FAST_FMA   2u   /* NOT bit-exact: contract a*v+b*w into fma (|rel err| ~1e-13). Off by default. */
+#define MPB_FLAG_DECISION_ONLY 8u /* opt-in, NOT the reference's contract: a read whose expected errors are
+                                    PROVABLY above the threshold (multiplicative Chernoff lower-tail bound on the
+                                    Poisson-binomial quantile, from the prepass' mean) is reported pass = 0,
+                                    ee = NaN without running its DP.  Every other read is computed exactly as
+                                    usual, and every pass/fail flag equals the full computation's.  For
+                                    pipelines that never look at the ee of a discarded read. */
 #define MPB_FLAG_TEST_UNDERPREDICT 4u /* test hook: halve every predicted row budget so that the
                                          overflow (second) pass is exercised; results are unchanged */
 

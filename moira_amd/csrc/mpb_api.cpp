@@ -416,6 +416,7 @@ static MpbDevParams make_dev_params(const mpb_filter_params *p, int32_t fixed_le
     const double z = inv_norm_cdf(1 - p->alpha);
     d.z = (float)z;
     d.zq = (float)((z * z - 1) / 6);
+    d.clow = (float)(sqrt(2 * log(1 / (1 - p->alpha))) * 1.0001);
     d.ambig_mode = p->ambig_mode;
     d.flags = p->flags;
     d.fixed_len = fixed_len;
@@ -445,7 +446,7 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     if (rc) return rc;
     const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
     hipStream_t s = c->stream;
-    { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, s); }
+    { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     { Span t(c, MPB_K_SCAN);     mpb_launch_scan(n, c->ws, s); }
     { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, c->ws, s); }
     { Span t(c, MPB_K_DP);       mpb_launch_dp(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }

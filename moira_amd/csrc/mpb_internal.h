@@ -31,6 +31,8 @@ struct MpbClass { int cap, G, R; };
 
 // reads handled by one prepass / scatter block (one thread per read in the ranking step)
 #define MPB_PRE_READS 256
+// class byte of a read the prepass already settled (MPB_FLAG_DECISION_ONLY): never scattered, never run
+#define MPB_CLS_SETTLED 0x7f
 
 // Device-side tables produced by the scan kernel, consumed by scatter and DP kernels.
 struct MpbTables {
@@ -51,6 +53,7 @@ struct MpbDevParams {
     double maxerrors;      // NaN when unset
     float  z;              // Phi^-1(1 - alpha), prediction only
     float  zq;             // (z*z - 1) / 6,     prediction only
+    float  clow;           // sqrt(2 ln(1/(1-alpha))): Chernoff lower-tail coefficient (MPB_FLAG_DECISION_ONLY)
     int32_t ambig_mode;
     uint32_t flags;
     int32_t fixed_len;     // used when d_len == nullptr
@@ -76,7 +79,7 @@ struct MpbWorkspace {
 // Launch wrappers (mpb_kernels.hip).  All asynchronous on `s`.
 void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
-                        hipStream_t s);
+                        double *ee_out, uint8_t *pass_out, hipStream_t s);
 void mpb_launch_scan(int64_t n, const MpbWorkspace &ws, hipStream_t s);
 void mpb_launch_scatter(int64_t n, const MpbWorkspace &ws, hipStream_t s);
 void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,

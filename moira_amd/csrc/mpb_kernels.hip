@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                                                  int64_t stride, const int32_t *__restrict__ len,
                                                  MpbDevParams prm, uint8_t *__restrict__ cls,
                                                  int32_t *__restrict__ blockhist,
-                                                 int32_t *__restrict__ ns_out)
+                                                 int32_t *__restrict__ ns_out,
+                                                 double *__restrict__ ee_out,
+                                                 uint8_t *__restrict__ pass_out)
 {
     __shared__ float2 s_tab[256];
     __shared__ float4 s_part[4][MPB_PRE_SUB];
@@ -175,9 +177,24 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                 int c = 0;
 #pragma unroll
                 for (int k = 0; k < MPB_NCLS - 1; k++) c += (rows > c_classes[k].cap) ? 1 : 0;
-                cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
                 ns_out[i] = nzero + n255;
-                atomicAdd(&s_hist[c], 1);
+                bool settled = false;
+                if (prm.flags & 8u) {                                     // MPB_FLAG_DECISION_ONLY
+                    // Chernoff: P(X <= (1-d)mu) <= exp(-d^2 mu / 2) <= 1-alpha for d = clow/sqrt(mu), so the
+                    // first CDF row above 1-alpha is > t = mu - clow*sqrt(mu) and ee >= floor(t).  mu is an
+                    // fp32 sum of approximated p: shave 1e-4 relative and 0.02 absolute before trusting it.
+                    const float t = mu * (1.0f - 1e-4f) - prm.clow * sqrtf(mu) - 0.02f;
+                    const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
+                    settled = mu > 1.0f && (double)floorf(t) > limit;
+                }
+                if (settled) {
+                    cls[i] = (uint8_t)(MPB_CLS_SETTLED | (nzero > 0 ? 0x80 : 0));
+                    ee_out[i] = __builtin_nan("");
+                    pass_out[i] = 0;
+                } else {
+                    cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
+                    atomicAdd(&s_hist[c], 1);
+                }
             }
         }
         __syncthreads();
@@ -270,9 +287,10 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + tid;
     const bool valid = i < n;
-    const int c = valid ? (cls[i] & 0x7f) : -1;
+    int c = valid ? (cls[i] & 0x7f) : -1;
+    if (c == MPB_CLS_SETTLED) c = -1;             // settled by the prepass: not part of any tile
     int rank = 0;
-    unsigned long long remaining = __ballot(valid);
+    unsigned long long remaining = __ballot(c >= 0);
     while (remaining) {
         const int leader = __ffsll((long long)remaining) - 1;
         const int cc = __shfl(c, leader);
@@ -282,7 +300,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
         remaining &= ~m;
     }
     __syncthreads();
-    if (valid) {
+    if (c >= 0) {
         int off = blockhist[(int64_t)c * gridDim.x + blockIdx.x];
         for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][c];
         perm[tb->perm_base[c] + off + rank] = (int32_t)i;
@@ -715,10 +733,10 @@ static inline int pre_blocks(int64_t n) { return (int)((n + MPB_PRE_READS - 1) /
 
 void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
-                        hipStream_t s)
+                        double *ee_out, uint8_t *pass_out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_prepass, dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm,
-                       ws.cls, ws.blockhist, ns_out);
+                       ws.cls, ws.blockhist, ns_out, ee_out, pass_out);
 }
 
 void mpb_launch_scan(int64_t n, const MpbWorkspace &ws, hipStream_t s)

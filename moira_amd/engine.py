@@ -87,11 +87,12 @@ class Engine:
     # ---- parameters -------------------------------------------------------------------------
     @staticmethod
     def params(alpha=0.005, uncert=0.01, maxerrors=None, ambigs="treat_as_errors", round_=False,
-               fast_fma=False, test_underpredict=False):
+               fast_fma=False, test_underpredict=False, decision_only=False):
         if ambigs not in L.AMBIG:
             raise ValueError("ambigs must be one of %s" % sorted(L.AMBIG))
         flags = (L.FLAG_ROUND if round_ else 0) | (L.FLAG_FAST_FMA if fast_fma else 0) | \
-                (L.FLAG_TEST_UNDERPREDICT if test_underpredict else 0)
+                (L.FLAG_TEST_UNDERPREDICT if test_underpredict else 0) | \
+                (L.FLAG_DECISION_ONLY if decision_only else 0)
         return L.FilterParams(float(alpha), float(uncert),
                               math.nan if maxerrors is None else float(maxerrors),
                               L.AMBIG[ambigs], flags)

@@ -296,3 +296,23 @@ def test_host_entry_chunks_large_batches(eng, oracle):
     ee, ns, ps, _ = oracle.filter_batch(np.ascontiguousarray(base[idx]), lens=lens[idx], threads=8)
     assert same(r.ee[idx], ee) and np.array_equal(r.ns[idx], ns) and np.array_equal(r.passed[idx], ps.astype(bool))
     assert r.n_pass == int(r.passed.sum())
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(alpha=0.05, uncert=0.02), dict(alpha=0.3), dict(maxerrors=6.0, ambigs="ignore"),
+                                dict(round_=True), dict(ambigs="disallow")])
+def test_decision_only_mode_never_changes_a_decision(eng, oracle, kw):
+    """MPB_FLAG_DECISION_ONLY: reads proven to fail are reported (pass=0, ee=NaN) without their DP;
+    every flag must equal the full computation's, every computed ee must stay bit-exact."""
+    q, lens = oracle.synth_fill(60000, 320, fixed_len=300, seed=6)
+    ee, ns, ps, _ = oracle.filter_batch(q, fixed_len=300, threads=8, **kw)
+    r = eng.filter(q, fixed_len=300, decision_only=True, **kw)
+    assert np.array_equal(r.passed, ps.astype(bool)) and np.array_equal(r.ns, ns)
+    skipped = np.isnan(r.ee)
+    assert skipped.sum() > 1000                       # the shortcut really fires on this workload
+    assert not ps[skipped].any()                      # only failing reads are ever skipped
+    assert same(r.ee[~skipped], ee[~skipped])
+    s = G.load_set("rand_mixed")
+    r2 = eng.filter(s["q"], lens=s["lens"], decision_only=True, **kw)
+    e2, n2, p2, _ = oracle.filter_batch(s["q"], lens=s["lens"], threads=8, **kw)
+    sk = np.isnan(r2.ee)
+    assert np.array_equal(r2.passed, p2.astype(bool)) and same(r2.ee[~sk], e2[~sk]) and not p2[sk].any()
