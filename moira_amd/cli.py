@@ -174,6 +174,10 @@ def build_parser():
     f.add_argument("-a", "--alpha", type=float, default=0.005, help="Alpha cutoff value for the error distributions.")
     f.add_argument("-b", "--bootstrap", type=int, default=100, help="Number of replicates to use with the bootstrap method")
     f.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK or 0).")
+    f.add_argument("--fast_discard", action="store_true",
+                   help="(not in moira.py) skip the exact error calculation for reads that provably exceed the "
+                        "threshold; only with --collapse false and the mothur pipeline, where the expected errors "
+                        "of a discarded read are never used. Kept/discarded sets are unchanged.")
     return p
 
 
@@ -398,7 +402,12 @@ def make_gpu_backend(device=None):
     from .engine import Engine
     eng = Engine(int(os.environ.get("LOCAL_RANK", "0")) if device is None else device)
 
-    def backend(seqs, quals, alpha, ambigs, round_, method="poisson_binomial"):
+    def backend(seqs, quals, alpha, ambigs, round_, method="poisson_binomial", fast_discard=None):
+        if fast_discard is not None and method == "poisson_binomial":
+            uncert, maxerrors = fast_discard
+            ee, ns, _ = filter_bucketed(eng, seqs, quals, alpha=alpha, ambigs=ambigs, round_=round_,
+                                        uncert=uncert, maxerrors=maxerrors, decision_only=True)
+            return np.where(np.isnan(ee), np.inf, ee)     # "certainly above the threshold"
         if method == "poisson":
             # the Python reference scores a lower-case n as a normal base (moira.py:1660)
             seqs = [s.replace("n", "A") if "n" in s else s for s in seqs]
@@ -436,7 +445,12 @@ def process_chunk(records, args, backend):
                  (np.maximum(ql, 1) if isinstance(ql, np.ndarray) else [q if q > 0 else 1 for q in ql])
                  for ql in quals]                                                       # QualStr clamps in ints()
         if args.error_calc in ("poisson_binomial", "poisson_binomial_py"):
-            ee = backend(seqs, quals, args.alpha, args.ambigs, args.round)             # includes +Ns / floor
+            if getattr(args, "fast_discard", False) and not args.collapse and args.pipeline == "mothur" \
+                    and "poisson" in getattr(backend, "methods", ()):
+                ee = backend(seqs, quals, args.alpha, args.ambigs, args.round,
+                             fast_discard=(args.uncert, args.maxerrors))
+            else:
+                ee = backend(seqs, quals, args.alpha, args.ambigs, args.round)         # includes +Ns / floor
             ee = [float(x) for x in ee]
         elif args.error_calc == "poisson" and "poisson" in getattr(backend, "methods", ()):
             ee = [float(x) for x in backend(seqs, quals, args.alpha, args.ambigs, args.round, method="poisson")]

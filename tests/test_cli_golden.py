@@ -28,7 +28,8 @@ def reference_args(**kw):
              maxerrors=None, processors=4, forward_fasta=None, forward_qual=None, reverse_fasta=None,
              reverse_qual=None, forward_fastq=None, reverse_fastq=None, output_format="fasta", collapse=True,
              pipeline="mothur", fastq_offset=33, relabel=None, output_compression="none", qscore_cap=40,
-             min_overlap=None, trim_overlap=False, bootstrap=100, output_prefix=None, device=None)
+             min_overlap=None, trim_overlap=False, bootstrap=100, output_prefix=None, device=None,
+             fast_discard=False)
     d.update(kw)
     return types.SimpleNamespace(**d)
 
@@ -136,4 +137,16 @@ def test_cli_poisson_method_gpu(tmp_path):
                            error_calc="poisson", collapse=False)
         assert cli.main(a, backend=be, out=open(os.devnull, "w")) == 0
         outs.append([open("%s.qc.%s" % (out, k)).read() for k in ("good.fasta", "bad.fasta", "good.qual")])
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_cli_fast_discard_keeps_the_same_reads(tmp_path):
+    outs = []
+    for fd in (False, True):
+        out = str(tmp_path / ("fd%d" % fd))
+        a = reference_args(paired=False, forward_fastq=os.path.join(GOLD, "test1.fastq.gz"), output_prefix=out,
+                           collapse=False, fast_discard=fd)
+        assert cli.main(a, out=open(os.devnull, "w")) == 0
+        outs.append([open("%s.qc.%s" % (out, k)).read() for k in ("good.fasta", "good.qual", "bad.fasta", "bad.qual")])
     assert outs[0] == outs[1]
