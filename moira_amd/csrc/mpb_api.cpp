@@ -434,6 +434,7 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     if (n < 0) return fail(MPB_E_INVALID, "n < 0");
     if (n > 0x7fffffffll - 4096) return fail(MPB_E_INVALID, "batch of %lld reads exceeds 2^31; split it", (long long)n);
     if (row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "row_stride must be a positive multiple of 16");
+    if (row_stride > MPB_MAX_LEN + 1) return fail(MPB_E_INVALID, "row_stride %lld exceeds %d (reads longer than %d bases are not supported)", (long long)row_stride, MPB_MAX_LEN + 1, MPB_MAX_LEN);
     if (((uintptr_t)d_q & 15) != 0) return fail(MPB_E_INVALID, "quality matrix must be 16-byte aligned");
     if (!d_len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len %d does not fit row_stride %lld", fixed_len, (long long)row_stride);
     const int32_t max_len = d_len ? (int32_t)(row_stride < MPB_MAX_LEN ? row_stride : MPB_MAX_LEN) : fixed_len;

@@ -11,8 +11,8 @@
 //              also counts ambiguous bases (Ns) and writes a per-block class histogram.
 //   k_scan / k_tables   exclusive scan of the histograms -> stable offsets, tile table.
 //   k_scatter  stable counting-sort scatter of read indices by class (deterministic).
-//   k_dp       the DP.  One wave = one tile of reads of ONE class, so every lane runs the same
-//              trip counts.  Class (G,R): G lanes share a read, each lane keeps R consecutive
+//   k_dp       the DP.  One wave = 8 consecutive tiles; a tile = 64/G reads of ONE class, so every
+//              lane runs the same trip counts.  Class (G,R): G lanes share a read, each lane keeps R consecutive
 //              entries of the running probability vector v[] in VGPRs; per base
 //                  v[j] = fl( fl(a*v[j]) + fl(b*v[j-1]) )      (no FMA: bit-exact with the
 //              reference, whose inner sum has exactly these two non-zero terms), the row
@@ -52,8 +52,9 @@ __device__ __forceinline__ int clamp_len(int li, int max_len) { return min(max(l
 // every wave-instruction loads 1 KiB of consecutive bytes.  Per byte: one ds_read_b64 from a
 // 256-entry float2 LUT {p, p(1-p)}, one packed f32 add (mu, var) and one fma (sum of p*p(1-p), from
 // which the third cumulant is var - 2*that).  Ambiguous bytes carry a large marker in the second
-// component; a chunk whose sum shows a marker (rare) is redone byte by byte.  Chunk partials go
-// through LDS and are summed per read in a fixed order (deterministic).
+// component (64 per 'N', 2048 per 'n'); the markers are peeled off each 16-byte sum with two floors,
+// without a branch.  Chunk partials go through LDS and are summed per read in a fixed order
+// (deterministic).  Requires stride <= 1024 (64 chunks per row; the C ABI enforces it).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t mask_dword(uint32_t w, int nvalid_bytes)
