@@ -113,8 +113,11 @@ def contigs_batch(fwd_seqs, fwd_quals, rev_seqs, rev_quals, match=1, mismatch=-1
             q = np.frombuffer("".join(x.s for x in quals).encode("latin-1"), np.uint8).astype(np.int32)
             q -= np.int32(quals[0].offset) if len({x.offset for x in quals}) == 1 else \
                 np.repeat(np.array([x.offset for x in quals], np.int32), off[1:] - off[:-1])
+        elif n and all(isinstance(x, np.ndarray) for x in quals):
+            q = np.concatenate(quals).astype(np.int32, copy=False)
         else:
-            q = np.fromiter((v for ql in quals for v in (ql.ints() if hasattr(ql, "ints") else ql)),
+            import itertools
+            q = np.fromiter(itertools.chain.from_iterable(ql.ints() if hasattr(ql, "ints") else ql for ql in quals),
                             dtype=np.int32, count=int(off[-1]))
         return s, q, off
     fs, fq, fo = cat(fwd_seqs, fwd_quals)
