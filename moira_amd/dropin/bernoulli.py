@@ -30,3 +30,12 @@ def calculate_errors_PB(contig, contig_quals, alpha):
 
 
 calculate_errors = calculate_errors_PB
+
+
+def calculate_errors_PB_batch(quals, lens=None, alpha=0.005, fixed_len=None):
+    """Batch form: `quals` is a C-contiguous uint8 (N x L_max) matrix in the packed
+    encoding of include/moira_pb.h (Q0 already clamped to 1, 0 = 'N', 255 = 'n'), `lens` an optional
+    int32 vector.  Returns (expected_errors float64[N], Ns int32[N]) -- per read exactly what
+    calculate_errors_PB returns, one library call for the whole matrix."""
+    r = _default_engine().filter(quals, lens=lens, fixed_len=fixed_len, alpha=alpha, ambigs="ignore", uncert=1.0)
+    return r.ee, r.ns

@@ -39,6 +39,9 @@ def test_kats_through_dropin_module(eng):
         k = kat[name]
         ee, ns = bernoulli.calculate_errors_PB(k["seq"], k["quals"], k["alpha"])
         assert ee + ns == want
+    s = G.load_set("synth250")
+    ee, ns = bernoulli.calculate_errors_PB_batch(s["q"], lens=s["lens"], alpha=float(s["alpha"]))
+    assert same(ee, G.expected_value(s)) and np.array_equal(ns, s["ns_ref"])
 
 
 def test_dropin_error_behaviour(eng):

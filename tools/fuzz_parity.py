@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Randomised differential test: HIP path (through the C ABI) vs the CPU oracle over random batch
+shapes, length distributions, quality profiles, alphas and modes.  Bit-exact or it prints the case.
+    python tools/fuzz_parity.py [rounds] [seed]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+import pb_oracle as O  # noqa: E402
+from moira_amd.engine import Engine  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+threads = O.lib().pbo_max_threads()
+bad = 0
+t0 = time.time()
+with Engine(0) as eng:
+    for it in range(rounds):
+        n = int(rng.choice([1, 7, 63, 64, 65, 255, 257, 1000, 5000, 20000]))
+        stride = int(rng.choice([16, 32, 48, 64, 160, 256, 304, 320, 512, 608, 1024]))
+        max_l = min(stride, 1023)
+        fixed = rng.random() < 0.4
+        if fixed:
+            L = int(rng.integers(0, max_l + 1))
+            lens = np.full(n, L, np.int32)
+        else:
+            lens = rng.integers(0, max_l + 1, n).astype(np.int32)
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            q = rng.integers(1, 42, (n, stride))
+        elif kind == 1:
+            q = rng.integers(1, 8, (n, stride))                      # very low quality: wide classes
+        elif kind == 2:
+            q = rng.integers(30, 42, (n, stride))                    # very high quality: tiny J, UB-case reads
+        elif kind == 3:
+            q = rng.integers(1, 255, (n, stride))
+        elif kind == 4:
+            base = rng.integers(2, 41, (n, 1))
+            q = np.clip(base + rng.integers(-3, 4, (n, stride)), 1, 60)
+        else:
+            q = np.clip(40 - (np.arange(stride)[None, :] / max(stride, 1)) * rng.integers(0, 40, (n, 1)), 1, 41)
+        q = q.astype(np.uint8)
+        amb = rng.random((n, stride)) < rng.choice([0, 0.001, 0.02, 0.3])
+        q[amb] = np.where(rng.random(int(amb.sum())) < 0.8, 0, 255)
+        if rng.random() < 0.5:                                       # garbage in the padding
+            pad = np.arange(stride)[None, :] >= lens[:, None]
+            q[pad] = rng.integers(0, 256, int(pad.sum()), dtype=np.uint8)
+        kw = dict(alpha=float(rng.choice([0.005, 0.001, 0.05, 0.3, 1e-5, 0.9])),
+                  ambigs=str(rng.choice(["treat_as_errors", "ignore", "disallow"])),
+                  round_=bool(rng.random() < 0.2))
+        if rng.random() < 0.3:
+            kw["maxerrors"] = float(rng.choice([0.5, 1.0, 3.0, 10.0]))
+        else:
+            kw["uncert"] = float(rng.choice([0.01, 0.02, 0.1, 1.0]))
+        extra = {}
+        if rng.random() < 0.15:
+            extra["test_underpredict"] = True
+        if rng.random() < 0.15:
+            extra["decision_only"] = True
+        ee, ns, ps, rows = O.filter_batch(q, lens=lens, threads=threads, **kw)
+        r = eng.filter(q, lens=None if fixed else lens, fixed_len=int(lens[0]) if fixed else None, **kw, **extra)
+        ok = np.array_equal(r.ns, ns) and np.array_equal(r.passed, ps.astype(bool))
+        if extra.get("decision_only"):
+            sk = np.isnan(r.ee) & ~np.isnan(ee)
+            ok = ok and np.array_equal(r.ee[~sk], ee[~sk], equal_nan=True) and not ps[sk].any()
+        else:
+            ok = ok and np.array_equal(r.ee, ee, equal_nan=True)
+        if not ok:
+            bad += 1
+            d = np.nonzero(~((r.ee == ee) | (np.isnan(r.ee) & np.isnan(ee))))[0]
+            print("MISMATCH round %d: n=%d stride=%d fixed=%s kind=%d kw=%s extra=%s first diffs %s rows %s"
+                  % (it, n, stride, fixed, kind, kw, extra, d[:5], rows[d[:5]]), flush=True)
+print("fuzz: %d rounds, %d mismatching rounds, %.1f s (oracle threads %d)" % (rounds, bad, time.time() - t0, threads))
+sys.exit(1 if bad else 0)
