@@ -40,7 +40,33 @@ namespace {
 
 __constant__ MpbClass c_classes[MPB_NCLS] = MPB_CLASS_TABLE;
 
+// rows -> smallest class whose cap >= rows, built at compile time
+struct ClassOfRows {
+    uint8_t t[MPB_MAX_LEN + 2];
+    constexpr ClassOfRows() : t{}
+    {
+        constexpr MpbClass cl[MPB_NCLS] = MPB_CLASS_TABLE;
+        for (int rows = 0; rows < MPB_MAX_LEN + 2; rows++) {
+            int c = 0;
+            for (int k = 0; k < MPB_NCLS - 1; k++) c += (rows > cl[k].cap) ? 1 : 0;
+            t[rows] = (uint8_t)c;
+        }
+    }
+};
+__constant__ ClassOfRows c_class_of_rows{};
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Orders this wave's LDS writes before its later LDS reads (LDS operations of one wave execute in
+// order; the fence stops the compiler from moving them and drains the counter).  Enough when the
+// LDS region is touched by one wave only.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // a length read from a caller-supplied device array never takes a kernel outside its row
 __device__ __forceinline__ int clamp_len(int li, int max_len) { return min(max(li, 0), max_len); }
@@ -88,6 +114,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
 {
     __shared__ float2 s_tab[256];
     __shared__ float4 s_part[4][MPB_PRE_SUB];
+    __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts}
     __shared__ int s_hist[MPB_NCLS];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     {
@@ -142,7 +169,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             const float k3 = var - 2.0f * s3;                              // sum p(1-p)(1-2p)
             s_part[w][g] = make_float4(mu, var, k3, amb);
         }
-        __syncthreads();
+        wave_lds_fence();      // s_part[w] / s_row[w] are private to this wave: no block barrier
         // 4 lanes per read sum its chunk partials in a fixed order
         {
             const int r = lane >> 2, part = lane & 3;
@@ -161,45 +188,51 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                 k3 += __shfl_xor(k3, off);
                 amb += __shfl_xor(amb, off);
             }
-            const int64_t i = wave_row0 + rb + r;
-            if (part == 0 && r < rows_here && i < n) {
-                const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
-                const int ambi = (int)amb;                                // exact: integer-valued float < 2^24
-                const int nzero = ambi & 1023, n255 = ambi >> 10;
-                // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
-                // rows 0..j* where j* is the first row whose CDF exceeds 1-alpha.
-                const float v = fmaxf(var, 1e-12f);
-                const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;
-                int rows = (int)floorf(x + 0.5f) + 1;
-                if (prm.flags & 4u) rows = rows / 2;                      // MPB_FLAG_TEST_UNDERPREDICT
-                const int scored = li - nzero - n255;
-                rows = min(rows, scored + 1);
-                rows = max(rows, 1);
-                int c = 0;
-#pragma unroll
-                for (int k = 0; k < MPB_NCLS - 1; k++) c += (rows > c_classes[k].cap) ? 1 : 0;
-                ns_out[i] = nzero + n255;
-                bool settled = false;
-                if (prm.flags & 8u) {                                     // MPB_FLAG_DECISION_ONLY
-                    // Chernoff: P(X <= (1-d)mu) <= exp(-d^2 mu / 2) <= 1-alpha for d = clow/sqrt(mu), so the
-                    // first CDF row above 1-alpha is > t = mu - clow*sqrt(mu) and ee >= floor(t).  mu is an
-                    // fp32 sum of approximated p: shave 1e-4 relative and 0.02 absolute before trusting it.
-                    const float t = mu * (1.0f - 1e-4f) - prm.clow * sqrtf(mu) - 0.02f;
-                    const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
-                    settled = mu > 1.0f && (double)floorf(t) > limit;
-                }
-                if (settled) {
-                    cls[i] = (uint8_t)(MPB_CLS_SETTLED | (nzero > 0 ? 0x80 : 0));
-                    ee_out[i] = __builtin_nan("");
-                    pass_out[i] = 0;
-                } else {
-                    cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
-                    atomicAdd(&s_hist[c], 1);
-                }
+            // one lane per read parks the sums; all 64 reads of the wave are classed together below
+            if (part == 0 && r < rows_here) s_row[w][rb + r] = make_float4(mu, var, k3, amb);
+        }
+        wave_lds_fence();      // s_part[w] / s_row[w] are private to this wave: no block barrier
+    }
+    // ---- classing: one lane per read, all 64 lanes busy (was: 16 of 64, four times) ----
+    {
+        const int64_t i = wave_row0 + lane;
+        if (i < n) {
+            const float4 e = s_row[w][lane];
+            const float mu = e.x, var = e.y, k3 = e.z;
+            const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
+            const int ambi = (int)e.w;                                    // exact: integer-valued float < 2^24
+            const int nzero = ambi & 1023, n255 = ambi >> 10;
+            // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
+            // rows 0..j* where j* is the first row whose CDF exceeds 1-alpha.
+            const float v = fmaxf(var, 1e-12f);
+            const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;
+            int rows = (int)floorf(x + 0.5f) + 1;
+            if (prm.flags & 4u) rows = rows / 2;                          // MPB_FLAG_TEST_UNDERPREDICT
+            const int scored = li - nzero - n255;
+            rows = min(rows, scored + 1);
+            rows = max(rows, 1);
+            const int c = c_class_of_rows.t[min(rows, MPB_MAX_LEN + 1)];
+            ns_out[i] = nzero + n255;
+            bool settled = false;
+            if (prm.flags & 8u) {                                         // MPB_FLAG_DECISION_ONLY
+                // Chernoff: P(X <= (1-d)mu) <= exp(-d^2 mu / 2) <= 1-alpha for d = clow/sqrt(mu), so the
+                // first CDF row above 1-alpha is > t = mu - clow*sqrt(mu) and ee >= floor(t).  mu is an
+                // fp32 sum of approximated p: shave 1e-4 relative and 0.02 absolute before trusting it.
+                const float t = mu * (1.0f - 1e-4f) - prm.clow * sqrtf(mu) - 0.02f;
+                const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
+                settled = mu > 1.0f && (double)floorf(t) > limit;
+            }
+            if (settled) {
+                cls[i] = (uint8_t)(MPB_CLS_SETTLED | (nzero > 0 ? 0x80 : 0));
+                ee_out[i] = __builtin_nan("");
+                pass_out[i] = 0;
+            } else {
+                cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
+                atomicAdd(&s_hist[c], 1);
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (tid < MPB_NCLS) blockhist[(int64_t)tid * gridDim.x + blockIdx.x] = s_hist[tid];   // class-major
 }
 
