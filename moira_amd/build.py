@@ -8,6 +8,8 @@ container; the .so travels to the GPU box with the source snapshot.
 -ffp-contract=off is REQUIRED: the DP cell and the interpolation must round exactly as the
 reference (gcc, baseline x86-64, no FMA) does.
 """
+import fcntl
+import hashlib
 import os
 import subprocess
 import sys
@@ -31,40 +33,71 @@ CONTIG_SRC = os.path.join(CSRC, "contig.cpp")
 CXX = os.environ.get("CXX", "g++")
 
 
-def contig_stale():
-    if not os.path.exists(CONTIG_LIB):
+CONTIG_DEPS = [CONTIG_SRC, os.path.join(ROOT, "include", "moira_contig.h")]
+
+
+def _digest(paths, flags):
+    h = hashlib.sha256(" ".join(flags).encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _is_stale(lib, deps, flags):
+    """A library is current when the digest of its sources + flags matches the stamp written next to it
+    (file times do not survive the copy to a GPU box)."""
+    stamp = lib + ".stamp"
+    if not os.path.exists(lib) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(CONTIG_LIB)
-    return any(os.path.getmtime(d) > t for d in (CONTIG_SRC, os.path.join(ROOT, "include", "moira_contig.h")))
+    try:
+        return open(stamp).read().strip() != _digest(deps, flags)
+    except OSError:
+        return True
+
+
+def _locked_build(lib, deps, flags, cmd, force, verbose):
+    """Build under an exclusive lock: the ranks of a multi-GPU job import the package at the same time."""
+    with open(lib + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if force or _is_stale(lib, deps, flags):
+                if verbose:
+                    print(" ".join(cmd))
+                tmp = lib + ".tmp.%d" % os.getpid()
+                subprocess.check_call(cmd[:-1] + [tmp])
+                os.replace(tmp, lib)
+                with open(lib + ".stamp", "w") as f:
+                    f.write(_digest(deps, flags))
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+    return lib
+
+
+CONTIG_FLAGS = ["-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-pthread", "-Wall"]
+
+
+def contig_stale():
+    return _is_stale(CONTIG_LIB, CONTIG_DEPS, CONTIG_FLAGS)
 
 
 def build_contig(force=False, verbose=False):
     """CPU-only contig construction library (g++, no HIP): north_star keeps NW on the CPU."""
     if not force and not contig_stale():
         return CONTIG_LIB
-    cmd = [CXX, "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-pthread", "-Wall",
-           CONTIG_SRC, "-o", CONTIG_LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return CONTIG_LIB
+    cmd = [CXX] + CONTIG_FLAGS + [CONTIG_SRC, "-o", CONTIG_LIB]
+    return _locked_build(CONTIG_LIB, CONTIG_DEPS, CONTIG_FLAGS, cmd, force, verbose)
 
 
 def stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    return _is_stale(LIB, DEPS, FLAGS)
 
 
 def build(force=False, verbose=False, extra=()):
-    if not force and not stale():
+    if not force and not stale() and not extra:
         return LIB
     cmd = [HIPCC] + FLAGS + list(extra) + SOURCES + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    return _locked_build(LIB, DEPS, FLAGS + list(extra), cmd, force or bool(extra), verbose)
 
 
 if __name__ == "__main__":
