@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--fast-fma", action="store_true", help="non-bit-exact FMA mode (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the opt-in-mode extra runs (profiling)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank dry run on a 1-GPU box: every rank uses device 0 and the (tiny) "
                          "collectives go over gloo; exercises the N>1 code path, not a scaling number")
@@ -147,17 +148,24 @@ def main():
     counts = step(counts=True)
     hist = eng.class_histogram()
     # extra (NOT the headline, work is skipped by design): opt-in MPB_FLAG_DECISION_ONLY, same batch
-    prm_do = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", fast_fma=args.fast_fma, decision_only=True)
-    for _ in range(2):
-        eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_do, want_counts=False)
-    eng.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_do, want_counts=False)
-    eng.synchronize()
-    dt_do = (time.perf_counter() - t1) / 5
-    counts_do = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_do)
-    hist_do = eng.class_histogram()
+    extras = {}
+    if not args.no_extras:
+        prm_do = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", fast_fma=args.fast_fma, decision_only=True)
+        for _ in range(2):
+            eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_do, want_counts=False)
+        eng.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_do, want_counts=False)
+        eng.synchronize()
+        dt_do = (time.perf_counter() - t1) / 5
+        counts_do = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_do)
+        hist_do = eng.class_histogram()
+        extras = {"decision_only_mode": {
+            "note": "opt-in MPB_FLAG_DECISION_ONLY on the same resident batch of rank 0: reads proven to fail "
+                    "(Chernoff bound) skip their DP and report ee=NaN; identical pass/fail flags; NOT the headline",
+            "reads_per_s_this_rank": n / dt_do, "ms_per_step": dt_do * 1e3,
+            "pass": counts_do.n_pass, "reads_run_through_dp": int(sum(hist_do.values()))}}
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -212,11 +220,7 @@ def main():
             "kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in times.items()},
             "outcome": {"pass": n_pass, "fail": n_fail, "overflow_reruns": n_ovf},
             "row_budget_histogram": {str(k): v for k, v in hist.items() if v},
-            "extras": {"decision_only_mode": {
-                "note": "opt-in MPB_FLAG_DECISION_ONLY on the same resident batch of rank 0: reads proven to fail "
-                        "(Chernoff bound) skip their DP and report ee=NaN; identical pass/fail flags; NOT the headline",
-                "reads_per_s_this_rank": n / dt_do, "ms_per_step": dt_do * 1e3,
-                "pass": counts_do.n_pass, "reads_run_through_dp": int(sum(hist_do.values()))}},
+            "extras": extras,
         }
         if world == 1 and not args.no_cpu_baseline:
             line.update(cpu_baseline(args.seed, L, stride))

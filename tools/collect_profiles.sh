@@ -8,8 +8,8 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 D=$PWD/gpurun_out/prof_$TAG
 mkdir -p $D
-rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $D/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $D/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $D/write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D/sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $D/sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $D/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $D/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $D/write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $D/sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $D/sq.log 2>&1
 echo "profiles collected under $D"
