@@ -150,3 +150,57 @@ def test_cli_fast_discard_keeps_the_same_reads(tmp_path):
         assert cli.main(a, out=open(os.devnull, "w")) == 0
         outs.append([open("%s.qc.%s" % (out, k)).read() for k in ("good.fasta", "good.qual", "bad.fasta", "bad.qual")])
     assert outs[0] == outs[1]
+
+
+def _fastq_to_fasta_qual(src_opener, src, fa, qu):
+    with src_opener(src, "rt") as f, open(fa, "w") as ffa, open(qu, "w") as fqu:
+        lines = [l.rstrip("\n") for l in f]
+    with open(fa, "w") as ffa, open(qu, "w") as fqu:
+        for i in range(0, len(lines), 4):
+            h = lines[i][1:]
+            ffa.write(">%s some description\n%s\n" % (h, lines[i + 1]))
+            fqu.write(">%s\tother text\n%s\n" % (h, " ".join(str(ord(c) - 33) for c in lines[i + 3])))
+
+
+def test_fasta_qual_input_reproduces_the_same_golden_files(tmp_path, oracle):
+    """The fasta+qual reader (moira/moira.py:1093-1149): same reads as test1/test2.fastq, written as
+    fasta + qual with trailing header text (which the reader must drop), give the same outputs."""
+    f1, q1 = str(tmp_path / "r1.fasta"), str(tmp_path / "r1.qual")
+    f2, q2 = str(tmp_path / "r2.fasta"), str(tmp_path / "r2.qual")
+    _fastq_to_fasta_qual(gzip.open, os.path.join(GOLD, "test1.fastq.gz"), f1, q1)
+    _fastq_to_fasta_qual(bz2.open, os.path.join(GOLD, "test2.fastq.bz2"), f2, q2)
+    out = str(tmp_path / "fwd")
+    a = reference_args(paired=False, forward_fasta=f1, forward_qual=q1, output_prefix=out)
+    assert cli.main(a, backend=oracle_backend(oracle), out=open(os.devnull, "w")) == 0
+    same_files(out, "forward")
+    out = str(tmp_path / "prd")
+    a = reference_args(paired=True, forward_fasta=f1, forward_qual=q1, reverse_fasta=f2, reverse_qual=q2,
+                       output_prefix=out)
+    assert cli.main(a, backend=oracle_backend(oracle), out=open(os.devnull, "w")) == 0
+    same_files(out, "paired")
+    # default output name = input name without its extension (moira.py:300-303)
+    a = reference_args(paired=False, forward_fasta=f1, forward_qual=q1)
+    assert cli.main(a, backend=oracle_backend(oracle), out=open(os.devnull, "w")) == 0
+    assert os.path.exists(str(tmp_path / "r1.qc.good.fasta"))
+
+
+def test_reader_errors(tmp_path):
+    fa, qu = str(tmp_path / "a.fasta"), str(tmp_path / "a.qual")
+    open(fa, "w").write(">r1\nACGT\n")
+    open(qu, "w").write(">r2\n30 30 30 30\n")
+    with pytest.raises(cli.NameMismatchError):
+        list(cli.parse_fasta_and_qual(cli.open_input(fa), cli.open_input(qu)))
+    open(qu, "w").write(">r1\n30 30 30\n")
+    with pytest.raises(cli.LengthMismatchError):
+        list(cli.parse_fasta_and_qual(cli.open_input(fa), cli.open_input(qu)))
+    fq = str(tmp_path / "a.fastq")
+    open(fq, "w").write("@r:1 extra\nACGT\n+\nIIII\n@r2\n\n+\n\n")
+    it = cli.parse_fastq(cli.open_input(fq))
+    assert next(it)[:3] == ("r_1", "ACGT", [40, 40, 40, 40])
+    with pytest.raises(cli.EmptySeqError):
+        next(it)
+    fq2 = str(tmp_path / "b.fastq")
+    open(fq2, "w").write("@other\nACGT\n+\nIIII\n")
+    open(fq, "w").write("@r1\nACGT\n+\nIIII\n")
+    with pytest.raises(cli.NameMismatchError):
+        list(cli.parse_fastq(cli.open_input(fq), cli.open_input(fq2)))
