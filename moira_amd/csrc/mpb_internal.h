@@ -29,8 +29,10 @@ struct MpbClass { int cap, G, R; };
 #define MPB_CLASS_ENTRY(ID, RR, GG) {(RR) * (GG), GG, RR},
 #define MPB_CLASS_TABLE { MPB_CLASSES(MPB_CLASS_ENTRY) }
 
-// reads handled by one prepass / scatter block (one thread per read in the ranking step)
-#define MPB_PRE_READS 256
+// reads handled by one prepass / scatter block: MPB_PRE_ROUNDS rounds of 256 (one thread per read in
+// the ranking step).  More reads per block = shorter histograms to scan.
+#define MPB_PRE_ROUNDS 4
+#define MPB_PRE_READS (256 * MPB_PRE_ROUNDS)
 // class byte of a read the prepass already settled (MPB_FLAG_DECISION_ONLY): never scattered, never run
 #define MPB_CLS_SETTLED 0x7f
 

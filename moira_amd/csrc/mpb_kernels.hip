@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
     const int rs = min(16, max(1, MPB_PRE_SUB / cpr));                     // rows per sub-batch
     const uint32_t inv = (uint32_t)(((1u << 20) + cpr - 1) / cpr);        // g / cpr == (g*inv) >> 20 for g*cpr < 2^20
     const int cpp = (cpr + 3) >> 2;                                       // chunks per reducing lane
-    const int64_t wave_row0 = (int64_t)blockIdx.x * MPB_PRE_READS + w * 64;
+    for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
+    const int64_t wave_row0 = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + w * 64;
+    if (wave_row0 >= n) break;                    // wave-uniform; nothing below is a block barrier
 
     for (int rb = 0; rb < 64; rb += rs) {
         const int rows_here = min(rs, 64 - rb);
@@ -232,6 +234,8 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             }
         }
     }
+    wave_lds_fence();                             // s_row[w] is reused by the next round
+    }   // rounds
     __syncthreads();
     if (tid < MPB_NCLS) blockhist[(int64_t)tid * gridDim.x + blockIdx.x] = s_hist[tid];   // class-major
 }
@@ -316,28 +320,35 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
                                                  int32_t *__restrict__ perm)
 {
     __shared__ int s_wcnt[4][MPB_NCLS];
+    __shared__ int s_base[MPB_NCLS];              // next free offset of each class inside this block's range
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    for (int k = tid; k < 4 * MPB_NCLS; k += 256) (&s_wcnt[0][0])[k] = 0;
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + tid;
-    const bool valid = i < n;
-    int c = valid ? (cls[i] & 0x7f) : -1;
-    if (c == MPB_CLS_SETTLED) c = -1;             // settled by the prepass: not part of any tile
-    int rank = 0;
-    unsigned long long remaining = __ballot(c >= 0);
-    while (remaining) {
-        const int leader = __ffsll((long long)remaining) - 1;
-        const int cc = __shfl(c, leader);
-        const unsigned long long m = __ballot(c == cc);
-        if (c == cc) rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == leader) s_wcnt[w][cc] = __popcll(m);
-        remaining &= ~m;
-    }
-    __syncthreads();
-    if (c >= 0) {
-        int off = blockhist[(int64_t)c * gridDim.x + blockIdx.x];
-        for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][c];
-        perm[tb->perm_base[c] + off + rank] = (int32_t)i;
+    if (tid < MPB_NCLS) s_base[tid] = blockhist[(int64_t)tid * gridDim.x + blockIdx.x];
+    for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
+        for (int k = tid; k < 4 * MPB_NCLS; k += 256) (&s_wcnt[0][0])[k] = 0;
+        __syncthreads();
+        const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + tid;
+        const bool valid = i < n;
+        int c = valid ? (cls[i] & 0x7f) : -1;
+        if (c == MPB_CLS_SETTLED) c = -1;         // settled by the prepass: not part of any tile
+        int rank = 0;
+        unsigned long long remaining = __ballot(c >= 0);
+        while (remaining) {
+            const int leader = __ffsll((long long)remaining) - 1;
+            const int cc = __shfl(c, leader);
+            const unsigned long long m = __ballot(c == cc);
+            if (c == cc) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == leader) s_wcnt[w][cc] = __popcll(m);
+            remaining &= ~m;
+        }
+        __syncthreads();
+        if (c >= 0) {
+            int off = s_base[c];
+            for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][c];
+            perm[tb->perm_base[c] + off + rank] = (int32_t)i;
+        }
+        __syncthreads();
+        if (tid < MPB_NCLS) s_base[tid] += s_wcnt[0][tid] + s_wcnt[1][tid] + s_wcnt[2][tid] + s_wcnt[3][tid];
+        __syncthreads();                          // before the next round clears s_wcnt
     }
 }
 
