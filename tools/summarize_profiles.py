@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the committed summaries:
+"""(reads also counted exactly: TCC_EA0_RDREQ_32B/64B/128B x 32/64/128 B -- on gfx950 practically every
+L2 fill is a 128-B request, for coalesced streams and per-lane gathers alike, which is why FETCH_SIZE,
+= requests x 64 B, reads half.)
+
+Turn gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the committed summaries:
 profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json and profiles/pmc_traffic.json (what
 bench.py reports as roofline.traffic for the default workload).
 
@@ -30,7 +34,7 @@ stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
 out = {}
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "tccrd", "tccwr", "sq"):
     files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     if not files:
         continue
@@ -49,12 +53,21 @@ for k, v in out.items():
         v["hbm_read_bytes"] = v["FETCH_SIZE"] * 1024 * 2
     if "WRITE_SIZE" in v:
         v["hbm_write_bytes"] = v["WRITE_SIZE"] * 1024
+    if "TCC_EA0_RDREQ_128B_sum" in v:     # exact: every read request by its size
+        v["hbm_read_bytes_exact"] = (32 * v.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * v.get("TCC_EA0_RDREQ_64B_sum", 0)
+                                     + 128 * v["TCC_EA0_RDREQ_128B_sum"])
+    if "TCC_EA0_WRREQ_sum" in v:          # write requests are 64 B or 32 B
+        v["hbm_write_bytes_exact"] = 64 * v.get("TCC_EA0_WRREQ_64B_sum", 0) + 32 * (v["TCC_EA0_WRREQ_sum"] - v.get("TCC_EA0_WRREQ_64B_sum", 0))
     if "GRBM_GUI_ACTIVE" in v:
         v["clock_ghz"] = v["GRBM_GUI_ACTIVE"] / 8 / v["duration_us"] / 1e3
 json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 dp = out.get("k_dp<false, false>", {})
 if "hbm_read_bytes" in dp and "hbm_write_bytes" in dp:
-    json.dump({"source": "profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag,
+    rd = dp.get("hbm_read_bytes_exact", dp["hbm_read_bytes"])
+    wr = dp.get("hbm_write_bytes_exact", dp["hbm_write_bytes"])
+    dp = dict(dp, hbm_read_bytes=rd, hbm_write_bytes=wr)
+    json.dump({"source": "profiles/%s_pmc.json (rocprofv3 --pmc, separate passes: TCC_EA0_RDREQ_{32B,64B,128B} and "
+                         "TCC_EA0_WRREQ{,_64B} request counts x their sizes; FETCH_SIZE x 2 / WRITE_SIZE agree)" % tag,
                "workload": {"reads": 10000000, "length": 300, "stride": 320, "seed": 2},
                "kernel": "k_dp", "hbm_read_bytes_per_launch": dp["hbm_read_bytes"],
                "hbm_write_bytes_per_launch": dp["hbm_write_bytes"],
