@@ -129,3 +129,15 @@ def test_pack_batch_ascii_matches_per_read_packer(oracle):
         out = np.zeros((len(seqs), 96), np.uint8)
         assert lib.mpb_pack_batch_ascii("".join(seqs).encode(), bad.encode(), off.ctypes.data, len(seqs), 33, 0, 96,
                                         out.ctypes.data, None) == L.E_RANGE
+
+
+def test_contig_library_exports_every_declared_symbol():
+    import ctypes
+    from moira_amd import contig as CT
+    lib = CT.load()
+    src = open(os.path.join(ROOT, "include", "moira_contig.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mct_[a-z_A-Z0-9]+)\s*\(", src)))
+    assert syms == ["mct_contigs_batch", "mct_last_error", "mct_make_contig", "mct_nw_align", "mct_reverse_complement"]
+    for s in syms:
+        assert isinstance(getattr(lib, s), ctypes._CFuncPtr)
