@@ -319,3 +319,29 @@ def test_decision_only_mode_never_changes_a_decision(eng, oracle, kw):
     e2, n2, p2, _ = oracle.filter_batch(s["q"], lens=s["lens"], threads=8, **kw)
     sk = np.isnan(r2.ee)
     assert np.array_equal(r2.passed, p2.astype(bool)) and same(r2.ee[~sk], e2[~sk]) and not p2[sk].any()
+
+
+def test_two_contexts_from_two_threads(oracle):
+    """One context per host thread on the same GPU: no shared mutable state between contexts."""
+    import threading
+    from moira_amd.engine import Engine
+    qs = [oracle.synth_fill(30000, 320, fixed_len=300, seed=s)[0] for s in (31, 32)]
+    want = [oracle.filter_batch(q, fixed_len=300, threads=4) for q in qs]
+    got = [None, None]
+    errs = []
+
+    def work(k):
+        try:
+            with Engine(0) as e:
+                for _ in range(5):
+                    got[k] = e.filter(qs[k], fixed_len=300)
+        except Exception as ex:      # pragma: no cover
+            errs.append(ex)
+    ts = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs
+    for k in (0, 1):
+        assert same(got[k].ee, want[k][0]) and np.array_equal(got[k].passed, want[k][2].astype(bool))
