@@ -111,7 +111,8 @@ int mpb_create(int device_id, mpb_ctx **out)
     if (e == hipSuccess) {
         double2 h[256];
         build_lut(h);
-        e = hipMemcpy(c->d_lut, h, sizeof(h), hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(c->d_lut, h, sizeof(h), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // h is on this frame
     }
     if (e != hipSuccess) {
         int rc = fail(MPB_E_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -279,7 +280,9 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
         // tables (2), overflow counter, pass counter
         const size_t bytes = 2 * align_up(sizeof(MpbTables), 256) + 512 + 2 * MPB_DPARGS_SLOT;
         HIPCHK(hipMalloc(&c->ws_small, bytes));
-        HIPCHK(hipMemset(c->ws_small, 0, bytes));
+        // on the context's stream, not the null stream: the stream is non-blocking, so a null-stream
+        // memset is unordered with the kernels below and can land after k_set_args has written dp_args
+        HIPCHK(hipMemsetAsync(c->ws_small, 0, bytes, c->stream));
         char *p = (char *)c->ws_small;
         c->ws.tables = (MpbTables *)p;
         c->ws.tables2 = (MpbTables *)(p + align_up(sizeof(MpbTables), 256));

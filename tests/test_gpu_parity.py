@@ -332,9 +332,11 @@ def test_two_contexts_from_two_threads(oracle):
 
     def work(k):
         try:
-            with Engine(0) as e:
-                for _ in range(5):
-                    got[k] = e.filter(qs[k], fixed_len=300)
+            for _ in range(6):           # fresh contexts: the first filter call of each also sets up its workspace
+                with Engine(0) as e:
+                    for _ in range(3):
+                        got[k] = e.filter(qs[k], fixed_len=300)
+                assert same(got[k].ee, want[k][0])
         except Exception as ex:      # pragma: no cover
             errs.append(ex)
     ts = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
