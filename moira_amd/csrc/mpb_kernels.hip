@@ -74,13 +74,16 @@ __device__ __forceinline__ int clamp_len(int li, int max_len) { return min(max(l
 // ------------------------------------------------------------------------------------------
 // k_prepass
 // ------------------------------------------------------------------------------------------
-// The matrix is walked as a flat stream of 16-byte chunks, one chunk per lane per iteration, so
-// every wave-instruction loads 1 KiB of consecutive bytes.  Per byte: one ds_read_b64 from a
-// 256-entry float2 LUT {p, p(1-p)}, one packed f32 add (mu, var) and one fma (sum of p*p(1-p), from
-// which the third cumulant is var - 2*that).  Ambiguous bytes carry a large marker in the second
-// component (64 per 'N', 2048 per 'n'); the markers are peeled off each 16-byte sum with two floors,
-// without a branch.  Chunk partials go through LDS and are summed per read in a fixed order
-// (deterministic).  Requires stride <= 1024 (64 chunks per row; the C ABI enforces it).
+// A wave takes 64 reads per round, 16 at a time: lane (r, cl) = (lane & 15, lane >> 4) walks the
+// 16-byte chunks cl, cl+4, cl+8 ... of read r, so one load instruction covers 64 consecutive bytes
+// of each of 16 rows and every partial sum stays in registers until the row is done.  Per byte: one
+// ds_read_b64 from a 256-entry float2 LUT {p, p(1-p)}, one packed f32 add (mu, var) and one fma
+// (sum of p*p(1-p), from which the third cumulant is var - 2*that).  Ambiguous bytes carry a large
+// marker in the second component (128 per 'N', 65536 per 'n'; a lane sees at most 256 bytes, whose
+// p(1-p) sum to <= 64, so both counts come off the lane total exactly with two floors).  Chunks that
+// are complete in every lane of the wave take a path without any masking; the ragged tail fills the
+// bytes past the read's end with Q254 (p = 4e-26).  The four lanes of a read are then combined in a
+// fixed order (deterministic).  Requires stride <= 1024 (16 chunks per lane; the C ABI enforces it).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t mask_dword(uint32_t w, int nvalid_bytes)
@@ -100,9 +103,23 @@ __device__ __forceinline__ uint32_t fill_dword(uint32_t w, int nvalid_bytes)
     return (w & m) | (0xFEFEFEFEu & ~m);
 }
 
-#define MPB_PRE_SUB 320      // chunks per wave sub-batch (5 KiB of float4 partials per wave)
-#define MPB_MARK_UPPER 64.0f    // second LUT component of 'N' (16 real p(1-p) sum to <= 4)
-#define MPB_MARK_LOWER 2048.0f  // ... of 'n' (> 16 * 64)
+#define MPB_PRE_NB 5              // column quads (4 x 16 bytes of a row) loaded ahead
+#define MPB_MARK_UPPER 128.0f     // second LUT component of 'N'
+#define MPB_MARK_LOWER 65536.0f   // ... of 'n' (> 256 * 128)
+
+// 16 bases into the lane's running sums
+__device__ __forceinline__ void pre_chunk(const float2 *tab, const uint4 x, f32x2 &a01, float &s3)
+{
+    const uint32_t ww[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float2 e = tab[(ww[d] >> (8 * t)) & 0xffu];
+            a01 += (f32x2){e.x, e.y};
+            s3 = __builtin_fmaf(e.x, e.y, s3);            // p == 0 for marked bytes
+        }
+}
 
 __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, int64_t n,
                                                  int64_t stride, const int32_t *__restrict__ len,
@@ -113,7 +130,6 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                                                  uint8_t *__restrict__ pass_out)
 {
     __shared__ float2 s_tab[256];
-    __shared__ float4 s_part[4][MPB_PRE_SUB];
     __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts}
     __shared__ int s_hist[MPB_NCLS];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -126,75 +142,72 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
     if (tid < MPB_NCLS) s_hist[tid] = 0;
     __syncthreads();
 
-    const int cpr = (int)(stride >> 4);                                   // chunks per row
-    const int rs = min(16, max(1, MPB_PRE_SUB / cpr));                     // rows per sub-batch
-    const uint32_t inv = (uint32_t)(((1u << 20) + cpr - 1) / cpr);        // g / cpr == (g*inv) >> 20 for g*cpr < 2^20
-    const int cpp = (cpr + 3) >> 2;                                       // chunks per reducing lane
+    const int r16 = lane & 15, cl = lane >> 4;
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
     const int64_t wave_row0 = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + w * 64;
     if (wave_row0 >= n) break;                    // wave-uniform; nothing below is a block barrier
 
-    for (int rb = 0; rb < 64; rb += rs) {
-        const int rows_here = min(rs, 64 - rb);
-        const int nchunks = rows_here * cpr;
-        for (int g = lane; g < nchunks; g += 64) {
-            const int r = (int)(((uint32_t)g * inv) >> 20);
-            const int c = g - r * cpr;
-            const int64_t i = wave_row0 + rb + r;
-            float mu = 0.f, var = 0.f, s3 = 0.f, amb = 0.f;
-            if (i < n) {
-                const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
-                const int nv = li - c * 16;
-                if (nv > 0) {
-                    uint4 x = *reinterpret_cast<const uint4 *>(q + i * stride + c * 16);
-                    // bytes past the read's end become Q254 (p = 4e-26: contributes nothing)
-                    const uint32_t ww[4] = {fill_dword(x.x, nv), fill_dword(x.y, nv - 4),
-                                            fill_dword(x.z, nv - 8), fill_dword(x.w, nv - 12)};
-                    f32x2 a01 = {0.f, 0.f};
+    for (int rb = 0; rb < 64; rb += 16) {
+        const int64_t i = wave_row0 + rb + r16;
+        const bool live = i < n;
+        const int li = live ? (len ? clamp_len(len[i], prm.max_len) : prm.fixed_len) : 0;
+        int ncol = (li + 15) >> 4;                // chunk columns to walk: the longest read of the 16
+        int nfull = live ? (li >> 4) : 1024;      // columns complete in every live lane
+        if (len || wave_row0 + 64 > n) {
 #pragma unroll
-                    for (int d = 0; d < 4; d++)
-#pragma unroll
-                        for (int t = 0; t < 4; t++) {
-                            const float2 e = s_tab[(ww[d] >> (8 * t)) & 0xffu];
-                            a01 += (f32x2){e.x, e.y};
-                            s3 = __builtin_fmaf(e.x, e.y, s3);            // p == 0 for marked bytes
-                        }
-                    mu = a01.x;
-                    // second component = sum p(1-p) (< 4.1) + 64 per 'N' + 2048 per 'n': peel the markers
-                    const float n255 = floorf(a01.y * (1.0f / MPB_MARK_LOWER));
-                    const float rem = a01.y - MPB_MARK_LOWER * n255;
-                    const float nzero = floorf(rem * (1.0f / MPB_MARK_UPPER));
-                    var = rem - MPB_MARK_UPPER * nzero;
-                    amb = nzero + 1024.0f * n255;
-                }
+            for (int off = 8; off >= 1; off >>= 1) {
+                ncol = max(ncol, __shfl_xor(ncol, off));
+                nfull = min(nfull, __shfl_xor(nfull, off));
             }
-            const float k3 = var - 2.0f * s3;                              // sum p(1-p)(1-2p)
-            s_part[w][g] = make_float4(mu, var, k3, amb);
         }
-        wave_lds_fence();      // s_part[w] / s_row[w] are private to this wave: no block barrier
-        // 4 lanes per read sum its chunk partials in a fixed order
-        {
-            const int r = lane >> 2, part = lane & 3;
-            float mu = 0.f, var = 0.f, k3 = 0.f, amb = 0.f;
-            if (r < rows_here) {
-                const int c0 = part * cpp, c1 = min(cpr, c0 + cpp);
-                for (int c = c0; c < c1; c++) {
-                    const float4 e = s_part[w][r * cpr + c];
-                    mu += e.x; var += e.y; k3 += e.z; amb += e.w;
-                }
+        ncol = __builtin_amdgcn_readfirstlane(ncol);
+        nfull = __builtin_amdgcn_readfirstlane(nfull);
+        const uint8_t *src = q + (live ? i : (int64_t)0) * stride + cl * 16;
+        f32x2 a01 = {0.f, 0.f};
+        float s3 = 0.f;
+        // MPB_PRE_NB column quads at a time: all their loads are issued before the first byte is
+        // looked at (a row of 300 bases is one such batch), so a wave keeps 5 KiB in flight
+        for (int cb = 0; cb < ncol; cb += 4 * MPB_PRE_NB) {
+            uint4 xs[MPB_PRE_NB];
+#pragma unroll
+            for (int b = 0; b < MPB_PRE_NB; b++) {
+                const int c0 = cb + 4 * b;
+                xs[b] = make_uint4(0, 0, 0, 0);
+                if (c0 < ncol && li > (c0 + cl) * 16)
+                    xs[b] = *reinterpret_cast<const uint4 *>(src + c0 * 16);
             }
 #pragma unroll
-            for (int off = 1; off <= 2; off <<= 1) {
-                mu += __shfl_xor(mu, off);
-                var += __shfl_xor(var, off);
-                k3 += __shfl_xor(k3, off);
-                amb += __shfl_xor(amb, off);
+            for (int b = 0; b < MPB_PRE_NB; b++) {
+                const int c0 = cb + 4 * b;
+                if (c0 >= ncol) break;                     // wave-uniform
+                uint4 y = xs[b];
+                if (c0 + 4 > nfull) {                      // wave-uniform: ragged tail, fill past the end
+                    const int nv = li - (c0 + cl) * 16;
+                    y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
+                    y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
+                }
+                pre_chunk(s_tab, y, a01, s3);
             }
-            // one lane per read parks the sums; all 64 reads of the wave are classed together below
-            if (part == 0 && r < rows_here) s_row[w][rb + r] = make_float4(mu, var, k3, amb);
         }
-        wave_lds_fence();      // s_part[w] / s_row[w] are private to this wave: no block barrier
+        // second component = sum p(1-p) (<= 64) + 128 per 'N' + 65536 per 'n': peel the markers
+        const float n255 = floorf(a01.y * (1.0f / MPB_MARK_LOWER));
+        const float rem = a01.y - MPB_MARK_LOWER * n255;
+        const float nzero = floorf(rem * (1.0f / MPB_MARK_UPPER));
+        float mu = a01.x;
+        float var = rem - MPB_MARK_UPPER * nzero;
+        float k3 = var - 2.0f * s3;                                       // sum p(1-p)(1-2p)
+        float amb = nzero + 1024.0f * n255;
+        // the four lanes of a read, combined in a fixed order: (cl0 + cl1) + (cl2 + cl3)
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            mu += __shfl_xor(mu, off);
+            var += __shfl_xor(var, off);
+            k3 += __shfl_xor(k3, off);
+            amb += __shfl_xor(amb, off);
+        }
+        if (cl == 0) s_row[w][rb + r16] = make_float4(mu, var, k3, amb);
     }
+    wave_lds_fence();          // s_row[w] is private to this wave: no block barrier
     // ---- classing: one lane per read, all 64 lanes busy (was: 16 of 64, four times) ----
     {
         const int64_t i = wave_row0 + lane;
