@@ -103,7 +103,9 @@ __device__ __forceinline__ uint32_t fill_dword(uint32_t w, int nvalid_bytes)
     return (w & m) | (0xFEFEFEFEu & ~m);
 }
 
+#ifndef MPB_PRE_NB
 #define MPB_PRE_NB 5              // column quads (4 x 16 bytes of a row) loaded ahead
+#endif
 #define MPB_MARK_UPPER 128.0f     // second LUT component of 'N'
 #define MPB_MARK_LOWER 65536.0f   // ... of 'n' (> 256 * 128)
 
