@@ -1,0 +1,146 @@
+/*
+ * moira_io.h -- C ABI of libmoira_io.so: the text side of moira's pipeline, in C (host only, no HIP).
+ *
+ * moira.py reads FASTQ one Python string per line and one Python int per base
+ * (ref: moira/moira.py:1152-1204 parse_fastq, :1177 `[ord(x) - offset for x in ...]`) and formats
+ * every output record with Python string operations (ref: moira/moira.py:842-970 write_results).
+ * At 2 x 10^9 reads/s in the filter that text handling is the whole run time, so the CLI keeps a
+ * chunk of the input file as ONE byte buffer and lets these functions
+ *   1. index the records in it (offset/length of header token, sequence line, quality line),
+ *   2. pack selected records straight into the uint8 quality matrix the filter takes
+ *      (same rules as mpb_pack_read_ascii in moira_pb.h),
+ *   3. format selected records as fasta / qual / fastq text into a caller-owned buffer.
+ * Nothing here allocates or keeps state; every buffer is the caller's.  Return values < 0 are errors;
+ * mio_last_error() holds the message (thread-local).
+ */
+#ifndef MOIRA_IO_H
+#define MOIRA_IO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIO_OK 0
+#define MIO_E_INVALID (-1)      /* bad argument */
+#define MIO_E_UNSUPPORTED (-2)  /* content the byte-level parser does not reproduce: fall back to the line parser */
+#define MIO_E_RANGE (-3)        /* a quality outside 0..254 */
+#define MIO_E_SPACE (-4)        /* output buffer too small; the call reports the size it needs */
+
+/* per-record problems found by mio_fastq_index, in the order the reference checks them
+ * (ref: moira/moira.py:1178-1183) */
+#define MIO_REC_OK 0
+#define MIO_REC_EMPTY_SEQ 1
+#define MIO_REC_EMPTY_QUAL 2
+#define MIO_REC_LENGTH_MISMATCH 3
+
+/* columns of one row of the record index (int64 each) */
+#define MIO_HDR_OFF 0   /* header token: after strip(), up to the first space/tab, leading '@'s dropped */
+#define MIO_HDR_LEN 1   /*   (':' -> '_' is applied when the header is emitted, ref: moira/moira.py:1175) */
+#define MIO_SEQ_OFF 2   /* sequence line, stripped */
+#define MIO_SEQ_LEN 3
+#define MIO_QUAL_OFF 4  /* quality line, stripped */
+#define MIO_QUAL_LEN 5
+#define MIO_IDX_COLS 6
+
+const char *mio_version(void);
+const char *mio_last_error(void);
+
+/*
+ * Index the complete 4-line records in buf[0, len).  Lines end with "\n" or "\r\n"; `final` != 0
+ * means the buffer ends the file, so an unterminated last line counts.  Every 4 lines are one record
+ * whatever they contain, as in the reference's parser (ref: moira/moira.py:1166-1174), and trailing
+ * lines that do not make a record are ignored.
+ *   idx        [max_records][MIO_IDX_COLS]
+ *   consumed   bytes of buf covered by the returned records (the caller keeps the rest)
+ *   bad_kind   MIO_REC_* of the first record that fails the reference's checks (indexing stops
+ *              there: the returned count is that record's position), else MIO_REC_OK
+ * Returns the number of records indexed, or MIO_E_UNSUPPORTED when the chunk holds a lone "\r"
+ * (universal-newline line break) or a byte >= 0x80 (the text-mode parser decodes and strips by
+ * Unicode rules there).
+ */
+int64_t mio_fastq_index(const char *buf, int64_t len, int32_t final, int64_t max_records,
+                        int64_t *idx, int64_t *consumed, int32_t *bad_kind);
+
+/*
+ * Pack records sel[0..nsel) (rows of idx; sel == NULL: records 0..nsel-1) into an nsel x row_stride
+ * uint8 matrix: Q = byte - fastq_offset, Q0 -> 1, 'N' -> 0, 'n' -> 255 (or an ordinary base when
+ * lower_n_is_base != 0, the Python twin's rule the Poisson path follows, ref: moira/moira.py:1660),
+ * at most max_len bases (--truncate; <= 0: no limit), rows zero-padded.
+ *   lens_out   int32[nsel]  bases packed
+ *   flags_out  uint8[nsel]  bit 0: the packed part holds an upper-case 'N'   (may be NULL)
+ * Returns MIO_OK, MIO_E_RANGE (quality < 0 or > 254; *bad_record = position in sel) or MIO_E_INVALID
+ * (a read does not fit row_stride).
+ */
+int32_t mio_pack(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel,
+                 int32_t fastq_offset, int32_t max_len, int32_t lower_n_is_base, int64_t row_stride,
+                 uint8_t *out, int32_t *lens_out, uint8_t *flags_out, int64_t *bad_record);
+
+/*
+ * hash(str) of 64-bit CPython 2.7 for the (truncated) sequence of records 0..n-1.  The collapse step
+ * keeps the reference's output order, which for groups of equal abundance is the slot order of a
+ * Python-2 dict keyed by the sequence (ref: moira/moira.py:459-475, :492; moira_amd/py2dict.py).
+ */
+int32_t mio_py2_hash(const char *buf, const int64_t *idx, int64_t n, int32_t max_len, uint64_t *out);
+
+/* what mio_format writes per record */
+#define MIO_FMT_FASTA 0   /* ">hdr[\tlabel]\nSEQ\n"                 ref: moira/moira.py:904,930,939,954,963 */
+#define MIO_FMT_QUAL 1    /* ">hdr[\tlabel]\nq q q ...\n"           ref: moira/moira.py:905,931,940,955,964 */
+#define MIO_FMT_FASTQ 2   /* "@hdr[\tlabel]\nSEQ\n+\nQUALSTRING\n"  ref: moira/moira.py:902,928,937,952,961 */
+
+/*
+ * Format records sel[0..nsel) into out[0, cap).
+ *   relabel     NULL: the record's own header (':' -> '_'); else header = relabel + decimal(relabel_index[k])
+ *               (ref: moira/moira.py:854-855)
+ *   relabel_index  int64[nsel], required with relabel
+ *   ee          double[nsel] or NULL: when non-NULL ";ee=%.2f;size=1;" is appended to the header
+ *               (USEARCH pipeline, ref: moira/moira.py:858-863)
+ *   labels / label_id   label_id int32[nsel] or NULL; label_id[k] >= 0 appends "\t" + labels[label_id[k]]
+ *   max_len     bases written (--truncate; <= 0: all)
+ *   qualities are shown after the Q0 -> 1 clamp, as the reference's writer sees them
+ *   (ref: moira/moira.py:814).
+ * Returns the bytes written, or MIO_E_SPACE with *needed set when cap is too small.
+ */
+int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel, int32_t kind,
+                   int32_t fastq_offset, int32_t max_len, const char *relabel, const int64_t *relabel_index,
+                   const double *ee, const char *const *labels, const int32_t *label_id,
+                   char *out, int64_t cap, int64_t *needed);
+
+/* ---- collapse of identical sequences (ref: moira/moira.py:459-475, :490-493) -----------------
+ * The reference keeps one dict entry per distinct (truncated) sequence: the representative is the
+ * member with the strictly smallest expected errors (first seen wins ties), names_info lists the
+ * members' headers (a new representative is inserted in front, everything else appended), and the
+ * groups are written by decreasing abundance, equal abundances in Python-2 dict order.
+ * A mio_collapse object is that dict, owning copies of what it needs (sequences, the
+ * representatives' qualities, every header), so the input chunks can be released. */
+typedef struct mio_collapse mio_collapse;
+mio_collapse *mio_collapse_create(void);
+void mio_collapse_destroy(mio_collapse *c);
+int64_t mio_collapse_count(const mio_collapse *c);          /* distinct sequences so far */
+
+/* Add records 0..n-1 of a chunk in file order.  ee double[n] (after +Ns / floor), flags uint8[n] from
+ * mio_pack (may be NULL), max_len as in mio_pack. */
+int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, int64_t n, int32_t max_len,
+                         const double *ee, const uint8_t *flags);
+
+/* Fix the output order (moira/moira.py:492) and copy out, in that order, per group: the
+ * representative's ee, the sequence length, the abundance and the flags (any pointer may be NULL). */
+int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *size, uint8_t *flags);
+
+#define MIO_FMT_NAMES 3   /* "hdr\tname,name,...\n"   ref: moira/moira.py:880,919,933,943,957,967 */
+
+/* mio_format for groups sel[0..nsel) (positions in the exported order).  Header = the
+ * representative's, or relabel + (position + 1) (ref: moira/moira.py:493, :854-855); with usearch != 0
+ * ";ee=%.2f;size=%d;" is appended (size = abundance, ref: moira/moira.py:858-863).  MIO_FMT_NAMES
+ * writes the mothur names line of each group; lstrip_gt uint8[nsel] (may be NULL) drops leading '>'
+ * from that line's header where the reference does (ref: moira/moira.py:880,894,907,943). */
+int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t nsel, int32_t kind,
+                            int32_t fastq_offset, const char *relabel, int32_t usearch,
+                            const char *const *labels, const int32_t *label_id, const uint8_t *lstrip_gt,
+                            char *out, int64_t cap, int64_t *needed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -89,6 +89,24 @@ def build_contig(force=False, verbose=False):
     return _locked_build(CONTIG_LIB, CONTIG_DEPS, CONTIG_FLAGS, cmd, force, verbose)
 
 
+IO_LIB = os.path.join(HERE, "libmoira_io.so")
+IO_SRC = os.path.join(CSRC, "fastio.cpp")
+IO_DEPS = [IO_SRC, os.path.join(ROOT, "include", "moira_io.h")]
+IO_FLAGS = ["-O3", "-fPIC", "-shared", "-std=c++17", "-Wall"]
+
+
+def io_stale():
+    return _is_stale(IO_LIB, IO_DEPS, IO_FLAGS)
+
+
+def build_io(force=False, verbose=False):
+    """CPU-only text I/O library of the CLI (g++, no HIP): FASTQ indexing, packing, record formatting."""
+    if not force and not io_stale():
+        return IO_LIB
+    cmd = [CXX] + IO_FLAGS + [IO_SRC, "-o", IO_LIB]
+    return _locked_build(IO_LIB, IO_DEPS, IO_FLAGS, cmd, force, verbose)
+
+
 def stale():
     return _is_stale(LIB, DEPS, FLAGS)
 
@@ -103,5 +121,7 @@ def build(force=False, verbose=False, extra=()):
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     build_contig(force="--force" in sys.argv, verbose=True)
+    build_io(force="--force" in sys.argv, verbose=True)
     print(LIB)
     print(CONTIG_LIB)
+    print(IO_LIB)

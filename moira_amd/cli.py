@@ -266,6 +266,17 @@ def open_input(filename):
     return f
 
 
+def open_input_binary(filename):
+    """Same sniffing, bytes out: the C parser (moira_amd/fastio.py) takes whole blocks."""
+    with io.open(filename, "rb") as fh:
+        start = fh.read(3)
+    if start.startswith(b"\x42\x5a\x68"):
+        return bz2.open(filename, "rb")
+    if start.startswith(b"\x1f\x8b\x08"):
+        return gzip.open(filename, "rb")
+    return io.open(filename, "rb", buffering=0)
+
+
 def _norm(header, mark):
     # strip, tabs -> spaces, first token, drop the leading mark(s), ':' -> '_'   (moira.py:1121,1175)
     return header.strip().replace("\t", " ").split(" ")[0].lstrip(mark).replace(":", "_")
@@ -414,7 +425,17 @@ def make_gpu_backend(device=None):
         ee, ns, _ = filter_bucketed(eng, seqs, quals, method=method, alpha=alpha, ambigs=ambigs,
                                     round_=round_, uncert=1.0)
         return ee
+    def matrix(q, lens, alpha, ambigs, round_, method="poisson_binomial", fast_discard=None):
+        """The same for reads that are already packed (the byte-level FASTQ path): ee per read."""
+        if fast_discard is not None and method == "poisson_binomial":
+            uncert, maxerrors = fast_discard
+            r = eng.filter(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, uncert=uncert,
+                           maxerrors=maxerrors, decision_only=True)
+            return np.where(np.isnan(r.ee), np.inf, r.ee)
+        run = eng.filter_poisson if method == "poisson" else eng.filter
+        return run(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, uncert=1.0).ee
     backend.engine = eng
+    backend.matrix = matrix
     backend.methods = ("poisson_binomial", "poisson")
     return backend
 
@@ -548,13 +569,14 @@ def write_results(index, header, sequence, quals, expected_errors, names_info, o
     return bad(label, nh, (1, 0, 0))
 
 
-def _open_outputs(args, output_name):
+def _open_outputs(args, output_name, binary=False):
+    mode = "wb" if binary else "wt"
     if args.output_compression == "gz":
-        opener, suffix = (lambda p: gzip.open(p, "wt")), ".gz"
+        opener, suffix = (lambda p: gzip.open(p, mode)), ".gz"
     elif args.output_compression == "bz2":
-        opener, suffix = (lambda p: bz2.open(p, "wt")), ".bz2"
+        opener, suffix = (lambda p: bz2.open(p, mode)), ".bz2"
     else:
-        opener, suffix = (lambda p: open(p, "w")), ""
+        opener, suffix = (lambda p: open(p, mode[:2] if binary else "w")), ""
     o = Outputs()
 
     def mk(stem):
@@ -594,9 +616,134 @@ def _close(o):
 
 
 # ---------------------------------------------------------------------------------------------
+# byte-level path for single-end FASTQ (include/moira_io.h): same results, no per-read Python text work
+# ---------------------------------------------------------------------------------------------
+def _fast_eligible(args, backend):
+    return bool(args.forward_fastq and not args.paired and not args.only_contig and not args.min_overlap
+                and args.error_calc in ("poisson_binomial", "poisson_binomial_py", "poisson")
+                and getattr(backend, "matrix", None) is not None
+                and (args.error_calc != "poisson" or "poisson" in getattr(backend, "methods", ()))
+                and not os.environ.get("MOIRA_NO_FASTIO"))
+
+
+def _run_fast_fastq(args, backend, o, say, t0):
+    """Chunks of the input as (bytes, record index); packing and record formatting in C
+    (moira_amd/fastio.py).  Decisions are write_results' (ref: moira/moira.py:842-970), vectorised.
+    Returns (processed, discarded_errors, discarded_minlength)."""
+    from . import fastio as F
+    from .buckets import bucket_of
+    T = args.truncate or 0
+    method = "poisson" if args.error_calc == "poisson" else "poisson_binomial"
+    fd = None
+    if getattr(args, "fast_discard", False) and not args.collapse and args.pipeline == "mothur" \
+            and method == "poisson_binomial":
+        fd = (args.uncert, args.maxerrors)
+    fq = args.output_format == "fastq"
+    usearch = args.pipeline == "USEARCH"
+    if args.maxerrors:
+        thr_label = "errors > %.2f" % args.maxerrors
+    else:
+        thr_label = "uncert > %.3f" % args.uncert
+    labels = ["length below %s" % args.truncate, "contains ambiguities", thr_label]
+    processed = 0
+    disc_err = disc_len = 0.0
+    groups = F.Collapse() if args.collapse else None
+    fh = open_input_binary(args.forward_fastq)
+    try:
+        for buf, idx in F.FastqChunks(fh, CHUNK_READS):
+            n = len(idx)
+            lens = np.minimum(idx[:, F.SEQ_LEN], T) if T else idx[:, F.SEQ_LEN].copy()
+            strides = bucket_of(lens, 64)
+            ee = np.empty(n, np.float64)
+            has_n = np.empty(n, bool)
+            for stride in np.unique(strides):
+                sel = np.nonzero(strides == stride)[0]
+                q, ln, fl = F.pack(buf, idx, sel, args.fastq_offset, T, lower_n_is_base=(method == "poisson"),
+                                   stride=int(stride))
+                ee[sel] = backend.matrix(q, ln, args.alpha, args.ambigs, args.round, method=method, fast_discard=fd)
+                has_n[sel] = fl
+            nan = np.isnan(ee)
+            if nan.any():
+                raise ReturnedNaNError(F.header_of(buf, idx[int(np.argmax(nan))]))
+            if args.collapse:
+                groups.add(buf, idx, ee, has_n, T)
+            else:
+                label = np.full(n, -1, np.int32)
+                if args.maxerrors:
+                    keep = ee <= args.maxerrors
+                else:
+                    keep = ee <= lens * args.uncert                              # len(sequence) * uncert, in double
+                label[~keep] = 2
+                if args.ambigs == "disallow":
+                    label[has_n] = 1
+                if T:
+                    label[idx[:, F.SEQ_LEN] < T] = 0
+                disc_len += int((label == 0).sum())
+                disc_err += int((label > 0).sum())
+                good, bad = np.nonzero(label < 0)[0], np.nonzero(label >= 0)[0]
+                for sel, main_f, qual_f, lab in ((good, o.contig, o.qual, None), (bad, o.bad_contig, o.bad_qual, label)):
+                    if not len(sel):
+                        continue
+                    kw = dict(fastq_offset=args.fastq_offset, max_len=T,
+                              relabel=args.relabel or None, relabel_index=(processed + sel) if args.relabel else None,
+                              ee=ee[sel] if usearch else None,
+                              labels=labels if lab is not None else None,
+                              label_id=lab[sel] if lab is not None else None)
+                    if fq:
+                        main_f.write(F.format_records(buf, idx, sel, F.FMT_FASTQ, **kw))
+                    else:
+                        main_f.write(F.format_records(buf, idx, sel, F.FMT_FASTA, **kw))
+                        qual_f.write(F.format_records(buf, idx, sel, F.FMT_QUAL, **kw))
+            processed += n
+            if not args.silent:
+                say("%d sequences processed in %.1f seconds." % (processed, time.time() - t0))
+        if args.collapse:
+            # the groups by decreasing abundance (moira.py:490-493), then write_results' decisions per group
+            gee, glen, gsize, g_n = groups.export()
+            label = np.full(len(gee), -1, np.int32)
+            keep = (gee <= args.maxerrors) if args.maxerrors else (gee <= glen * args.uncert)
+            label[~keep] = 2
+            if args.ambigs == "disallow":
+                label[g_n] = 1
+            if T:
+                label[glen < T] = 0
+            disc_len += int(gsize[label == 0].sum())
+            disc_err += int(gsize[label > 0].sum())
+            names = args.pipeline == "mothur"
+            # header.lstrip('>') on the names line of "length below" and "errors >" groups (moira.py:880,943)
+            strip = (label == 0) | ((label == 2) & bool(args.maxerrors))
+            for sel, main_f, qual_f, names_f, lab in ((np.nonzero(label < 0)[0], o.contig, o.qual, o.names, None),
+                                                      (np.nonzero(label >= 0)[0], o.bad_contig, o.bad_qual, o.bad_names, label)):
+                if not len(sel):
+                    continue
+                kw = dict(fastq_offset=args.fastq_offset, relabel=args.relabel or None, usearch=usearch,
+                          labels=labels if lab is not None else None, label_id=lab[sel] if lab is not None else None)
+                if fq:
+                    main_f.write(groups.format(sel, F.FMT_FASTQ, **kw))
+                else:
+                    main_f.write(groups.format(sel, F.FMT_FASTA, **kw))
+                    qual_f.write(groups.format(sel, F.FMT_QUAL, **kw))
+                if names:
+                    names_f.write(groups.format(sel, F.FMT_NAMES, fastq_offset=args.fastq_offset,
+                                                relabel=args.relabel or None, usearch=usearch, lstrip_gt=strip[sel]))
+    except F.RecordError as e:
+        name = args.forward_fastq
+        if e.kind == F.REC_EMPTY_SEQ:
+            raise EmptySeqError(e.header, name)
+        if e.kind == F.REC_EMPTY_QUAL:
+            raise EmptyQualError(e.header, name)
+        raise LengthMismatchError(e.header, name)
+    finally:
+        fh.close()
+        if groups is not None:
+            groups.close()
+    return processed, disc_err, disc_len
+
+
+# ---------------------------------------------------------------------------------------------
 # main (ref: moira/moira.py:264-578)
 # ---------------------------------------------------------------------------------------------
-def main(args, backend=None, out=None):
+def main(args, backend=None, out=None, _no_fastio=False):
     """`backend(seqs, quals, alpha, ambigs, round) -> ee` defaults to the HIP library; the parameter
     exists so the host logic can be unit-tested on machines without a GPU."""
     def say(msg=""):
@@ -629,7 +776,6 @@ def main(args, backend=None, out=None):
             rf = open_input(args.reverse_fasta) if args.paired else None
             rq = open_input(args.reverse_qual) if args.paired else None
             parse = parse_fasta_and_qual(ff, fqf, rf, rq)
-        o = _open_outputs(args, output_name)
     except IOError as e:
         say(str(e))
         say()
@@ -637,6 +783,13 @@ def main(args, backend=None, out=None):
     needs_gpu = (not args.only_contig) and args.error_calc in ("poisson_binomial", "poisson_binomial_py", "poisson")
     if backend is None and needs_gpu:
         backend = make_gpu_backend(getattr(args, "device", None))
+    fast = _fast_eligible(args, backend) and not _no_fastio
+    try:
+        o = _open_outputs(args, output_name, binary=fast)
+    except IOError as e:
+        say(str(e))
+        say()
+        return 1
     try:
         processed = 0
         disc_err = disc_len = disc_ov = 0.0
@@ -669,13 +822,22 @@ def main(args, backend=None, out=None):
             if not args.silent:
                 say("%d sequences processed in %.1f seconds." % (processed, time.time() - t0))
 
-        for rec in parse:
-            chunk.append(rec)
-            if len(chunk) >= CHUNK_READS:
+        if fast:
+            from . import fastio
+            try:
+                processed, disc_err, disc_len = _run_fast_fastq(args, backend, o, say, t0)
+            except fastio.Unsupported:
+                # content the byte-level parser does not reproduce: start over with the line parser
+                _close(o)
+                return main(args, backend=backend, out=out, _no_fastio=True)
+        else:
+            for rec in parse:
+                chunk.append(rec)
+                if len(chunk) >= CHUNK_READS:
+                    flush(chunk)
+                    chunk = []
+            if chunk:
                 flush(chunk)
-                chunk = []
-        if chunk:
-            flush(chunk)
         if args.collapse:
             order = sorted(uniques, key=lambda s: len(uniques[s]["names_info"]), reverse=True)   # stable
             for index, sequence in enumerate(order, start=1):

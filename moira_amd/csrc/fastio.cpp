@@ -1,0 +1,477 @@
+// libmoira_io.so -- byte-level FASTQ indexing, packing and record formatting for the CLI
+// (C ABI in include/moira_io.h).  Host only; built with g++.
+//
+// Behaviour follows the reference's text handling (moira/moira.py:1152-1204 parse_fastq,
+// :842-970 write_results) as restated in moira_amd/cli.py; tests/test_fastio.py compares the two
+// paths byte for byte.
+#include "../../include/moira_io.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// what str.strip() removes from an ASCII string
+inline bool is_space(unsigned char c)
+{
+    return c == ' ' || (c >= 0x09 && c <= 0x0d) || (c >= 0x1c && c <= 0x1f);
+}
+
+struct Span { int64_t off, len; };
+
+inline Span strip(const char *buf, int64_t a, int64_t b)       // [a, b) -> stripped
+{
+    while (a < b && is_space((unsigned char)buf[a])) a++;
+    while (b > a && is_space((unsigned char)buf[b - 1])) b--;
+    return {a, b - a};
+}
+
+// decimal text of 1..254 (the qualities a .qual line can show), built once
+struct QualText {
+    char txt[256][4];
+    unsigned char len[256];
+    QualText()
+    {
+        for (int q = 0; q < 256; q++) len[q] = (unsigned char)snprintf(txt[q], 4, "%d", q > 999 ? 999 : q);
+    }
+};
+const QualText g_qt;
+
+struct Out {
+    char *p; int64_t cap, n;
+    inline void put(const char *s, int64_t k)
+    {
+        if (n + k <= cap) memcpy(p + n, s, (size_t)k);
+        n += k;
+    }
+    inline void ch(char c)
+    {
+        if (n < cap) p[n] = c;
+        n++;
+    }
+};
+
+}  // namespace
+
+// ---- collapse of identical sequences (ref: moira/moira.py:459-475, :490-493) --------------------
+
+struct mio_collapse {
+    struct Uniq {
+        int64_t seq_off, qual_off;       // arena offsets; the rep's qualities are re-pointed on a better rep
+        int32_t len;
+        uint8_t flags;
+        double ee;
+        int64_t size;                    // len(names_info)
+        int64_t front, back_head, back_tail;   // names: front-inserted (newest first), then first seen + appended
+    };
+    struct Name { int64_t off; int32_t len; int64_t next; };
+    struct Slot { uint64_t hash; int64_t uid; };             // uid < 0: empty
+    std::vector<char> arena;
+    std::vector<Uniq> uniq;
+    std::vector<Name> names;
+    std::vector<Slot> slots;                                 // CPython 2.7 dict layout: PyDict_MINSIZE 8
+    uint64_t mask = 7;
+    std::vector<int64_t> order;                              // output order, built by mio_collapse_export
+    mio_collapse() : slots(8, Slot{0, -1}) {}
+
+    int64_t put(const char *p, int64_t n)
+    {
+        const int64_t off = (int64_t)arena.size();
+        arena.insert(arena.end(), p, p + n);
+        return off;
+    }
+    // lookdict / insertdict_clean of CPython 2.7 (no deletions): first empty slot of the probe sequence
+    int64_t *find(uint64_t h, const char *key, int64_t len, Slot **where)
+    {
+        uint64_t i = h & mask, perturb = h;
+        for (;;) {
+            Slot &sl = slots[i & mask];
+            if (sl.uid < 0) { *where = &sl; return nullptr; }
+            if (sl.hash == h) {
+                const Uniq &u = uniq[sl.uid];
+                if (u.len == len && memcmp(arena.data() + u.seq_off, key, (size_t)len) == 0) return &sl.uid;
+            }
+            i = (i << 2) + i + perturb + 1;
+            perturb >>= 5;
+        }
+    }
+    void place(uint64_t h, int64_t uid)
+    {
+        uint64_t i = h & mask, perturb = h;
+        for (;;) {
+            Slot &sl = slots[i & mask];
+            if (sl.uid < 0) { sl.hash = h; sl.uid = uid; return; }
+            i = (i << 2) + i + perturb + 1;
+            perturb >>= 5;
+        }
+    }
+    void maybe_resize()
+    {
+        const uint64_t used = uniq.size();
+        if (used * 3 < (mask + 1) * 2) return;
+        const uint64_t minused = (used > 50000 ? 2 : 4) * used;      // dictresize(): 4 x used, 2 x above 50000
+        uint64_t newsize = 8;
+        while (newsize <= minused) newsize <<= 1;
+        std::vector<Slot> old;
+        old.swap(slots);
+        slots.assign(newsize, Slot{0, -1});
+        mask = newsize - 1;
+        for (const Slot &e : old)                                     // re-inserted in old slot order
+            if (e.uid >= 0) place(e.hash, e.uid);
+    }
+};
+
+namespace {
+
+uint64_t py2_hash(const unsigned char *s, int64_t L)
+{
+    if (L <= 0) return 0;
+    uint64_t x = (uint64_t)s[0] << 7;
+    for (int64_t i = 0; i < L; i++) x = (1000003ull * x) ^ s[i];
+    x ^= (uint64_t)L;
+    if (x == ~0ull) x = ~0ull - 1;
+    return x;
+}
+
+void put_quals(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset)
+{
+    if (o.n + 4 * L <= o.cap) {                               // ' '.join(map(str, quals)); fast when it fits
+        char *w = o.p + o.n;
+        for (int64_t i = 0; i < L; i++) {
+            int q = (int)ql[i] - fastq_offset;
+            q = q <= 0 ? 1 : q > 255 ? 255 : q;               // (packing has already rejected q < 0 / > 254)
+            memcpy(w, g_qt.txt[q], 4);
+            w += g_qt.len[q];
+            *w++ = ' ';
+        }
+        if (L > 0) w--;                                       // no trailing separator
+        o.n = w - o.p;
+    } else {
+        for (int64_t i = 0; i < L; i++) {
+            int q = (int)ql[i] - fastq_offset;
+            q = q <= 0 ? 1 : q > 255 ? 255 : q;
+            o.n += g_qt.len[q] + (i + 1 < L ? 1 : 0);
+        }
+    }
+}
+
+void put_qual_string(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset)
+{
+    // chr(q + offset) of the clamped qualities = the input string with Q0 shown as Q1
+    if (o.n + L <= o.cap)
+        for (int64_t i = 0; i < L; i++) o.p[o.n + i] = (char)(ql[i] == fastq_offset ? ql[i] + 1 : ql[i]);
+    o.n += L;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mio_version(void) { return "moira_io 0.1"; }
+const char *mio_last_error(void) { return g_err; }
+
+int64_t mio_fastq_index(const char *buf, int64_t len, int32_t final, int64_t max_records,
+                        int64_t *idx, int64_t *consumed, int32_t *bad_kind)
+{
+    if (!buf || len < 0 || max_records < 0 || !idx || !consumed || !bad_kind)
+        return fail(MIO_E_INVALID, "mio_fastq_index: bad arguments");
+    *consumed = 0;
+    *bad_kind = MIO_REC_OK;
+    int64_t n = 0, pos = 0;
+    Span line[4];
+    while (n < max_records) {
+        int64_t p = pos;
+        int k = 0;
+        for (; k < 4; k++) {
+            if (p >= len) break;
+            const char *nl = (const char *)memchr(buf + p, '\n', (size_t)(len - p));
+            int64_t e;
+            if (nl) e = nl - buf;
+            else if (final) e = len;
+            else break;
+            // a "\r" that is not the one before "\n" would be a line break of its own
+            const char *cr = (const char *)memchr(buf + p, '\r', (size_t)(e - p));
+            if (cr && !(nl && cr == nl - 1)) return fail(MIO_E_UNSUPPORTED, "lone carriage return");
+            unsigned char any = 0;
+            for (int64_t t = p; t < e; t++) any |= (unsigned char)buf[t];
+            if (any & 0x80) return fail(MIO_E_UNSUPPORTED, "non-ASCII byte");
+            line[k] = strip(buf, p, e);
+            p = nl ? e + 1 : e;
+        }
+        if (k < 4) break;                                   // incomplete record: wait for more input
+        // header: replace('\t',' ').split(' ')[0].lstrip('@')                  moira.py:1175
+        int64_t h0 = line[0].off, h1 = h0;
+        const int64_t hend = line[0].off + line[0].len;
+        while (h1 < hend && buf[h1] != ' ' && buf[h1] != '\t') h1++;
+        while (h0 < h1 && buf[h0] == '@') h0++;
+        int64_t *r = idx + n * MIO_IDX_COLS;
+        r[MIO_HDR_OFF] = h0; r[MIO_HDR_LEN] = h1 - h0;
+        r[MIO_SEQ_OFF] = line[1].off; r[MIO_SEQ_LEN] = line[1].len;
+        r[MIO_QUAL_OFF] = line[3].off; r[MIO_QUAL_LEN] = line[3].len;
+        int bad = MIO_REC_OK;                                // moira.py:1178-1183, in this order
+        if (line[1].len == 0) bad = MIO_REC_EMPTY_SEQ;
+        else if (line[3].len == 0) bad = MIO_REC_EMPTY_QUAL;
+        else if (line[1].len != line[3].len) bad = MIO_REC_LENGTH_MISMATCH;
+        if (bad) { *bad_kind = bad; break; }                 // idx row n describes the offending record
+        n++;
+        pos = p;
+        *consumed = pos;
+    }
+    return n;
+}
+
+int32_t mio_pack(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel,
+                 int32_t fastq_offset, int32_t max_len, int32_t lower_n_is_base, int64_t row_stride,
+                 uint8_t *out, int32_t *lens_out, uint8_t *flags_out, int64_t *bad_record)
+{
+    if (!buf || !idx || nsel < 0 || row_stride <= 0 || (nsel > 0 && (!out || !lens_out)))
+        return fail(MIO_E_INVALID, "mio_pack: bad arguments");
+    for (int64_t k = 0; k < nsel; k++) {
+        const int64_t *r = idx + (sel ? sel[k] : k) * MIO_IDX_COLS;
+        int64_t L = r[MIO_QUAL_LEN];
+        if (max_len > 0 && L > max_len) L = max_len;
+        if (L > row_stride) {
+            if (bad_record) *bad_record = k;
+            return fail(MIO_E_INVALID, "read of %lld bases does not fit a %lld-byte row", (long long)L, (long long)row_stride);
+        }
+        const unsigned char *sq = (const unsigned char *)buf + r[MIO_SEQ_OFF];
+        const unsigned char *ql = (const unsigned char *)buf + r[MIO_QUAL_OFF];
+        uint8_t *row = out + k * row_stride;
+        int lo = 0, hi = 0;
+        unsigned char any_n = 0;
+        for (int64_t i = 0; i < L; i++) {
+            int q = (int)ql[i] - fastq_offset;               // moira.py:1177
+            lo |= q;                                         // sign bit set <=> some q < 0
+            hi |= 254 - q;                                   // sign bit set <=> some q > 254
+            q = q == 0 ? 1 : q;                              // moira.py:814, bernoullimodule.c:104-107
+            const unsigned char b = sq[i];
+            const bool up = b == 'N', low = b == 'n' && !lower_n_is_base;   // bernoullimodule.c:196
+            any_n |= (unsigned char)up;
+            row[i] = up ? 0 : low ? 255 : (uint8_t)q;
+        }
+        if ((lo | hi) < 0) {
+            if (bad_record) *bad_record = k;
+            if (lo < 0) return fail(MIO_E_RANGE, "Qualities must have positive values.");
+            return fail(MIO_E_RANGE, "quality exceeds the encodable maximum 254");
+        }
+        memset(row + L, 0, (size_t)(row_stride - L));
+        lens_out[k] = (int32_t)L;
+        if (flags_out) flags_out[k] = any_n;
+    }
+    return MIO_OK;
+}
+
+int32_t mio_py2_hash(const char *buf, const int64_t *idx, int64_t n, int32_t max_len, uint64_t *out)
+{
+    if (!buf || !idx || n < 0 || (n > 0 && !out)) return fail(MIO_E_INVALID, "mio_py2_hash: bad arguments");
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t *r = idx + k * MIO_IDX_COLS;
+        int64_t L = r[MIO_SEQ_LEN];
+        if (max_len > 0 && L > max_len) L = max_len;
+        const unsigned char *s = (const unsigned char *)buf + r[MIO_SEQ_OFF];
+        out[k] = py2_hash(s, L);                              // CPython 2.7 Objects/stringobject.c string_hash
+    }
+    return MIO_OK;
+}
+
+int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel, int32_t kind,
+                   int32_t fastq_offset, int32_t max_len, const char *relabel, const int64_t *relabel_index,
+                   const double *ee, const char *const *labels, const int32_t *label_id,
+                   char *out, int64_t cap, int64_t *needed)
+{
+    if (!buf || !idx || nsel < 0 || kind < MIO_FMT_FASTA || kind > MIO_FMT_FASTQ || cap < 0 || (cap > 0 && !out) ||
+        (relabel && !relabel_index) || (label_id && !labels))
+        return fail(MIO_E_INVALID, "mio_format: bad arguments");
+    Out o{out, cap, 0};
+    const int64_t relabel_len = relabel ? (int64_t)strlen(relabel) : 0;
+    char num[64];
+    for (int64_t k = 0; k < nsel; k++) {
+        const int64_t *r = idx + (sel ? sel[k] : k) * MIO_IDX_COLS;
+        o.ch(kind == MIO_FMT_FASTQ ? '@' : '>');
+        if (relabel) {                                       // moira.py:854-855
+            o.put(relabel, relabel_len);
+            o.put(num, snprintf(num, sizeof(num), "%lld", (long long)relabel_index[k]));
+        } else {
+            const char *h = buf + r[MIO_HDR_OFF];
+            const int64_t hl = r[MIO_HDR_LEN];
+            if (o.n + hl <= o.cap)
+                for (int64_t i = 0; i < hl; i++) o.p[o.n + i] = h[i] == ':' ? '_' : h[i];   // moira.py:1175
+            o.n += hl;
+        }
+        if (ee) o.put(num, snprintf(num, sizeof(num), ";ee=%.2f;size=1;", ee[k]));           // moira.py:858-863
+        if (label_id && label_id[k] >= 0) {
+            const char *lab = labels[label_id[k]];
+            o.ch('\t');
+            o.put(lab, (int64_t)strlen(lab));
+        }
+        o.ch('\n');
+        int64_t L = r[MIO_SEQ_LEN];
+        if (max_len > 0 && L > max_len) L = max_len;
+        if (kind != MIO_FMT_QUAL) {
+            o.put(buf + r[MIO_SEQ_OFF], L);
+            o.ch('\n');
+        }
+        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); }
+        if (kind != MIO_FMT_FASTA) {
+            const unsigned char *ql = (const unsigned char *)buf + r[MIO_QUAL_OFF];
+            if (kind == MIO_FMT_FASTQ) put_qual_string(o, ql, L, fastq_offset);
+            else put_quals(o, ql, L, fastq_offset);
+            o.ch('\n');
+        }
+    }
+    if (needed) *needed = o.n;
+    if (o.n > cap) return fail(MIO_E_SPACE, "output needs %lld bytes", (long long)o.n);
+    return o.n;
+}
+
+
+mio_collapse *mio_collapse_create(void) { return new (std::nothrow) mio_collapse(); }
+void mio_collapse_destroy(mio_collapse *c) { delete c; }
+int64_t mio_collapse_count(const mio_collapse *c) { return c ? (int64_t)c->uniq.size() : 0; }
+
+int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, int64_t n, int32_t max_len,
+                         const double *ee, const uint8_t *flags)
+{
+    if (!c || !buf || !idx || n < 0 || (n > 0 && !ee)) return fail(MIO_E_INVALID, "mio_collapse_add: bad arguments");
+    try {
+        c->order.clear();
+        std::vector<char> hdr;
+        for (int64_t k = 0; k < n; k++) {
+            const int64_t *r = idx + k * MIO_IDX_COLS;
+            int64_t L = r[MIO_SEQ_LEN];
+            if (max_len > 0 && L > max_len) L = max_len;
+            const char *seq = buf + r[MIO_SEQ_OFF];
+            hdr.assign(buf + r[MIO_HDR_OFF], buf + r[MIO_HDR_OFF] + r[MIO_HDR_LEN]);
+            for (char &ch : hdr) if (ch == ':') ch = '_';                           // moira.py:1175
+            const int64_t name_id = (int64_t)c->names.size();
+            c->names.push_back({c->put(hdr.data(), (int64_t)hdr.size()), (int32_t)hdr.size(), -1});
+            const uint64_t h = py2_hash((const unsigned char *)seq, L);
+            mio_collapse::Slot *where = nullptr;
+            int64_t *hit = c->find(h, seq, L, &where);
+            if (!hit) {                                                             // moira.py:461-464
+                mio_collapse::Uniq u;
+                u.seq_off = c->put(seq, L);
+                u.qual_off = c->put(buf + r[MIO_QUAL_OFF], L);
+                u.len = (int32_t)L; u.flags = flags ? flags[k] : 0; u.ee = ee[k]; u.size = 1;
+                u.front = -1; u.back_head = u.back_tail = name_id;
+                where->hash = h; where->uid = (int64_t)c->uniq.size();
+                c->uniq.push_back(u);
+                c->maybe_resize();
+            } else {
+                mio_collapse::Uniq &u = c->uniq[*hit];
+                u.size++;
+                if (ee[k] < u.ee) {                                                 // moira.py:466-471: strict <
+                    u.ee = ee[k];
+                    u.qual_off = c->put(buf + r[MIO_QUAL_OFF], L);
+                    c->names[name_id].next = u.front;                               // names_info.insert(0, header)
+                    u.front = name_id;
+                } else {                                                            // names_info.append(header)
+                    c->names[u.back_tail].next = name_id;
+                    u.back_tail = name_id;
+                }
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(MIO_E_INVALID, "out of memory while collapsing");
+    }
+    return MIO_OK;
+}
+
+int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *size, uint8_t *flags)
+{
+    if (!c) return fail(MIO_E_INVALID, "mio_collapse_export: bad arguments");
+    // sorted(uniques, key=abundance, reverse=True): stable, on dict iteration (= slot) order  moira.py:492
+    c->order.clear();
+    for (const auto &sl : c->slots)
+        if (sl.uid >= 0) c->order.push_back(sl.uid);
+    std::stable_sort(c->order.begin(), c->order.end(),
+                     [c](int64_t a, int64_t b) { return c->uniq[a].size > c->uniq[b].size; });
+    for (size_t k = 0; k < c->order.size(); k++) {
+        const auto &u = c->uniq[c->order[k]];
+        if (ee) ee[k] = u.ee;
+        if (len) len[k] = u.len;
+        if (size) size[k] = u.size;
+        if (flags) flags[k] = u.flags;
+    }
+    return MIO_OK;
+}
+
+int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t nsel, int32_t kind,
+                            int32_t fastq_offset, const char *relabel, int32_t usearch,
+                            const char *const *labels, const int32_t *label_id, const uint8_t *lstrip_gt,
+                            char *out, int64_t cap, int64_t *needed)
+{
+    if (!c || nsel < 0 || (nsel > 0 && !sel) || kind < MIO_FMT_FASTA || kind > MIO_FMT_NAMES || cap < 0 ||
+        (cap > 0 && !out) || (label_id && !labels))
+        return fail(MIO_E_INVALID, "mio_collapse_format: bad arguments");
+    if (c->order.size() != c->uniq.size()) return fail(MIO_E_INVALID, "call mio_collapse_export first");
+    Out o{out, cap, 0};
+    const int64_t relabel_len = relabel ? (int64_t)strlen(relabel) : 0;
+    const char *A = c->arena.data();
+    char num[96];
+    std::vector<char> hdr;
+    for (int64_t k = 0; k < nsel; k++) {
+        if (sel[k] < 0 || sel[k] >= (int64_t)c->order.size()) return fail(MIO_E_INVALID, "selection out of range");
+        const auto &u = c->uniq[c->order[sel[k]]];
+        const auto &rep = c->names[u.front >= 0 ? u.front : u.back_head];           // names_info[0] == rep_header
+        hdr.clear();
+        if (relabel) {                                                              // moira.py:854-855, index from 1
+            hdr.insert(hdr.end(), relabel, relabel + relabel_len);
+            const int m = snprintf(num, sizeof(num), "%lld", (long long)(sel[k] + 1));
+            hdr.insert(hdr.end(), num, num + m);
+        } else {
+            hdr.insert(hdr.end(), A + rep.off, A + rep.off + rep.len);
+        }
+        if (usearch) {                                                              // moira.py:858-863
+            const int m = snprintf(num, sizeof(num), ";ee=%.2f;size=%lld;", u.ee, (long long)u.size);
+            hdr.insert(hdr.end(), num, num + m);
+        }
+        if (kind == MIO_FMT_NAMES) {                                                // "%s\t%s\n" % (header, ",".join(names_info))
+            size_t h0 = 0;
+            if (lstrip_gt && lstrip_gt[k])
+                while (h0 < hdr.size() && hdr[h0] == '>') h0++;
+            o.put(hdr.data() + h0, (int64_t)(hdr.size() - h0));
+            o.ch('\t');
+            bool first = true;
+            for (int pass = 0; pass < 2; pass++)
+                for (int64_t id = pass == 0 ? u.front : u.back_head; id >= 0; id = c->names[id].next) {
+                    if (!first) o.ch(',');
+                    first = false;
+                    o.put(A + c->names[id].off, c->names[id].len);
+                }
+            o.ch('\n');
+            continue;
+        }
+        o.ch(kind == MIO_FMT_FASTQ ? '@' : '>');
+        o.put(hdr.data(), (int64_t)hdr.size());
+        if (label_id && label_id[k] >= 0) {
+            const char *lab = labels[label_id[k]];
+            o.ch('\t');
+            o.put(lab, (int64_t)strlen(lab));
+        }
+        o.ch('\n');
+        if (kind != MIO_FMT_QUAL) { o.put(A + u.seq_off, u.len); o.ch('\n'); }
+        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); put_qual_string(o, (const unsigned char *)A + u.qual_off, u.len, fastq_offset); o.ch('\n'); }
+        if (kind == MIO_FMT_QUAL) { put_quals(o, (const unsigned char *)A + u.qual_off, u.len, fastq_offset); o.ch('\n'); }
+    }
+    if (needed) *needed = o.n;
+    if (o.n > cap) return fail(MIO_E_SPACE, "output needs %lld bytes", (long long)o.n);
+    return o.n;
+}
+
+}  // extern "C"

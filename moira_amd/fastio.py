@@ -1,0 +1,259 @@
+"""ctypes front-end of libmoira_io.so (include/moira_io.h): the CLI's text handling in C.
+
+A chunk of the input file stays ONE bytes object; records are rows of an int64 index into it.
+`FastqChunks` yields (buf, idx) chunks; `pack` builds the uint8 quality matrix of selected records;
+`format_records` renders selected records as fasta / qual / fastq bytes.
+(ref: moira/moira.py:1152-1204 parse_fastq, :842-970 write_results.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmoira_io.so")
+E_INVALID, E_UNSUPPORTED, E_RANGE, E_SPACE = -1, -2, -3, -4
+REC_OK, REC_EMPTY_SEQ, REC_EMPTY_QUAL, REC_LENGTH_MISMATCH = 0, 1, 2, 3
+HDR_OFF, HDR_LEN, SEQ_OFF, SEQ_LEN, QUAL_OFF, QUAL_LEN, IDX_COLS = 0, 1, 2, 3, 4, 5, 6
+FMT_FASTA, FMT_QUAL, FMT_FASTQ, FMT_NAMES = 0, 1, 2, 3
+_lib = None
+
+
+class Unsupported(Exception):
+    """The byte-level parser met content it does not reproduce (lone CR, non-ASCII): use the line parser."""
+
+
+class RecordError(Exception):
+    """A record failed one of the reference's checks; .kind is REC_*, .header the normalised header."""
+
+    def __init__(self, kind, header):
+        Exception.__init__(self, kind, header)
+        self.kind, self.header = kind, header
+
+
+PROTOTYPES = {
+    "mio_version": (C.c_char_p, []),
+    "mio_last_error": (C.c_char_p, []),
+    "mio_fastq_index": (C.c_int64, [C.c_char_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mio_pack": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                             C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mio_py2_hash": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "mio_collapse_create": (C.c_void_p, []),
+    "mio_collapse_destroy": (None, [C.c_void_p]),
+    "mio_collapse_count": (C.c_int64, [C.c_void_p]),
+    "mio_collapse_add": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mio_collapse_export": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mio_collapse_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mio_format": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_void_p]),
+}
+
+
+def load():
+    global _lib
+    if _lib is None:
+        from . import build as _build
+        if _build.io_stale():
+            _build.build_io()
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _err():
+    return load().mio_last_error().decode()
+
+
+def header_of(buf, row):
+    """The normalised header of one index row (moira.py:1175)."""
+    return buf[row[HDR_OFF]:row[HDR_OFF] + row[HDR_LEN]].decode("ascii").replace(":", "_")
+
+
+def index(buf, final, max_records):
+    """-> (idx int64[n, 6], consumed bytes, bad) ; bad is None or a RecordError for the record after the n-th."""
+    L = load()
+    idx = np.empty((max(max_records, 1) + 0, IDX_COLS), np.int64)
+    consumed = C.c_int64(0)
+    bad = C.c_int32(0)
+    n = L.mio_fastq_index(buf, len(buf), 1 if final else 0, max_records, idx.ctypes.data, C.addressof(consumed),
+                          C.addressof(bad))
+    if n == E_UNSUPPORTED:
+        raise Unsupported(_err())
+    if n < 0:
+        raise ValueError(_err())
+    err = RecordError(bad.value, header_of(buf, idx[n])) if bad.value else None
+    return idx[:n], consumed.value, err
+
+
+def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, stride=None):
+    """-> (q uint8[nsel, stride], lens int32[nsel], has_upper_N bool[nsel])"""
+    L = load()
+    if sel is not None:
+        sel = np.ascontiguousarray(sel, np.int64)
+    n = len(sel) if sel is not None else len(idx)
+    if stride is None:
+        ql = idx[:, QUAL_LEN] if sel is None else idx[sel, QUAL_LEN]
+        longest = int(ql.max()) if n else 1
+        if max_len > 0:
+            longest = min(longest, max_len)
+        stride = (max(longest, 1) + 15) // 16 * 16
+    q = np.empty((n, stride), np.uint8)
+    lens = np.empty(n, np.int32)
+    flags = np.empty(n, np.uint8)
+    bad = C.c_int64(-1)
+    rc = L.mio_pack(buf, idx.ctypes.data, sel.ctypes.data if sel is not None else None, n, int(fastq_offset),
+                    int(max_len), 1 if lower_n_is_base else 0, stride, q.ctypes.data, lens.ctypes.data,
+                    flags.ctypes.data, C.addressof(bad))
+    if rc:
+        raise ValueError(_err())
+    return q, lens, flags.astype(bool)
+
+
+def py2_hashes(buf, idx, max_len=0):
+    """CPython-2.7 hash(str) of every record's (truncated) sequence, as Python ints."""
+    out = np.empty(len(idx), np.uint64)
+    if load().mio_py2_hash(buf, idx.ctypes.data, len(idx), int(max_len), out.ctypes.data):
+        raise ValueError(_err())
+    return out.tolist()
+
+
+def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None, relabel_index=None, ee=None,
+                   labels=None, label_id=None):
+    """Selected records as one bytes-like object (kind: FMT_FASTA / FMT_QUAL / FMT_FASTQ)."""
+    L = load()
+    sel = np.ascontiguousarray(sel, np.int64)
+    n = len(sel)
+    if n == 0:
+        return b""
+    idx = np.ascontiguousarray(idx)
+    if relabel is not None:
+        relabel_index = np.ascontiguousarray(relabel_index, np.int64)
+    if ee is not None:
+        ee = np.ascontiguousarray(ee, np.float64)
+    lab_arr = None
+    if label_id is not None:
+        label_id = np.ascontiguousarray(label_id, np.int32)
+        enc = [s.encode() for s in labels]
+        lab_arr = (C.c_char_p * len(enc))(*enc)
+    L_ = np.minimum(idx[sel, SEQ_LEN], max_len) if max_len > 0 else idx[sel, SEQ_LEN]
+    per = 4 if kind == FMT_QUAL else (2 if kind == FMT_FASTQ else 1)
+    cap = int(L_.sum()) * per + int(idx[sel, HDR_LEN].sum()) + n * (64 + (len(relabel) if relabel else 0)
+                                                                   + (max(map(len, labels)) if labels else 0))
+    out = np.empty(cap, np.uint8)
+    needed = C.c_int64(0)
+    args = (buf, idx.ctypes.data, sel.ctypes.data, n, kind, int(fastq_offset), int(max_len),
+            relabel.encode() if relabel is not None else None,
+            relabel_index.ctypes.data if relabel is not None else None,
+            ee.ctypes.data if ee is not None else None,
+            C.cast(lab_arr, C.c_void_p) if lab_arr is not None else None,
+            label_id.ctypes.data if label_id is not None else None)
+    w = L.mio_format(*args, out.ctypes.data, cap, C.addressof(needed))
+    if w == E_SPACE:
+        cap = needed.value
+        out = np.empty(cap, np.uint8)
+        w = L.mio_format(*args, out.ctypes.data, cap, C.addressof(needed))
+    if w < 0:
+        raise ValueError(_err())
+    return memoryview(out)[:w]
+
+
+class Collapse:
+    """The reference's `uniques` dict (moira/moira.py:459-475) kept in C: add chunks, export the groups
+    in output order, format them."""
+
+    def __init__(self):
+        self.lib = load()
+        self.h = self.lib.mio_collapse_create()
+        if not self.h:
+            raise MemoryError("mio_collapse_create failed")
+
+    def close(self):
+        if self.h:
+            self.lib.mio_collapse_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __len__(self):
+        return self.lib.mio_collapse_count(self.h)
+
+    def add(self, buf, idx, ee, flags, max_len=0):
+        idx = np.ascontiguousarray(idx)
+        ee = np.ascontiguousarray(ee, np.float64)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        if self.lib.mio_collapse_add(self.h, buf, idx.ctypes.data, len(idx), int(max_len), ee.ctypes.data,
+                                     flags.ctypes.data):
+            raise ValueError(_err())
+
+    def export(self):
+        """-> (ee, length, abundance, has_upper_N) per group, in output order."""
+        n = len(self)
+        ee, ln, size, fl = np.empty(n), np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.uint8)
+        if self.lib.mio_collapse_export(self.h, ee.ctypes.data, ln.ctypes.data, size.ctypes.data, fl.ctypes.data):
+            raise ValueError(_err())
+        self._len, self._size = ln, size
+        return ee, ln, size, fl.astype(bool)
+
+    def format(self, sel, kind, fastq_offset=33, relabel=None, usearch=False, labels=None, label_id=None,
+               lstrip_gt=None):
+        sel = np.ascontiguousarray(sel, np.int64)
+        n = len(sel)
+        if n == 0:
+            return b""
+        lab_arr = None
+        if label_id is not None:
+            label_id = np.ascontiguousarray(label_id, np.int32)
+            enc = [s.encode() for s in labels]
+            lab_arr = (C.c_char_p * len(enc))(*enc)
+        if lstrip_gt is not None:
+            lstrip_gt = np.ascontiguousarray(lstrip_gt, np.uint8)
+        args = (self.h, sel.ctypes.data, n, kind, int(fastq_offset), relabel.encode() if relabel else None,
+                1 if usearch else 0, C.cast(lab_arr, C.c_void_p) if lab_arr is not None else None,
+                label_id.ctypes.data if label_id is not None else None,
+                lstrip_gt.ctypes.data if lstrip_gt is not None else None)
+        needed = C.c_int64(0)
+        cap = int(self._len[sel].sum()) * (4 if kind == FMT_QUAL else 2) + n * 128
+        out = np.empty(cap, np.uint8)
+        w = self.lib.mio_collapse_format(*args, out.ctypes.data, cap, C.addressof(needed))
+        if w == E_SPACE:
+            cap = needed.value
+            out = np.empty(cap, np.uint8)
+            w = self.lib.mio_collapse_format(*args, out.ctypes.data, cap, C.addressof(needed))
+        if w < 0:
+            raise ValueError(_err())
+        return memoryview(out)[:w]
+
+
+class FastqChunks:
+    """Iterate a binary FASTQ stream as (buf, idx) chunks of at most `max_records` records.
+    Raises Unsupported before anything has been yielded from a chunk the C parser cannot take."""
+
+    def __init__(self, fh, max_records, block_bytes=1 << 25):
+        self.fh, self.max_records, self.block = fh, max_records, block_bytes
+
+    def __iter__(self):
+        tail = b""
+        eof = False
+        while not eof or tail:
+            if not eof:
+                more = self.fh.read(self.block)
+                if more:
+                    tail = tail + more if tail else more
+                else:
+                    eof = True
+            while tail:
+                idx, consumed, err = index(tail, eof, self.max_records)
+                if len(idx):
+                    yield tail, idx
+                if err is not None:
+                    raise err
+                tail = tail[consumed:]
+                if len(idx) < self.max_records:
+                    break                       # the rest is an incomplete record: read on
+            if eof:
+                return                          # trailing lines that do not make a record are dropped

@@ -44,6 +44,17 @@ class Py2Dict:
     def __len__(self):
         return self.used
 
+    def get(self, key, default=None):
+        return self.values.get(key, default)
+
+    def insert(self, key, value, h):
+        """__setitem__ for a NEW key whose hash is already known (computed in C for a whole chunk)."""
+        self.values[key] = value
+        self._place(h, key)
+        self.used += 1
+        if self.used * 3 >= (self.mask + 1) * 2:
+            self._resize((2 if self.used > 50000 else 4) * self.used)
+
     def _place(self, h, key):
         mask, slots = self.mask, self.slots
         i = h & mask

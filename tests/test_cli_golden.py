@@ -42,6 +42,12 @@ def oracle_backend(oracle):
         lens = np.array([len(s) for s in seqs], np.int32)
         ee, _, _, _ = oracle.filter_batch(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, threads=4)
         return ee
+
+    def matrix(q, lens, alpha, ambigs, round_, method="poisson_binomial", fast_discard=None):
+        # packed reads (the byte-level FASTQ path, moira_amd/fastio.py)
+        return oracle.filter_batch(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, threads=4)[0]
+    backend.matrix = matrix
+    backend.methods = ("poisson_binomial",)
     return backend
 
 
@@ -76,6 +82,11 @@ def run_paired(tmp_path, backend, compression="none"):
 
 
 def test_forward_dataset_host_logic(tmp_path, oracle):
+    run_forward(tmp_path, oracle_backend(oracle))
+
+
+def test_forward_dataset_host_logic_line_parser(tmp_path, oracle, monkeypatch):
+    monkeypatch.setenv("MOIRA_NO_FASTIO", "1")          # the per-line Python path, kept as the fallback
     run_forward(tmp_path, oracle_backend(oracle))
 
 

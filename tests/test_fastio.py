@@ -1,0 +1,258 @@
+"""libmoira_io.so (include/moira_io.h): the CLI's byte-level FASTQ path must be indistinguishable from
+the line-by-line path that restates the reference (moira/moira.py:1152-1204 parse_fastq,
+:842-970 write_results).  CPU only: the filter itself is injected (oracle)."""
+import gzip
+import io
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+
+from moira_amd import cli, fastio as F
+from moira_amd.py2dict import py2_str_hash
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+ROOT = os.path.dirname(HERE)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "moira_io.h")).read()
+    names = set(re.findall(r"\b(mio_[a-z0-9_]+)\s*\(", hdr))
+    assert names >= {"mio_fastq_index", "mio_pack", "mio_format", "mio_py2_hash", "mio_last_error", "mio_version"}
+    lib = F.load()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(F.PROTOTYPES) == names
+
+
+def make_fastq(rng, n, quirks=True, lo=20, hi=120):
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        seq = "".join(rng.choice(list("ACGTNn"), L, p=[.24, .24, .24, .24, .03, .01]))
+        qual = "".join(chr(33 + int(x)) for x in rng.integers(0, 42, L))
+        hdr = "@M0:%d:x%d" % (i % 7, i)
+        if quirks:
+            k = i % 6
+            if k == 1:
+                hdr = "@@" + hdr[1:] + " extra words"
+            elif k == 2:
+                hdr = hdr + "\tTAB field"
+            elif k == 3:
+                hdr = "  " + hdr + "  "
+        eol = "\r\n" if (quirks and i % 5 == 0) else "\n"
+        pad = " \t" if (quirks and i % 4 == 0) else ""
+        recs.append(hdr + eol + seq + pad + eol + "+" + eol + qual + pad + eol)
+    return "".join(recs)
+
+
+def slow_records(text, offset=33):
+    fh = io.StringIO(text, newline=None)
+    fh.moira_name = "x"
+    return list(cli.parse_fastq(fh, None, offset, raw=True))
+
+
+@pytest.mark.parametrize("final_newline", [True, False])
+def test_index_matches_line_parser(final_newline):
+    rng = np.random.default_rng(3)
+    text = make_fastq(rng, 500)
+    if not final_newline:
+        text = text.rstrip("\r\n ")
+    text_extra = text + ("\n@dangling\nACGT\n" if final_newline else "")   # lines that do not make a record
+    want = slow_records(text_extra)
+    buf = text_extra.encode()
+    idx, consumed, err = F.index(buf, True, 10 ** 6)
+    assert err is None and len(idx) == len(want) == 500
+    for row, (h, s, q, _, _) in zip(idx, want):
+        assert F.header_of(buf, row) == h
+        assert buf[row[F.SEQ_OFF]:row[F.SEQ_OFF] + row[F.SEQ_LEN]].decode() == s
+        assert buf[row[F.QUAL_OFF]:row[F.QUAL_OFF] + row[F.QUAL_LEN]].decode() == q.s
+    # streamed in small blocks: same records, whatever the block boundaries cut through
+    got = []
+    for b, ix in F.FastqChunks(io.BytesIO(buf), max_records=37, block_bytes=1000):
+        got += [(F.header_of(b, r), bytes(b[r[F.SEQ_OFF]:r[F.SEQ_OFF] + r[F.SEQ_LEN]]).decode()) for r in ix]
+    assert got == [(h, s) for h, s, _, _, _ in want]
+
+
+def test_index_reports_the_reference_errors_and_unsupported_content():
+    ok = "@a\nACGT\n+\nIIII\n"
+    for bad, kind in (("@b\n\n+\nIIII\n", F.REC_EMPTY_SEQ), ("@b\nACGT\n+\n\n", F.REC_EMPTY_QUAL),
+                      ("@b\nACGT\n+\nIII\n", F.REC_LENGTH_MISMATCH)):
+        idx, consumed, err = F.index((ok + bad + ok).encode(), True, 100)
+        assert len(idx) == 1 and consumed == len(ok) and err.kind == kind and err.header == "b"
+    with pytest.raises(F.Unsupported):
+        F.index(b"@a\nAC\rGT\n+\nIIII\n", True, 10)              # lone CR: a line break for the text parser
+    with pytest.raises(F.Unsupported):
+        F.index("@a\u00a0\nACGT\n+\nIIII\n".encode(), True, 10)   # non-ASCII: Unicode strip rules
+
+
+def test_pack_follows_the_packing_rules():
+    rng = np.random.default_rng(5)
+    text = make_fastq(rng, 300, quirks=False)
+    recs = slow_records(text)
+    buf = text.encode()
+    idx, _, _ = F.index(buf, True, 1000)
+    for T, lower in ((0, False), (50, False), (0, True)):
+        sel = np.arange(len(idx))[::2]
+        q, lens, has_n = F.pack(buf, idx, sel, 33, T, lower_n_is_base=lower, stride=128)
+        for k, i in enumerate(sel):
+            _, s, ql, _, _ = recs[i]
+            s, qi = (s[:T], ql.ints()[:T]) if T else (s, ql.ints())          # ints(): ord - offset, Q0 -> 1
+            want = np.array([0 if c == "N" else (255 if (c == "n" and not lower) else v) for c, v in zip(s, qi)], np.uint8)
+            assert lens[k] == len(s) and np.array_equal(q[k, :len(s)], want) and not q[k, len(s):].any()
+            assert has_n[k] == ("N" in s)
+    with pytest.raises(ValueError, match="positive"):
+        b = b"@a\nACGT\n+\nII!I\n"
+        ix, _, _ = F.index(b, True, 10)
+        F.pack(b, ix, None, 64, 0, stride=16)                                # '!' - 64 < 0
+    with pytest.raises(ValueError, match="does not fit"):
+        F.pack(buf, idx, None, 33, 0, stride=16)
+
+
+def test_py2_hash_matches_the_python_restatement():
+    rng = np.random.default_rng(7)
+    text = make_fastq(rng, 200, quirks=False)
+    buf = text.encode()
+    idx, _, _ = F.index(buf, True, 1000)
+    for T in (0, 33):
+        hs = F.py2_hashes(buf, idx, T)
+        for h, (_, s, _, _, _) in zip(hs, slow_records(text)):
+            assert h == py2_str_hash((s[:T] if T else s).encode())
+
+
+def test_format_matches_the_python_writer():
+    rng = np.random.default_rng(9)
+    text = make_fastq(rng, 120)
+    buf = text.encode()
+    idx, _, _ = F.index(buf, True, 1000)
+    recs = slow_records(text)
+    sel = np.arange(len(idx))[1::3]
+    ee = rng.random(len(sel)) * 30
+    lab = (np.arange(len(sel)) % 3 - 1).astype(np.int32)
+    labels = ["uncert > 0.010", "contains ambiguities"]
+    for T in (0, 40):
+        for relabel in (None, "seq_"):
+            for use_ee in (False, True):
+                want = {F.FMT_FASTA: "", F.FMT_QUAL: "", F.FMT_FASTQ: ""}
+                for k, i in enumerate(sel):
+                    h, s, ql, _, _ = recs[i]
+                    if T:
+                        s, ql = s[:T], ql[:T]
+                    if relabel:
+                        h = "%s%d" % (relabel, 1000 + k)
+                    if use_ee:
+                        h += ";ee=%.2f;size=%d;" % (ee[k], 1)
+                    if lab[k] >= 0:
+                        h += "\t" + labels[lab[k]]
+                    want[F.FMT_FASTA] += ">%s\n%s\n" % (h, s)
+                    want[F.FMT_QUAL] += ">%s\n%s\n" % (h, " ".join(map(str, ql.ints())))
+                    want[F.FMT_FASTQ] += "@%s\n%s\n+\n%s\n" % (h, s, "".join(chr(v + 33) for v in ql.ints()))
+                for kind in want:
+                    got = F.format_records(buf, idx, sel, kind, 33, T, relabel=relabel,
+                                           relabel_index=1000 + np.arange(len(sel)), ee=ee if use_ee else None,
+                                           labels=labels, label_id=lab)
+                    assert bytes(got).decode() == want[kind]
+
+
+def matrix_backend(oracle):
+    """The injected filter for packed matrices (what make_gpu_backend().matrix is on a GPU box)."""
+    def backend(seqs, quals, alpha, ambigs, round_):
+        stride = 16 * ((max(len(s) for s in seqs) + 15) // 16)
+        quals = [ql.ints() if hasattr(ql, "ints") else ql for ql in quals]
+        q = np.stack([oracle.pack_read(s, ql, stride) for s, ql in zip(seqs, quals)])
+        lens = np.array([len(s) for s in seqs], np.int32)
+        return oracle.filter_batch(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, threads=4)[0]
+
+    def matrix(q, lens, alpha, ambigs, round_, method="poisson_binomial", fast_discard=None):
+        assert method == "poisson_binomial" and fast_discard is None
+        return oracle.filter_batch(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, threads=4)[0]
+    backend.matrix = matrix
+    backend.methods = ("poisson_binomial",)
+    return backend
+
+
+def args_for(path, out, **kw):
+    d = dict(alpha=0.005, match=1, gap=-2, mismatch=-1, insert=20, deltaq=6, consensus_qscore="best",
+             paired=False, truncate=None, only_contig=False, error_calc="poisson_binomial",
+             ambigs="treat_as_errors", round=False, silent=True, nowarnings=False, doc=False, uncert=0.01,
+             maxerrors=None, processors=2, forward_fasta=None, forward_qual=None, reverse_fasta=None,
+             reverse_qual=None, forward_fastq=path, reverse_fastq=None, output_format="fasta", collapse=False,
+             pipeline="mothur", fastq_offset=33, relabel=None, output_compression="none", qscore_cap=40,
+             min_overlap=None, trim_overlap=False, bootstrap=100, output_prefix=out, device=None,
+             fast_discard=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def outputs_of(prefix):
+    d = os.path.dirname(prefix)
+    res = {}
+    for f in sorted(os.listdir(d)):
+        if f.startswith(os.path.basename(prefix) + "."):
+            p = os.path.join(d, f)
+            res[f.split(".", 1)[1]] = (gzip.open(p).read() if f.endswith(".gz") else open(p, "rb").read())
+    return res
+
+
+CASES = [
+    dict(),
+    dict(collapse=True),
+    dict(collapse=True, pipeline="USEARCH"),
+    dict(output_format="fastq"),
+    dict(output_format="fastq", collapse=True, truncate=60),
+    dict(truncate=60, relabel="r"),
+    dict(pipeline="USEARCH", maxerrors=1.5),
+    dict(ambigs="disallow", round=True),
+    dict(ambigs="ignore", output_compression="gz", uncert=0.05),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_cli_byte_level_path_equals_line_path(tmp_path, oracle, monkeypatch, case):
+    rng = np.random.default_rng(100 + case)
+    # duplicates so that collapse has groups, a few Q0 bases, ragged lengths across two buckets
+    base = make_fastq(rng, 150, quirks=True, lo=30, hi=100)
+    text = base + make_fastq(np.random.default_rng(100 + case), 60, quirks=True, lo=30, hi=100)
+    src = tmp_path / "in.fastq"
+    src.write_bytes(text.encode())
+    kw = CASES[case]
+    backend = matrix_backend(oracle)
+    calls = []
+    real = cli._run_fast_fastq
+    monkeypatch.setattr(cli, "_run_fast_fastq", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    assert cli.main(args_for(str(src), str(tmp_path / "fast"), **kw), backend=backend, out=open(os.devnull, "w")) == 0
+    assert calls == [1]                                                  # the byte-level path really ran
+    monkeypatch.setenv("MOIRA_NO_FASTIO", "1")
+    assert cli.main(args_for(str(src), str(tmp_path / "slow"), **kw), backend=backend, out=open(os.devnull, "w")) == 0
+    assert calls == [1]
+    fast, slow = outputs_of(str(tmp_path / "fast")), outputs_of(str(tmp_path / "slow"))
+    assert fast.keys() == slow.keys() and len(fast) >= 2
+    for k in fast:
+        assert fast[k] == slow[k], k
+    assert sum(len(v) for v in fast.values()) > 1000
+
+
+def test_cli_falls_back_to_the_line_parser(tmp_path, oracle):
+    text = make_fastq(np.random.default_rng(1), 40, quirks=False).replace("\n", "\r")      # old-Mac line ends
+    src = tmp_path / "cr.fastq"
+    src.write_bytes(text.encode())
+    backend = matrix_backend(oracle)
+    assert cli.main(args_for(str(src), str(tmp_path / "a")), backend=backend, out=open(os.devnull, "w")) == 0
+    os.environ["MOIRA_NO_FASTIO"] = "1"
+    try:
+        assert cli.main(args_for(str(src), str(tmp_path / "b")), backend=backend, out=open(os.devnull, "w")) == 0
+    finally:
+        del os.environ["MOIRA_NO_FASTIO"]
+    a, b = outputs_of(str(tmp_path / "a")), outputs_of(str(tmp_path / "b"))
+    assert a == b and sum(len(v) for v in a.values()) > 100
+
+
+def test_cli_raises_the_reference_exceptions(tmp_path, oracle):
+    src = tmp_path / "bad.fastq"
+    src.write_bytes(b"@a\nACGT\n+\nIIII\n@b:1\nACGT\n+\nIII\n")
+    with pytest.raises(cli.LengthMismatchError) as e:
+        cli.main(args_for(str(src), str(tmp_path / "o")), backend=matrix_backend(oracle), out=open(os.devnull, "w"))
+    assert "b_1" in str(e.value)

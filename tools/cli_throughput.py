@@ -25,10 +25,28 @@ path = os.path.join(tmp, "synth.fastq")
 with open(path, "w") as f:
     for i in range(n):
         f.write("@r%d\n%s\n+\n%s\n" % (i, bases[i].tobytes().decode(), qa[i].tobytes().decode()))
-args = cli.parse_arguments(["-ffq", path, "-op", os.path.join(tmp, "out"), "--silent", "-c", "false"])
-t = time.perf_counter()
-rc = cli.main(args, out=open(os.devnull, "w"))
-dt = time.perf_counter() - t
-good = sum(1 for l in open(os.path.join(tmp, "out.qc.good.fasta")) if l.startswith(">"))
-print("CLI end to end: %d reads (250 bp, fastq in, fasta+qual out, no collapse) in %.2f s = %.0f reads/s; kept %d; rc=%d"
-      % (n, dt, n / dt, good, rc))
+
+
+def run(label, extra, env=None):
+    old = os.environ.pop("MOIRA_NO_FASTIO", None)
+    if env:
+        os.environ.update(env)
+    try:
+        out = os.path.join(tmp, "out_" + label.replace(" ", "_"))
+        args = cli.parse_arguments(["-ffq", path, "-op", out, "--silent"] + extra)
+        t = time.perf_counter()
+        rc = cli.main(args, out=open(os.devnull, "w"))
+        dt = time.perf_counter() - t
+        print("CLI end to end [%s]: %d reads (250 bp) in %.2f s = %.0f reads/s; rc=%d" % (label, n, dt, n / dt, rc), flush=True)
+    finally:
+        os.environ.pop("MOIRA_NO_FASTIO", None)
+        if old is not None:
+            os.environ["MOIRA_NO_FASTIO"] = old
+
+
+run("warm-up", ["-c", "false"])
+run("fastq in, fasta+qual out, no collapse", ["-c", "false"])
+run("fastq in, fastq out, no collapse", ["-c", "false", "-o", "fastq"])
+run("fastq in, fasta+qual out, collapse", ["-c", "true"])
+run("line parser: fasta+qual out, no collapse", ["-c", "false"], {"MOIRA_NO_FASTIO": "1"})
+run("line parser: fasta+qual out, collapse", ["-c", "true"], {"MOIRA_NO_FASTIO": "1"})
