@@ -43,6 +43,14 @@ int mct_nw_align(const char *seq1, int32_t len1, const char *seq2, int32_t len2,
                  int32_t match, int32_t mismatch, int32_t gap,
                  char *aln1, char *aln2, int32_t *aln_len, int32_t *score);
 
+/* The same alignment by the plain row-by-row loop with 32-bit scores.  mct_nw_align walks the matrix
+ * by anti-diagonals with 16-bit scores (SIMD) and switches to this form by itself when
+ * (len1 + len2) x the largest |parameter| could leave 16 bits; exported so that the two can be
+ * compared. */
+int mct_nw_align_scalar(const char *seq1, int32_t len1, const char *seq2, int32_t len2,
+                        int32_t match, int32_t mismatch, int32_t gap,
+                        char *aln1, char *aln2, int32_t *aln_len, int32_t *score);
+
 /* Consensus of two aligned reads.  contig/contig_quals must hold aln_len entries. */
 int mct_make_contig(const char *fwd_aln, const int32_t *fwd_quals, const char *rev_aln,
                     const int32_t *rev_quals, int32_t aln_len, int32_t insert, int32_t deltaq,

@@ -74,7 +74,7 @@ def _locked_build(lib, deps, flags, cmd, force, verbose):
     return lib
 
 
-CONTIG_FLAGS = ["-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-pthread", "-Wall"]
+CONTIG_FLAGS = ["-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-pthread", "-Wall"]
 
 
 def contig_stale():

@@ -34,6 +34,7 @@ def load():
         L.mct_last_error.restype = C.c_char_p
         L.mct_reverse_complement.argtypes = [C.c_char_p, vp, i32, vp, vp]
         L.mct_nw_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.mct_nw_align_scalar.argtypes = L.mct_nw_align.argtypes
         L.mct_make_contig.argtypes = [C.c_char_p, vp, C.c_char_p, vp, i32, i32, i32, i32, i32, i32,
                                       vp, vp, vp, vp, vp, vp]
         L.mct_contigs_batch.argtypes = [C.c_int64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
@@ -62,14 +63,16 @@ def reverse_complement(sequence, quals=None):
     return out.value.decode()
 
 
-def nw_align(seq_1, seq_2, match, mismatch, gap):
+def nw_align(seq_1, seq_2, match, mismatch, gap, scalar=False):
+    """scalar=True: the row-by-row 32-bit loop instead of the anti-diagonal SIMD walk (same result)."""
     L = load()
     a, b = str(seq_1).encode(), str(seq_2).encode()
     n = len(a) + len(b) + 1
     o1, o2 = C.create_string_buffer(n), C.create_string_buffer(n)
     alen, score = C.c_int32(), C.c_int32()
-    _check(L.mct_nw_align(a, len(a), b, len(b), int(match), int(mismatch), int(gap),
-                          C.addressof(o1), C.addressof(o2), C.addressof(alen), C.addressof(score)))
+    fn = L.mct_nw_align_scalar if scalar else L.mct_nw_align
+    _check(fn(a, len(a), b, len(b), int(match), int(mismatch), int(gap),
+              C.addressof(o1), C.addressof(o2), C.addressof(alen), C.addressof(score)))
     return o1.value.decode(), o2.value.decode(), score.value
 
 

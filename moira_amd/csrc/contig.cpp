@@ -8,6 +8,7 @@
 
 #include "../../include/moira_contig.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -62,8 +63,10 @@ struct NwScratch {
 };
 
 // ref: moira/nw_align.pyx:49-201.  Row index i walks seq1 (with the leading pad), column j seq2.
-int nw_align_impl(const char *s1, int n1, const char *s2, int n2, int match, int mismatch, int gap,
-                  char *aln1, char *aln2, int32_t *aln_len, int32_t *score_out, NwScratch &sc)
+// Scalar, row-major, 32-bit form: the plain restatement, kept for validation and for parameters whose
+// scores could leave 16 bits.
+int nw_align_scalar(const char *s1, int n1, const char *s2, int n2, int match, int mismatch, int gap,
+                    char *aln1, char *aln2, int32_t *aln_len, int32_t *score_out, NwScratch &sc)
 {
     const int L1 = n1 + 1, L2 = n2 + 1;
     sc.score.assign((size_t)L1 * L2, 0);
@@ -130,6 +133,115 @@ int nw_align_impl(const char *s1, int n1, const char *s2, int n2, int match, int
     *aln_len = k;
     *score_out = score;
     return MCT_OK;
+}
+
+// One anti-diagonal d = i + j of the matrix: its cells depend only on diagonals d-1 and d-2, so the
+// loop below has no carried dependence and compiles to 16-lane integer SIMD where the CPU has AVX2
+// (the clone is picked at load time).  All arrays are indexed by the row i of the cell.
+__attribute__((target_clones("avx2", "default")))
+void nw_diagonal(const int16_t *__restrict d2, const int16_t *__restrict d1, int16_t *__restrict cur,
+                 uint8_t *__restrict ptr, const char *__restrict a, const char *__restrict b,
+                 int ilo, int ihi, int16_t match, int16_t mismatch, int16_t gap)
+{
+    for (int i = ilo; i <= ihi; i++) {
+        const int16_t dg = (int16_t)(d2[i - 1] + (a[i] == b[i] ? match : mismatch));
+        const int16_t up = (int16_t)(d1[i - 1] + gap);
+        const int16_t lf = (int16_t)(d1[i] + gap);
+        const int16_t mx = dg >= up ? dg : up;
+        cur[i] = lf > mx ? lf : mx;
+        // tie-break order of nw_align.pyx:96-113 (diag >= up, diag >= left, up >= left), branch-free:
+        // left only when it beats both, else diag when diag >= up, else up
+        ptr[i] = lf > mx ? (uint8_t)PTR_LEFT : (dg >= up ? (uint8_t)PTR_DIAG : (uint8_t)PTR_UP);
+    }
+}
+
+struct DiagScratch {
+    std::vector<int16_t> score;
+    std::vector<uint8_t> ptr;
+    std::vector<int64_t> base;      // base[d]: index of cell (i, d - i) is base[d] + i
+    std::vector<char> s2r;
+};
+
+// Same algorithm on anti-diagonal storage with 16-bit scores.
+int nw_align_diag(const char *s1, int n1, const char *s2, int n2, int match, int mismatch, int gap,
+                  char *aln1, char *aln2, int32_t *aln_len, int32_t *score_out, DiagScratch &sc)
+{
+    const int D = n1 + n2;
+    sc.base.resize((size_t)D + 1);
+    int64_t total = 8;                                   // slack so that base[d] + i - 1 never underflows
+    for (int d = 0; d <= D; d++) {
+        const int lo = d > n2 ? d - n2 : 0, hi = d < n1 ? d : n1;
+        sc.base[d] = total - lo;
+        total += hi - lo + 1;
+    }
+    sc.score.assign((size_t)total + 8, 0);
+    sc.ptr.assign((size_t)total + 8, PTR_UP);            // first column points up (:64-76) ...
+    int16_t *S = sc.score.data();
+    uint8_t *P = sc.ptr.data();
+    for (int j = 1; j <= n2; j++) P[sc.base[j] + 0] = PTR_LEFT;      // ... first row points left
+    sc.s2r.resize((size_t)n2 + 1);
+    for (int t = 0; t < n2; t++) sc.s2r[t] = s2[n2 - 1 - t];
+    const char *A = s1 - 1;                              // A[i] = s1[i - 1]
+    for (int d = 2; d <= D; d++) {
+        const int ilo = d - n2 > 1 ? d - n2 : 1, ihi = d - 1 < n1 ? d - 1 : n1;
+        if (ilo > ihi) continue;
+        // b[i] = s2[(d - i) - 1] = s2r[n2 - d + i]
+        nw_diagonal(S + sc.base[d - 2], S + sc.base[d - 1], S + sc.base[d], P + sc.base[d], A,
+                    sc.s2r.data() + (n2 - d), ilo, ihi, (int16_t)match, (int16_t)mismatch, (int16_t)gap);
+    }
+    auto at = [&](int i, int j) { return sc.base[i + j] + i; };
+    // 3' overlap fix-up (:155-201): last maximum (>=) of the last column and of the last row
+    int best_col_score = -10000, best_col_idx = 0;
+    for (int i = 0; i <= n1; i++) {
+        const int c = S[at(i, n2)];
+        if (c >= best_col_score) { best_col_score = c; best_col_idx = i; }
+    }
+    int best_row_score = -10000, best_row_idx = 0;
+    for (int j = 0; j <= n2; j++) {
+        const int c = S[at(n1, j)];
+        if (c >= best_row_score) { best_row_score = c; best_row_idx = j; }
+    }
+    if (best_col_idx == n1 && best_row_idx == n2) {
+        // nothing to do
+    } else if (best_col_score > best_row_score) {
+        for (int i = n1; i > best_col_idx; i--) P[at(i, n2)] = PTR_UP;
+    } else {
+        for (int j = n2; j > best_row_idx; j--) P[at(n1, j)] = PTR_LEFT;
+    }
+    // traceback (:129-150), filled backwards then reversed
+    int i = n1, j = n2, k = 0;
+    int32_t score = 0;
+    while (i > 0 || j > 0) {
+        const int64_t c = at(i, j);
+        const uint8_t p = P[c];
+        score += S[c];
+        const bool mv_i = (p == PTR_DIAG || p == PTR_UP), mv_j = (p == PTR_DIAG || p == PTR_LEFT);
+        aln1[k] = mv_i ? s1[i - 1] : '-';
+        aln2[k] = mv_j ? s2[j - 1] : '-';
+        k++;
+        if (mv_i) i--;
+        if (mv_j) j--;
+    }
+    for (int a = 0, b = k - 1; a < b; a++, b--) {
+        char t = aln1[a]; aln1[a] = aln1[b]; aln1[b] = t;
+        t = aln2[a]; aln2[a] = aln2[b]; aln2[b] = t;
+    }
+    aln1[k] = 0; aln2[k] = 0;
+    *aln_len = k;
+    *score_out = score;
+    return MCT_OK;
+}
+
+struct NwWork { NwScratch scalar; DiagScratch diag; };
+
+int nw_align_impl(const char *s1, int n1, const char *s2, int n2, int match, int mismatch, int gap,
+                  char *aln1, char *aln2, int32_t *aln_len, int32_t *score_out, NwWork &w)
+{
+    auto mag = [](int v) { return (int64_t)(v < 0 ? -(int64_t)v : v); };
+    const int64_t worst = ((int64_t)n1 + n2 + 2) * std::max(mag(match), std::max(mag(mismatch), mag(gap)));
+    if (worst < 30000)        // every score, and the -10000 sentinel of the fix-up scan, fits 16 bits
+        return nw_align_diag(s1, n1, s2, n2, match, mismatch, gap, aln1, aln2, aln_len, score_out, w.diag);
+    return nw_align_scalar(s1, n1, s2, n2, match, mismatch, gap, aln1, aln2, aln_len, score_out, w.scalar);
 }
 
 inline double qual2prob(int q) { return pow(10, q / (-10.0)); }                       // moira.py:1392-1393
@@ -210,8 +322,17 @@ extern "C" int mct_nw_align(const char *seq1, int32_t len1, const char *seq2, in
                             int32_t *aln_len, int32_t *score)
 {
     if (len1 < 0 || len2 < 0 || !aln1 || !aln2 || !aln_len || !score) return fail(MCT_E_INVALID, "bad arguments");
+    NwWork w;
+    return nw_align_impl(seq1, len1, seq2, len2, match, mismatch, gap, aln1, aln2, aln_len, score, w);
+}
+
+extern "C" int mct_nw_align_scalar(const char *seq1, int32_t len1, const char *seq2, int32_t len2,
+                                   int32_t match, int32_t mismatch, int32_t gap, char *aln1, char *aln2,
+                                   int32_t *aln_len, int32_t *score)
+{
+    if (len1 < 0 || len2 < 0 || !aln1 || !aln2 || !aln_len || !score) return fail(MCT_E_INVALID, "bad arguments");
     NwScratch sc;
-    return nw_align_impl(seq1, len1, seq2, len2, match, mismatch, gap, aln1, aln2, aln_len, score, sc);
+    return nw_align_scalar(seq1, len1, seq2, len2, match, mismatch, gap, aln1, aln2, aln_len, score, sc);
 }
 
 extern "C" int mct_make_contig(const char *fa, const int32_t *fq, const char *ra, const int32_t *rq,
@@ -239,7 +360,7 @@ extern "C" int mct_contigs_batch(int64_t n, const char *fwd_seq, const int32_t *
     std::vector<int> rc(threads, MCT_OK);
     std::vector<std::string> msgs(threads);
     auto work = [&](int t) {
-        NwScratch sc;
+        NwWork sc;
         std::vector<char> rseq, a1, a2;
         std::vector<int32_t> rq, qa, qb;
         for (int64_t i = t; i < n; i += threads) {

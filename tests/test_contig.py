@@ -101,3 +101,29 @@ def test_against_python_reference_when_available(tmp_path):
             want = M.make_contig(a1, list(fq), a2, list(rrq), 20, 6, mode, cap, trim)
             got = CT.make_contig(a1, fq, a2, rrq, 20, 6, mode, cap, trim)
             assert got == tuple(want), (it, mode)
+
+
+def test_simd_walk_equals_scalar_loop():
+    """mct_nw_align (anti-diagonals, 16-bit, SIMD) against mct_nw_align_scalar (the plain restatement of
+    moira/nw_align.pyx:49-201): alignment strings and score, incl. empty/1-base reads, unequal lengths,
+    tie-heavy low-complexity reads, other parameters, and the automatic switch for large parameters."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    cases = [("", ""), ("A", ""), ("", "C"), ("A", "A"), ("A", "C"), ("ACGT", "ACGT"), ("AAAAAAAA", "AAAA"),
+             ("ACGTACGTAC", "TTTT")]
+    for _ in range(300):
+        n1, n2 = int(rng.integers(1, 330)), int(rng.integers(1, 330))
+        alphabet = "ACGT" if rng.random() < 0.7 else "AC"
+        a = "".join(rng.choice(list(alphabet), n1))
+        if rng.random() < 0.6:          # an overlapping pair, as real paired reads are
+            k = int(rng.integers(1, min(n1, n2) + 1))
+            b = a[n1 - k:] + "".join(rng.choice(list(alphabet), n2 - k))
+            b = "".join(c if rng.random() > 0.03 else "T" for c in b)
+        else:
+            b = "".join(rng.choice(list(alphabet), n2))
+        cases.append((a, b))
+    for a, b in cases:
+        for m, mm, g in ((1, -1, -2), (2, -3, -1), (1, 0, 0)):
+            assert CT.nw_align(a, b, m, mm, g) == CT.nw_align(a, b, m, mm, g, scalar=True), (a, b, m, mm, g)
+    a, b = cases[20]
+    assert CT.nw_align(a, b, 500, -700, -900) == CT.nw_align(a, b, 500, -700, -900, scalar=True)   # 32-bit path
