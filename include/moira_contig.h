@@ -25,6 +25,7 @@ extern "C" {
 #define MCT_E_BASE     -2   /* not an IUPAC base (ValueError in the reference, moira.py:1229-1230) */
 #define MCT_E_NOMEM    -4
 #define MCT_E_BUFFER   -6   /* output buffer too small */
+#define MCT_E_RANGE    -7   /* a quality that does not fit one byte at the given FASTQ offset */
 
 #define MCT_CONSENSUS_BEST      0
 #define MCT_CONSENSUS_SUM       1
@@ -68,6 +69,20 @@ int mct_contigs_batch(int64_t n, const char *fwd_seq, const int32_t *fwd_qual, c
                       int32_t consensus, int32_t qscore_cap, int32_t trim_overlap, int32_t threads,
                       int32_t cap_per_contig, char *contigs, int32_t *contig_quals,
                       int32_t *contig_len, int32_t *overlap_length, int32_t *gaps, int32_t *mismatches);
+
+/* The same for a chunk of paired FASTQ records that are still text: fbuf/fidx and rbuf/ridx are a file
+ * buffer and its record index as mio_fastq_index (include/moira_io.h) produces them.  Qualities are
+ * byte - fastq_offset (ref: moira/moira.py:1177,1189), unclamped, as process_data hands them to
+ * make_contig.  Output is again a buffer + record index, so that every mio_* function treats a contig
+ * like a read: slot i of out_buf (rec_cap bytes) holds the forward header token, the contig and its
+ * qualities as bytes (q + fastq_offset); out_idx[i] = the MIO_* columns into out_buf.
+ * Returns MCT_E_RANGE when a quality is negative or q + fastq_offset > 255, MCT_E_BUFFER when a
+ * record does not fit rec_cap. */
+int mct_contigs_from_fastq(int64_t n, const char *fbuf, const int64_t *fidx, const char *rbuf, const int64_t *ridx,
+                           int32_t fastq_offset, int32_t match, int32_t mismatch, int32_t gap, int32_t insert,
+                           int32_t deltaq, int32_t consensus, int32_t qscore_cap, int32_t trim_overlap,
+                           int32_t threads, int64_t rec_cap, char *out_buf, int64_t *out_idx,
+                           int32_t *overlap_length, int32_t *gaps, int32_t *mismatches);
 
 #ifdef __cplusplus
 }

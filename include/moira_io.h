@@ -77,6 +77,10 @@ int32_t mio_pack(const char *buf, const int64_t *idx, const int64_t *sel, int64_
                  int32_t fastq_offset, int32_t max_len, int32_t lower_n_is_base, int64_t row_stride,
                  uint8_t *out, int32_t *lens_out, uint8_t *flags_out, int64_t *bad_record);
 
+/* Paired input: position of the first pair whose header tokens differ (the reference's
+ * forward_header != reverse_header, ref: moira/moira.py:1197-1198), or -1. */
+int64_t mio_first_header_mismatch(const char *fbuf, const int64_t *fidx, const char *rbuf, const int64_t *ridx, int64_t n);
+
 /*
  * hash(str) of 64-bit CPython 2.7 for the (truncated) sequence of records 0..n-1.  The collapse step
  * keeps the reference's output order, which for groups of equal abundance is the slot order of a
@@ -107,6 +111,13 @@ int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int6
                    const double *ee, const char *const *labels, const int32_t *label_id,
                    char *out, int64_t cap, int64_t *needed);
 
+/* contigs.report lines of records sel[0..nsel) that are written one by one (no collapse, n_seqs = 1):
+ * header as in mio_format, aux int32[.][3] indexed by RECORD (not by position in sel)
+ * (ref: moira/moira.py:868). */
+int64_t mio_format_report(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel,
+                          const char *relabel, const int64_t *relabel_index, const double *ee,
+                          const int32_t *aux, char *out, int64_t cap, int64_t *needed);
+
 /* ---- collapse of identical sequences (ref: moira/moira.py:459-475, :490-493) -----------------
  * The reference keeps one dict entry per distinct (truncated) sequence: the representative is the
  * member with the strictly smallest expected errors (first seen wins ties), names_info lists the
@@ -120,14 +131,17 @@ void mio_collapse_destroy(mio_collapse *c);
 int64_t mio_collapse_count(const mio_collapse *c);          /* distinct sequences so far */
 
 /* Add records 0..n-1 of a chunk in file order.  ee double[n] (after +Ns / floor), flags uint8[n] from
- * mio_pack (may be NULL), max_len as in mio_pack. */
+ * mio_pack (may be NULL), max_len as in mio_pack, aux int32[n][3] = overlap length, gaps, mismatches of
+ * each contig (NULL for single reads: zeros); a group carries its representative's. */
 int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, int64_t n, int32_t max_len,
-                         const double *ee, const uint8_t *flags);
+                         const double *ee, const uint8_t *flags, const int32_t *aux);
 
 /* Fix the output order (moira/moira.py:492) and copy out, in that order, per group: the
- * representative's ee, the sequence length, the abundance and the flags (any pointer may be NULL). */
-int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *size, uint8_t *flags);
+ * representative's ee, the sequence length, the abundance, the flags and aux[.][3] (any pointer may be
+ * NULL). */
+int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *size, uint8_t *flags, int32_t *aux);
 
+#define MIO_FMT_REPORT 4  /* "hdr\tn_seqs\toverlap\tgaps\tmismatches\n"   ref: moira/moira.py:866,868 */
 #define MIO_FMT_NAMES 3   /* "hdr\tname,name,...\n"   ref: moira/moira.py:880,919,933,943,957,967 */
 
 /* mio_format for groups sel[0..nsel) (positions in the exported order).  Header = the

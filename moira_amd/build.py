@@ -33,7 +33,8 @@ CONTIG_SRC = os.path.join(CSRC, "contig.cpp")
 CXX = os.environ.get("CXX", "g++")
 
 
-CONTIG_DEPS = [CONTIG_SRC, os.path.join(ROOT, "include", "moira_contig.h")]
+CONTIG_DEPS = [CONTIG_SRC, os.path.join(ROOT, "include", "moira_contig.h"),
+               os.path.join(ROOT, "include", "moira_io.h")]
 
 
 def _digest(paths, flags):

@@ -602,7 +602,8 @@ def _open_outputs(args, output_name, binary=False):
             o.names, o.bad_names = mk("qc.good.names"), mk("qc.bad.names")
     if args.paired:
         o.report = mk("contigs.report")
-        o.report.write("header\tn_seqs\toverlap_length\tgaps\tmismatches\n")
+        head = "header\tn_seqs\toverlap_length\tgaps\tmismatches\n"
+        o.report.write(head.encode() if binary else head)
     return o
 
 
@@ -616,20 +617,81 @@ def _close(o):
 
 
 # ---------------------------------------------------------------------------------------------
-# byte-level path for single-end FASTQ (include/moira_io.h): same results, no per-read Python text work
+# byte-level path for FASTQ input (include/moira_io.h): same results, no per-read Python text work
 # ---------------------------------------------------------------------------------------------
+PAIR_CHUNK_READS = 65536      # a contig slot is header + 2 x (l1 + l2) bytes
+
+
 def _fast_eligible(args, backend):
-    return bool(args.forward_fastq and not args.paired and not args.only_contig and not args.min_overlap
+    return bool(args.forward_fastq and not args.only_contig
+                and (args.paired or not args.min_overlap)
                 and args.error_calc in ("poisson_binomial", "poisson_binomial_py", "poisson")
                 and getattr(backend, "matrix", None) is not None
                 and (args.error_calc != "poisson" or "poisson" in getattr(backend, "methods", ()))
                 and not os.environ.get("MOIRA_NO_FASTIO"))
 
 
+def _record_error(which, e, args):
+    """The exception the line parser raises for a record that fails its checks (moira.py:1178-1195;
+    the reverse file's empty-line errors name the forward header and file, as there)."""
+    from . import fastio as F
+    if which == 0:
+        name = args.forward_fastq
+        if e.kind == F.REC_EMPTY_SEQ:
+            return EmptySeqError(e.header, name)
+        if e.kind == F.REC_EMPTY_QUAL:
+            return EmptyQualError(e.header, name)
+        return LengthMismatchError(e.header, name)
+    if e.kind == F.REC_EMPTY_SEQ:
+        return EmptySeqError(e.forward_header, args.forward_fastq)
+    if e.kind == F.REC_EMPTY_QUAL:
+        return EmptyQualError(e.forward_header, args.forward_fastq)
+    return LengthMismatchError(e.header, args.reverse_fastq)
+
+
+def _fast_chunks(args):
+    """(buf, idx, aux) per chunk: reads as they are in the file, or contigs built from the two files."""
+    from . import fastio as F
+    if not args.paired:
+        fh = open_input_binary(args.forward_fastq)
+        try:
+            for buf, idx in F.FastqChunks(fh, CHUNK_READS):
+                yield buf, idx, None
+        except F.RecordError as e:
+            raise _record_error(0, e, args)
+        finally:
+            fh.close()
+        return
+    from . import contig as CT
+    ffh, rfh = open_input_binary(args.forward_fastq), open_input_binary(args.reverse_fastq)
+    try:
+        for fbuf, fidx, rbuf, ridx in F.PairedFastqChunks(ffh, rfh, PAIR_CHUNK_READS):
+            # forward_header != reverse_header (moira.py:1197-1198); ':' -> '_' on both sides cannot change equality
+            bad = F.first_header_mismatch(fbuf, fidx, rbuf, ridx)
+            n = len(fidx) if bad < 0 else bad
+            if n:
+                try:
+                    cbuf, cidx, aux = CT.contigs_from_fastq(
+                        fbuf, fidx[:n], rbuf, ridx[:n], args.fastq_offset, args.match, args.mismatch, args.gap,
+                        args.insert, args.deltaq, args.consensus_qscore, args.qscore_cap, args.trim_overlap,
+                        threads=args.processors)
+                except CT.QualityRange as e:
+                    raise F.Unsupported(str(e))
+                yield cbuf, cidx, aux
+            if bad >= 0:
+                raise NameMismatchError(F.header_of(fbuf, fidx[bad]), None, F.header_of(rbuf, ridx[bad]), None)
+    except F.PairedRecordError as e:
+        raise _record_error(e.which, e.err, args)
+    finally:
+        ffh.close()
+        rfh.close()
+
+
 def _run_fast_fastq(args, backend, o, say, t0):
-    """Chunks of the input as (bytes, record index); packing and record formatting in C
-    (moira_amd/fastio.py).  Decisions are write_results' (ref: moira/moira.py:842-970), vectorised.
-    Returns (processed, discarded_errors, discarded_minlength)."""
+    """Chunks of the input as (buffer, record index); contig construction, packing, collapse and record
+    formatting in C (moira_amd/fastio.py, moira_amd/contig.py).  Decisions are write_results'
+    (ref: moira/moira.py:842-970), vectorised.
+    Returns (processed, discarded_errors, discarded_minlength, discarded_minoverlap)."""
     from . import fastio as F
     from .buckets import bucket_of
     T = args.truncate or 0
@@ -640,17 +702,30 @@ def _run_fast_fastq(args, backend, o, say, t0):
         fd = (args.uncert, args.maxerrors)
     fq = args.output_format == "fastq"
     usearch = args.pipeline == "USEARCH"
-    if args.maxerrors:
-        thr_label = "errors > %.2f" % args.maxerrors
-    else:
-        thr_label = "uncert > %.3f" % args.uncert
-    labels = ["length below %s" % args.truncate, "contains ambiguities", thr_label]
+    thr_label = ("errors > %.2f" % args.maxerrors) if args.maxerrors else ("uncert > %.3f" % args.uncert)
+    # the fastq branch of the reference prints args.truncate in the overlap label (moira.py:888); kept
+    labels = ["length below %s" % args.truncate, "contains ambiguities", thr_label,
+              "overlap length below %s" % (args.truncate if fq else args.min_overlap)]
+    min_ov = args.min_overlap if args.paired and args.min_overlap else 0
+
+    def decide(ee, length, has_n, ov):
+        """write_results' branch per record or group: -1 good, else the index of its label."""
+        label = np.full(len(ee), -1, np.int32)
+        keep = (ee <= args.maxerrors) if args.maxerrors else (ee <= length * args.uncert)   # len(sequence) * uncert
+        label[~keep] = 2
+        if args.ambigs == "disallow":
+            label[has_n] = 1
+        if min_ov:
+            label[ov < min_ov] = 3
+        if T:
+            label[length < T] = 0
+        return label
+
     processed = 0
-    disc_err = disc_len = 0.0
+    disc_err = disc_len = disc_ov = 0.0
     groups = F.Collapse() if args.collapse else None
-    fh = open_input_binary(args.forward_fastq)
     try:
-        for buf, idx in F.FastqChunks(fh, CHUNK_READS):
+        for buf, idx, aux in _fast_chunks(args):
             n = len(idx)
             lens = np.minimum(idx[:, F.SEQ_LEN], T) if T else idx[:, F.SEQ_LEN].copy()
             strides = bucket_of(lens, 64)
@@ -666,29 +741,24 @@ def _run_fast_fastq(args, backend, o, say, t0):
             if nan.any():
                 raise ReturnedNaNError(F.header_of(buf, idx[int(np.argmax(nan))]))
             if args.collapse:
-                groups.add(buf, idx, ee, has_n, T)
+                groups.add(buf, idx, ee, has_n, T, aux)
             else:
-                label = np.full(n, -1, np.int32)
-                if args.maxerrors:
-                    keep = ee <= args.maxerrors
-                else:
-                    keep = ee <= lens * args.uncert                              # len(sequence) * uncert, in double
-                label[~keep] = 2
-                if args.ambigs == "disallow":
-                    label[has_n] = 1
-                if T:
-                    label[idx[:, F.SEQ_LEN] < T] = 0
+                label = decide(ee, lens, has_n, aux[:, 0] if aux is not None else None)
                 disc_len += int((label == 0).sum())
-                disc_err += int((label > 0).sum())
+                disc_ov += int((label == 3).sum())
+                disc_err += int(((label == 1) | (label == 2)).sum())
+                hdr = dict(relabel=args.relabel or None)
+                if args.paired:
+                    everything = np.arange(n)
+                    o.report.write(F.format_report(buf, idx, everything, aux, relabel_index=processed + everything,
+                                                   ee=ee if usearch else None, **hdr))
                 good, bad = np.nonzero(label < 0)[0], np.nonzero(label >= 0)[0]
                 for sel, main_f, qual_f, lab in ((good, o.contig, o.qual, None), (bad, o.bad_contig, o.bad_qual, label)):
                     if not len(sel):
                         continue
-                    kw = dict(fastq_offset=args.fastq_offset, max_len=T,
-                              relabel=args.relabel or None, relabel_index=(processed + sel) if args.relabel else None,
-                              ee=ee[sel] if usearch else None,
-                              labels=labels if lab is not None else None,
-                              label_id=lab[sel] if lab is not None else None)
+                    kw = dict(fastq_offset=args.fastq_offset, max_len=T, relabel_index=processed + sel,
+                              ee=ee[sel] if usearch else None, labels=labels if lab is not None else None,
+                              label_id=lab[sel] if lab is not None else None, **hdr)
                     if fq:
                         main_f.write(F.format_records(buf, idx, sel, F.FMT_FASTQ, **kw))
                     else:
@@ -699,45 +769,33 @@ def _run_fast_fastq(args, backend, o, say, t0):
                 say("%d sequences processed in %.1f seconds." % (processed, time.time() - t0))
         if args.collapse:
             # the groups by decreasing abundance (moira.py:490-493), then write_results' decisions per group
-            gee, glen, gsize, g_n = groups.export()
-            label = np.full(len(gee), -1, np.int32)
-            keep = (gee <= args.maxerrors) if args.maxerrors else (gee <= glen * args.uncert)
-            label[~keep] = 2
-            if args.ambigs == "disallow":
-                label[g_n] = 1
-            if T:
-                label[glen < T] = 0
+            gee, glen, gsize, g_n, gaux = groups.export()
+            label = decide(gee, glen, g_n, gaux[:, 0])
             disc_len += int(gsize[label == 0].sum())
-            disc_err += int(gsize[label > 0].sum())
+            disc_ov += int(gsize[label == 3].sum())
+            disc_err += int(gsize[(label == 1) | (label == 2)].sum())
             names = args.pipeline == "mothur"
-            # header.lstrip('>') on the names line of "length below" and "errors >" groups (moira.py:880,943)
-            strip = (label == 0) | ((label == 2) & bool(args.maxerrors))
+            hdr = dict(fastq_offset=args.fastq_offset, relabel=args.relabel or None, usearch=usearch)
+            if args.paired:
+                o.report.write(groups.format(np.arange(len(gee)), F.FMT_REPORT, **hdr))
+            # header.lstrip('>') on the names line of three kinds of bad groups (moira.py:880,894,943)
+            strip = (label == 0) | (label == 3) | ((label == 2) & bool(args.maxerrors))
             for sel, main_f, qual_f, names_f, lab in ((np.nonzero(label < 0)[0], o.contig, o.qual, o.names, None),
                                                       (np.nonzero(label >= 0)[0], o.bad_contig, o.bad_qual, o.bad_names, label)):
                 if not len(sel):
                     continue
-                kw = dict(fastq_offset=args.fastq_offset, relabel=args.relabel or None, usearch=usearch,
-                          labels=labels if lab is not None else None, label_id=lab[sel] if lab is not None else None)
+                kw = dict(labels=labels if lab is not None else None, label_id=lab[sel] if lab is not None else None, **hdr)
                 if fq:
                     main_f.write(groups.format(sel, F.FMT_FASTQ, **kw))
                 else:
                     main_f.write(groups.format(sel, F.FMT_FASTA, **kw))
                     qual_f.write(groups.format(sel, F.FMT_QUAL, **kw))
                 if names:
-                    names_f.write(groups.format(sel, F.FMT_NAMES, fastq_offset=args.fastq_offset,
-                                                relabel=args.relabel or None, usearch=usearch, lstrip_gt=strip[sel]))
-    except F.RecordError as e:
-        name = args.forward_fastq
-        if e.kind == F.REC_EMPTY_SEQ:
-            raise EmptySeqError(e.header, name)
-        if e.kind == F.REC_EMPTY_QUAL:
-            raise EmptyQualError(e.header, name)
-        raise LengthMismatchError(e.header, name)
+                    names_f.write(groups.format(sel, F.FMT_NAMES, lstrip_gt=strip[sel], **hdr))
     finally:
-        fh.close()
         if groups is not None:
             groups.close()
-    return processed, disc_err, disc_len
+    return processed, disc_err, disc_len, disc_ov
 
 
 # ---------------------------------------------------------------------------------------------
@@ -825,7 +883,7 @@ def main(args, backend=None, out=None, _no_fastio=False):
         if fast:
             from . import fastio
             try:
-                processed, disc_err, disc_len = _run_fast_fastq(args, backend, o, say, t0)
+                processed, disc_err, disc_len, disc_ov = _run_fast_fastq(args, backend, o, say, t0)
             except fastio.Unsupported:
                 # content the byte-level parser does not reproduce: start over with the line parser
                 _close(o)

@@ -136,3 +136,37 @@ def contigs_batch(fwd_seqs, fwd_quals, rev_seqs, rev_quals, match=1, mismatch=-1
                                gaps.ctypes.data, mism.ctypes.data))
     seqs = [contigs[i, :clen[i]].tobytes().decode() for i in range(n)]
     return seqs, cq, clen, ov, gaps, mism
+
+
+class QualityRange(Exception):
+    """A quality that the byte-level contig path cannot carry (negative, or q + offset > 255)."""
+
+
+def contigs_from_fastq(fbuf, fidx, rbuf, ridx, fastq_offset=33, match=1, mismatch=-1, gap=-2, insert=20, deltaq=6,
+                       consensus_qscore="best", qscore_cap=40, trim_overlap=False, threads=None):
+    """Contigs of a chunk of paired records that are still FASTQ text (buffers + record indices of
+    moira_amd.fastio).  Returns (cbuf uint8[n * rec_cap], cidx int64[n, 6], aux int32[n, 3]): contigs as a
+    buffer + record index again (qualities as bytes q + offset), aux = overlap length, gaps, mismatches."""
+    L = load()
+    if not hasattr(L.mct_contigs_from_fastq, "_ready"):
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        L.mct_contigs_from_fastq.argtypes = [i64, vp, vp, vp, vp] + [i32] * 10 + [i64, vp, vp, vp, vp, vp]
+        L.mct_contigs_from_fastq._ready = True
+    if consensus_qscore not in CONSENSUS:
+        raise ValueError('consensus_qscore must be "best", "sum" or "posterior".')
+    fidx, ridx = np.ascontiguousarray(fidx), np.ascontiguousarray(ridx)
+    n = len(fidx)
+    threads = threads or (os.cpu_count() or 1)
+    rec_cap = int((fidx[:, 1] + 2 * (fidx[:, 3] + ridx[:, 3])).max()) + 8 if n else 8     # header + 2 x (l1 + l2)
+    cbuf = np.empty(n * rec_cap, np.uint8)
+    cidx = np.empty((n, 6), np.int64)
+    aux = np.empty((3, n), np.int32)
+    ptr = lambda b: b.ctypes.data if isinstance(b, np.ndarray) else b
+    rc = L.mct_contigs_from_fastq(n, ptr(fbuf), fidx.ctypes.data, ptr(rbuf), ridx.ctypes.data, int(fastq_offset),
+                                  match, mismatch, gap, insert, deltaq, CONSENSUS[consensus_qscore], qscore_cap,
+                                  1 if trim_overlap else 0, threads, rec_cap, cbuf.ctypes.data, cidx.ctypes.data,
+                                  aux[0].ctypes.data, aux[1].ctypes.data, aux[2].ctypes.data)
+    if rc == -7:
+        raise QualityRange(L.mct_last_error().decode())
+    _check(rc)
+    return cbuf, cidx, np.ascontiguousarray(aux.T)

@@ -7,6 +7,7 @@
 // order, the 3' overlap fix-up and the odd "score = sum of path cells" definition are kept.
 
 #include "../../include/moira_contig.h"
+#include "../../include/moira_io.h"      // MIO_* record-index columns
 
 #include <algorithm>
 #include <cmath>
@@ -377,6 +378,78 @@ extern "C" int mct_contigs_batch(int64_t n, const char *fwd_seq, const int32_t *
                                          &overlap_length[i], &gaps[i], &mismatches[i], qa, qb);
             if (r) { rc[t] = r; msgs[t] = g_err; return; }
             contig_len[i] = clen;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    for (int t = 0; t < threads; t++)
+        if (rc[t]) return fail(rc[t], "%s", msgs[t].c_str());
+    return MCT_OK;
+}
+
+extern "C" int mct_contigs_from_fastq(int64_t n, const char *fbuf, const int64_t *fidx, const char *rbuf,
+                                      const int64_t *ridx, int32_t fastq_offset, int32_t match, int32_t mismatch,
+                                      int32_t gap, int32_t insert, int32_t deltaq, int32_t consensus,
+                                      int32_t qscore_cap, int32_t trim_overlap, int32_t threads, int64_t rec_cap,
+                                      char *out_buf, int64_t *out_idx, int32_t *overlap_length, int32_t *gaps,
+                                      int32_t *mismatches)
+{
+    if (n < 0 || rec_cap <= 0 || (n > 0 && (!fbuf || !fidx || !rbuf || !ridx || !out_buf || !out_idx ||
+                                            !overlap_length || !gaps || !mismatches)))
+        return fail(MCT_E_INVALID, "bad arguments");
+    if (threads < 1) threads = 1;
+    if (threads > n && n > 0) threads = (int32_t)n;
+    std::vector<int> rc(threads, MCT_OK);
+    std::vector<std::string> msgs(threads);
+    auto work = [&](int t) {
+        NwWork sc;
+        std::vector<char> rseq, a1, a2, contig;
+        std::vector<int32_t> fq, rq_raw, rq, qa, qb, cq;
+        // contiguous shares: neighbouring output slots belong to one thread
+        const int64_t i0 = n * t / threads, i1 = n * (t + 1) / threads;
+        for (int64_t i = i0; i < i1; i++) {
+            const int64_t *f = fidx + i * MIO_IDX_COLS, *r = ridx + i * MIO_IDX_COLS;
+            const int l1 = (int)f[MIO_SEQ_LEN], l2 = (int)r[MIO_SEQ_LEN];
+            fq.resize(l1 + 1); rq_raw.resize(l2 + 1); rq.resize(l2 + 1); rseq.resize(l2 + 1);
+            a1.resize(l1 + l2 + 2); a2.resize(l1 + l2 + 2); contig.resize(l1 + l2 + 2); cq.resize(l1 + l2 + 2);
+            const unsigned char *fql = (const unsigned char *)fbuf + f[MIO_QUAL_OFF];
+            const unsigned char *rql = (const unsigned char *)rbuf + r[MIO_QUAL_OFF];
+            int lo = 0;
+            for (int k = 0; k < l1; k++) { fq[k] = (int)fql[k] - fastq_offset; lo |= fq[k]; }      // moira.py:1177
+            for (int k = 0; k < l2; k++) { rq_raw[k] = (int)rql[k] - fastq_offset; lo |= rq_raw[k]; }  // :1189
+            int rr = MCT_OK;
+            if (lo < 0) rr = fail(MCT_E_RANGE, "negative quality in pair %lld", (long long)i);
+            if (!rr) rr = mct_reverse_complement(rbuf + r[MIO_SEQ_OFF], rq_raw.data(), l2, rseq.data(), rq.data());
+            int32_t alen = 0, score = 0, clen = 0;
+            if (!rr) rr = nw_align_impl(fbuf + f[MIO_SEQ_OFF], l1, rseq.data(), l2, match, mismatch, gap,
+                                        a1.data(), a2.data(), &alen, &score, sc);
+            if (!rr) rr = make_contig_impl(a1.data(), fq.data(), a2.data(), rq.data(), alen, insert, deltaq, consensus,
+                                           qscore_cap, trim_overlap, contig.data(), cq.data(), &clen,
+                                           &overlap_length[i], &gaps[i], &mismatches[i], qa, qb);
+            const int64_t hl = f[MIO_HDR_LEN];
+            if (!rr && hl + 2 * (int64_t)clen > rec_cap)
+                rr = fail(MCT_E_BUFFER, "contig %lld needs %lld > %lld bytes", (long long)i, (long long)(hl + 2 * (int64_t)clen), (long long)rec_cap);
+            if (!rr) {
+                char *slot = out_buf + i * rec_cap;
+                memcpy(slot, fbuf + f[MIO_HDR_OFF], (size_t)hl);
+                memcpy(slot + hl, contig.data(), (size_t)clen);
+                unsigned char *qo = (unsigned char *)slot + hl + clen;
+                int hi = 0;
+                for (int k = 0; k < clen; k++) {
+                    const int b = cq[k] + fastq_offset;
+                    hi |= (255 - b) | cq[k];                 // sign bit set <=> b > 255 or q < 0
+                    qo[k] = (unsigned char)b;
+                }
+                if (hi < 0) rr = fail(MCT_E_RANGE, "a quality of contig %lld does not fit one byte", (long long)i);
+                int64_t *o = out_idx + i * MIO_IDX_COLS;
+                const int64_t base = i * rec_cap;
+                o[MIO_HDR_OFF] = base; o[MIO_HDR_LEN] = hl;
+                o[MIO_SEQ_OFF] = base + hl; o[MIO_SEQ_LEN] = clen;
+                o[MIO_QUAL_OFF] = base + hl + clen; o[MIO_QUAL_LEN] = clen;
+            }
+            if (rr) { rc[t] = rr; msgs[t] = g_err; return; }
         }
     };
     std::vector<std::thread> pool;

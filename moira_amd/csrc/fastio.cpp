@@ -76,6 +76,7 @@ struct mio_collapse {
         int32_t len;
         uint8_t flags;
         double ee;
+        int32_t aux[3];                  // overlap_length, gaps, mismatches of the representative
         int64_t size;                    // len(names_info)
         int64_t front, back_head, back_tail;   // names: front-inserted (newest first), then first seen + appended
     };
@@ -276,6 +277,17 @@ int32_t mio_pack(const char *buf, const int64_t *idx, const int64_t *sel, int64_
     return MIO_OK;
 }
 
+int64_t mio_first_header_mismatch(const char *fbuf, const int64_t *fidx, const char *rbuf, const int64_t *ridx, int64_t n)
+{
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t *f = fidx + k * MIO_IDX_COLS, *r = ridx + k * MIO_IDX_COLS;
+        if (f[MIO_HDR_LEN] != r[MIO_HDR_LEN] ||
+            memcmp(fbuf + f[MIO_HDR_OFF], rbuf + r[MIO_HDR_OFF], (size_t)f[MIO_HDR_LEN]) != 0)
+            return k;
+    }
+    return -1;
+}
+
 int32_t mio_py2_hash(const char *buf, const int64_t *idx, int64_t n, int32_t max_len, uint64_t *out)
 {
     if (!buf || !idx || n < 0 || (n > 0 && !out)) return fail(MIO_E_INVALID, "mio_py2_hash: bad arguments");
@@ -340,12 +352,42 @@ int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int6
 }
 
 
+int64_t mio_format_report(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel,
+                          const char *relabel, const int64_t *relabel_index, const double *ee,
+                          const int32_t *aux, char *out, int64_t cap, int64_t *needed)
+{
+    if (!buf || !idx || nsel < 0 || !aux || cap < 0 || (cap > 0 && !out) || (relabel && !relabel_index))
+        return fail(MIO_E_INVALID, "mio_format_report: bad arguments");
+    Out o{out, cap, 0};
+    const int64_t relabel_len = relabel ? (int64_t)strlen(relabel) : 0;
+    char num[96];
+    for (int64_t k = 0; k < nsel; k++) {
+        const int64_t rec = sel ? sel[k] : k;
+        const int64_t *r = idx + rec * MIO_IDX_COLS;
+        if (relabel) {
+            o.put(relabel, relabel_len);
+            o.put(num, snprintf(num, sizeof(num), "%lld", (long long)relabel_index[k]));
+        } else {
+            const char *h = buf + r[MIO_HDR_OFF];
+            const int64_t hl = r[MIO_HDR_LEN];
+            if (o.n + hl <= o.cap)
+                for (int64_t i = 0; i < hl; i++) o.p[o.n + i] = h[i] == ':' ? '_' : h[i];
+            o.n += hl;
+        }
+        if (ee) o.put(num, snprintf(num, sizeof(num), ";ee=%.2f;size=1;", ee[k]));
+        o.put(num, snprintf(num, sizeof(num), "\t1\t%d\t%d\t%d\n", aux[3 * rec], aux[3 * rec + 1], aux[3 * rec + 2]));   // moira.py:868
+    }
+    if (needed) *needed = o.n;
+    if (o.n > cap) return fail(MIO_E_SPACE, "output needs %lld bytes", (long long)o.n);
+    return o.n;
+}
+
 mio_collapse *mio_collapse_create(void) { return new (std::nothrow) mio_collapse(); }
 void mio_collapse_destroy(mio_collapse *c) { delete c; }
 int64_t mio_collapse_count(const mio_collapse *c) { return c ? (int64_t)c->uniq.size() : 0; }
 
 int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, int64_t n, int32_t max_len,
-                         const double *ee, const uint8_t *flags)
+                         const double *ee, const uint8_t *flags, const int32_t *aux)
 {
     if (!c || !buf || !idx || n < 0 || (n > 0 && !ee)) return fail(MIO_E_INVALID, "mio_collapse_add: bad arguments");
     try {
@@ -368,6 +410,7 @@ int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, i
                 u.seq_off = c->put(seq, L);
                 u.qual_off = c->put(buf + r[MIO_QUAL_OFF], L);
                 u.len = (int32_t)L; u.flags = flags ? flags[k] : 0; u.ee = ee[k]; u.size = 1;
+                for (int a = 0; a < 3; a++) u.aux[a] = aux ? aux[3 * k + a] : 0;
                 u.front = -1; u.back_head = u.back_tail = name_id;
                 where->hash = h; where->uid = (int64_t)c->uniq.size();
                 c->uniq.push_back(u);
@@ -377,6 +420,7 @@ int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, i
                 u.size++;
                 if (ee[k] < u.ee) {                                                 // moira.py:466-471: strict <
                     u.ee = ee[k];
+                    for (int a = 0; a < 3; a++) u.aux[a] = aux ? aux[3 * k + a] : 0;
                     u.qual_off = c->put(buf + r[MIO_QUAL_OFF], L);
                     c->names[name_id].next = u.front;                               // names_info.insert(0, header)
                     u.front = name_id;
@@ -392,7 +436,7 @@ int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, i
     return MIO_OK;
 }
 
-int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *size, uint8_t *flags)
+int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *size, uint8_t *flags, int32_t *aux)
 {
     if (!c) return fail(MIO_E_INVALID, "mio_collapse_export: bad arguments");
     // sorted(uniques, key=abundance, reverse=True): stable, on dict iteration (= slot) order  moira.py:492
@@ -407,6 +451,7 @@ int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *
         if (len) len[k] = u.len;
         if (size) size[k] = u.size;
         if (flags) flags[k] = u.flags;
+        if (aux) for (int a = 0; a < 3; a++) aux[3 * k + a] = u.aux[a];
     }
     return MIO_OK;
 }
@@ -416,7 +461,7 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
                             const char *const *labels, const int32_t *label_id, const uint8_t *lstrip_gt,
                             char *out, int64_t cap, int64_t *needed)
 {
-    if (!c || nsel < 0 || (nsel > 0 && !sel) || kind < MIO_FMT_FASTA || kind > MIO_FMT_NAMES || cap < 0 ||
+    if (!c || nsel < 0 || (nsel > 0 && !sel) || kind < MIO_FMT_FASTA || kind > MIO_FMT_REPORT || cap < 0 ||
         (cap > 0 && !out) || (label_id && !labels))
         return fail(MIO_E_INVALID, "mio_collapse_format: bad arguments");
     if (c->order.size() != c->uniq.size()) return fail(MIO_E_INVALID, "call mio_collapse_export first");
@@ -440,6 +485,11 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
         if (usearch) {                                                              // moira.py:858-863
             const int m = snprintf(num, sizeof(num), ";ee=%.2f;size=%lld;", u.ee, (long long)u.size);
             hdr.insert(hdr.end(), num, num + m);
+        }
+        if (kind == MIO_FMT_REPORT) {                                               // moira.py:866
+            o.put(hdr.data(), (int64_t)hdr.size());
+            o.put(num, snprintf(num, sizeof(num), "\t%lld\t%d\t%d\t%d\n", (long long)u.size, u.aux[0], u.aux[1], u.aux[2]));
+            continue;
         }
         if (kind == MIO_FMT_NAMES) {                                                // "%s\t%s\n" % (header, ",".join(names_info))
             size_t h0 = 0;

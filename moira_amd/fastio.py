@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmoira_io.so")
 E_INVALID, E_UNSUPPORTED, E_RANGE, E_SPACE = -1, -2, -3, -4
 REC_OK, REC_EMPTY_SEQ, REC_EMPTY_QUAL, REC_LENGTH_MISMATCH = 0, 1, 2, 3
 HDR_OFF, HDR_LEN, SEQ_OFF, SEQ_LEN, QUAL_OFF, QUAL_LEN, IDX_COLS = 0, 1, 2, 3, 4, 5, 6
-FMT_FASTA, FMT_QUAL, FMT_FASTQ, FMT_NAMES = 0, 1, 2, 3
+FMT_FASTA, FMT_QUAL, FMT_FASTQ, FMT_NAMES, FMT_REPORT = 0, 1, 2, 3, 4
 _lib = None
 
 
@@ -34,18 +34,22 @@ class RecordError(Exception):
 PROTOTYPES = {
     "mio_version": (C.c_char_p, []),
     "mio_last_error": (C.c_char_p, []),
-    "mio_fastq_index": (C.c_int64, [C.c_char_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mio_pack": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+    "mio_fastq_index": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mio_pack": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mio_py2_hash": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "mio_py2_hash": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "mio_collapse_create": (C.c_void_p, []),
     "mio_collapse_destroy": (None, [C.c_void_p]),
     "mio_collapse_count": (C.c_int64, [C.c_void_p]),
-    "mio_collapse_add": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
-    "mio_collapse_export": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mio_collapse_add": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "mio_collapse_export": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mio_format_report": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mio_collapse_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "mio_format": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+    "mio_first_header_mismatch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "mio_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p]),
 }
@@ -69,9 +73,14 @@ def _err():
     return load().mio_last_error().decode()
 
 
+def _ptr(buf):
+    """bytes (a file chunk) or a uint8 numpy array (contigs built in C) as a C pointer argument."""
+    return buf.ctypes.data if isinstance(buf, np.ndarray) else buf
+
+
 def header_of(buf, row):
     """The normalised header of one index row (moira.py:1175)."""
-    return buf[row[HDR_OFF]:row[HDR_OFF] + row[HDR_LEN]].decode("ascii").replace(":", "_")
+    return bytes(buf[row[HDR_OFF]:row[HDR_OFF] + row[HDR_LEN]]).decode("ascii").replace(":", "_")
 
 
 def index(buf, final, max_records):
@@ -80,7 +89,7 @@ def index(buf, final, max_records):
     idx = np.empty((max(max_records, 1) + 0, IDX_COLS), np.int64)
     consumed = C.c_int64(0)
     bad = C.c_int32(0)
-    n = L.mio_fastq_index(buf, len(buf), 1 if final else 0, max_records, idx.ctypes.data, C.addressof(consumed),
+    n = L.mio_fastq_index(_ptr(buf), len(buf), 1 if final else 0, max_records, idx.ctypes.data, C.addressof(consumed),
                           C.addressof(bad))
     if n == E_UNSUPPORTED:
         raise Unsupported(_err())
@@ -106,7 +115,8 @@ def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, 
     lens = np.empty(n, np.int32)
     flags = np.empty(n, np.uint8)
     bad = C.c_int64(-1)
-    rc = L.mio_pack(buf, idx.ctypes.data, sel.ctypes.data if sel is not None else None, n, int(fastq_offset),
+    idx = np.ascontiguousarray(idx)
+    rc = L.mio_pack(_ptr(buf), idx.ctypes.data, sel.ctypes.data if sel is not None else None, n, int(fastq_offset),
                     int(max_len), 1 if lower_n_is_base else 0, stride, q.ctypes.data, lens.ctypes.data,
                     flags.ctypes.data, C.addressof(bad))
     if rc:
@@ -114,10 +124,16 @@ def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, 
     return q, lens, flags.astype(bool)
 
 
+def first_header_mismatch(fbuf, fidx, rbuf, ridx):
+    """Position of the first pair whose header tokens differ, or -1."""
+    fidx, ridx = np.ascontiguousarray(fidx), np.ascontiguousarray(ridx)
+    return load().mio_first_header_mismatch(_ptr(fbuf), fidx.ctypes.data, _ptr(rbuf), ridx.ctypes.data, len(fidx))
+
+
 def py2_hashes(buf, idx, max_len=0):
     """CPython-2.7 hash(str) of every record's (truncated) sequence, as Python ints."""
     out = np.empty(len(idx), np.uint64)
-    if load().mio_py2_hash(buf, idx.ctypes.data, len(idx), int(max_len), out.ctypes.data):
+    if load().mio_py2_hash(_ptr(buf), idx.ctypes.data, len(idx), int(max_len), out.ctypes.data):
         raise ValueError(_err())
     return out.tolist()
 
@@ -146,7 +162,7 @@ def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None
                                                                    + (max(map(len, labels)) if labels else 0))
     out = np.empty(cap, np.uint8)
     needed = C.c_int64(0)
-    args = (buf, idx.ctypes.data, sel.ctypes.data, n, kind, int(fastq_offset), int(max_len),
+    args = (_ptr(buf), idx.ctypes.data, sel.ctypes.data, n, kind, int(fastq_offset), int(max_len),
             relabel.encode() if relabel is not None else None,
             relabel_index.ctypes.data if relabel is not None else None,
             ee.ctypes.data if ee is not None else None,
@@ -157,6 +173,31 @@ def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None
         cap = needed.value
         out = np.empty(cap, np.uint8)
         w = L.mio_format(*args, out.ctypes.data, cap, C.addressof(needed))
+    if w < 0:
+        raise ValueError(_err())
+    return memoryview(out)[:w]
+
+
+def format_report(buf, idx, sel, aux, relabel=None, relabel_index=None, ee=None):
+    """contigs.report lines of records written one by one (n_seqs = 1); aux int32[n_records, 3]."""
+    L = load()
+    sel = np.ascontiguousarray(sel, np.int64)
+    n = len(sel)
+    if n == 0:
+        return b""
+    idx = np.ascontiguousarray(idx)
+    aux = np.ascontiguousarray(aux, np.int32)
+    if relabel is not None:
+        relabel_index = np.ascontiguousarray(relabel_index, np.int64)
+    if ee is not None:
+        ee = np.ascontiguousarray(ee, np.float64)
+    cap = int(idx[sel, HDR_LEN].sum()) + n * (96 + (len(relabel) if relabel else 0))
+    out = np.empty(cap, np.uint8)
+    needed = C.c_int64(0)
+    w = L.mio_format_report(_ptr(buf), idx.ctypes.data, sel.ctypes.data, n, relabel.encode() if relabel else None,
+                            relabel_index.ctypes.data if relabel is not None else None,
+                            ee.ctypes.data if ee is not None else None, aux.ctypes.data, out.ctypes.data, cap,
+                            C.addressof(needed))
     if w < 0:
         raise ValueError(_err())
     return memoryview(out)[:w]
@@ -182,22 +223,26 @@ class Collapse:
     def __len__(self):
         return self.lib.mio_collapse_count(self.h)
 
-    def add(self, buf, idx, ee, flags, max_len=0):
+    def add(self, buf, idx, ee, flags, max_len=0, aux=None):
         idx = np.ascontiguousarray(idx)
         ee = np.ascontiguousarray(ee, np.float64)
         flags = np.ascontiguousarray(flags, np.uint8)
-        if self.lib.mio_collapse_add(self.h, buf, idx.ctypes.data, len(idx), int(max_len), ee.ctypes.data,
-                                     flags.ctypes.data):
+        if aux is not None:
+            aux = np.ascontiguousarray(aux, np.int32)
+        if self.lib.mio_collapse_add(self.h, _ptr(buf), idx.ctypes.data, len(idx), int(max_len), ee.ctypes.data,
+                                     flags.ctypes.data, aux.ctypes.data if aux is not None else None):
             raise ValueError(_err())
 
     def export(self):
-        """-> (ee, length, abundance, has_upper_N) per group, in output order."""
+        """-> (ee, length, abundance, has_upper_N, aux[., 3]) per group, in output order."""
         n = len(self)
         ee, ln, size, fl = np.empty(n), np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.uint8)
-        if self.lib.mio_collapse_export(self.h, ee.ctypes.data, ln.ctypes.data, size.ctypes.data, fl.ctypes.data):
+        aux = np.empty((n, 3), np.int32)
+        if self.lib.mio_collapse_export(self.h, ee.ctypes.data, ln.ctypes.data, size.ctypes.data, fl.ctypes.data,
+                                        aux.ctypes.data):
             raise ValueError(_err())
         self._len, self._size = ln, size
-        return ee, ln, size, fl.astype(bool)
+        return ee, ln, size, fl.astype(bool), aux
 
     def format(self, sel, kind, fastq_offset=33, relabel=None, usearch=False, labels=None, label_id=None,
                lstrip_gt=None):
@@ -217,7 +262,7 @@ class Collapse:
                 label_id.ctypes.data if label_id is not None else None,
                 lstrip_gt.ctypes.data if lstrip_gt is not None else None)
         needed = C.c_int64(0)
-        cap = int(self._len[sel].sum()) * (4 if kind == FMT_QUAL else 2) + n * 128
+        cap = int(self._len[sel].sum()) * (4 if kind == FMT_QUAL else 2) + n * 160
         out = np.empty(cap, np.uint8)
         w = self.lib.mio_collapse_format(*args, out.ctypes.data, cap, C.addressof(needed))
         if w == E_SPACE:
@@ -257,3 +302,56 @@ class FastqChunks:
                     break                       # the rest is an incomplete record: read on
             if eof:
                 return                          # trailing lines that do not make a record are dropped
+
+
+class PairedRecordError(Exception):
+    """RecordError of file `which` (0 forward, 1 reverse) in a paired run."""
+
+    def __init__(self, which, err):
+        Exception.__init__(self, which, err)
+        self.which, self.err = which, err
+
+
+class PairedFastqChunks:
+    """Two FASTQ streams in lockstep: (fbuf, fidx, rbuf, ridx) with the same number of records each.
+    Stops with the shorter file, as zip() does in the reference's parser (moira/moira.py:1158-1160); a
+    record that fails the reference's checks raises only when its pair is reached, forward file first."""
+
+    def __init__(self, ffh, rfh, max_records, block_bytes=1 << 24):
+        self.fh, self.max_records, self.block = (ffh, rfh), max_records, block_bytes
+
+    def __iter__(self):
+        tail, eof, want = [b"", b""], [False, False], [True, True]
+        while True:
+            for k in (0, 1):
+                if want[k] and not eof[k]:
+                    more = self.fh[k].read(self.block)
+                    if more:
+                        tail[k] = tail[k] + more if tail[k] else more
+                    else:
+                        eof[k] = True
+            got = [index(tail[k], eof[k], self.max_records) for k in (0, 1)]
+            n = min(len(got[0][0]), len(got[1][0]))
+            # does file k hold a complete record number n (sound or not)?
+            has_next = [len(got[k][0]) > n or got[k][2] is not None for k in (0, 1)]
+            err = None
+            if has_next[0] and has_next[1]:
+                for k in (0, 1):
+                    if err is None and got[k][2] is not None and len(got[k][0]) == n:
+                        err = PairedRecordError(k, got[k][2])
+                if err is not None and err.which == 1:       # then forward record n is sound: the reference names it
+                    err.err.forward_header = header_of(tail[0], got[0][0][n])
+            if n:
+                for k in (0, 1):
+                    if len(got[k][0]) > n:                   # keep what the other file has not reached yet
+                        got[k] = index(tail[k], eof[k], n)
+                yield tail[0], got[0][0], tail[1], got[1][0]
+                tail = [tail[k][got[k][1]:] for k in (0, 1)]
+            if err is not None:
+                raise err
+            if n == self.max_records:
+                want = [len(tail[k]) < self.block for k in (0, 1)]
+                continue
+            if any(not has_next[k] and eof[k] for k in (0, 1)):
+                return                                       # one file is exhausted: zip() stops here
+            want = [not has_next[k] for k in (0, 1)]

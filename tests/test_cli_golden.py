@@ -85,6 +85,11 @@ def test_forward_dataset_host_logic(tmp_path, oracle):
     run_forward(tmp_path, oracle_backend(oracle))
 
 
+def test_paired_dataset_host_logic_line_parser(tmp_path, oracle, monkeypatch):
+    monkeypatch.setenv("MOIRA_NO_FASTIO", "1")
+    run_paired(tmp_path, oracle_backend(oracle))
+
+
 def test_forward_dataset_host_logic_line_parser(tmp_path, oracle, monkeypatch):
     monkeypatch.setenv("MOIRA_NO_FASTIO", "1")          # the per-line Python path, kept as the fallback
     run_forward(tmp_path, oracle_backend(oracle))

@@ -256,3 +256,102 @@ def test_cli_raises_the_reference_exceptions(tmp_path, oracle):
     with pytest.raises(cli.LengthMismatchError) as e:
         cli.main(args_for(str(src), str(tmp_path / "o")), backend=matrix_backend(oracle), out=open(os.devnull, "w"))
     assert "b_1" in str(e.value)
+
+
+# ---- paired input: contigs built in C from the two file buffers -------------------------------------
+def make_pairs(rng, n, read_len=(60, 110), frag=(90, 160)):
+    comp = str.maketrans("ACGTN", "TGCAN")
+    f_recs, r_recs = [], []
+    for i in range(n):
+        L1, L2 = int(rng.integers(*read_len)), int(rng.integers(*read_len))
+        F_ = max(int(rng.integers(*frag)), L1, L2)
+        if i % 9 == 0:
+            F_ = L1 + L2 + 5                                   # no real overlap
+        fragment = "".join(rng.choice(list("ACGT"), F_))
+        if i % 7 == 3:
+            fragment = fragment[:F_ // 2] + fragment[:F_ - F_ // 2]     # a repeat: several equally good alignments
+        fwd = list(fragment[:L1])
+        rev = list(fragment[F_ - L2:][::-1].translate(comp))
+        for read in (fwd, rev):
+            for k in range(len(read)):
+                if rng.random() < 0.03:
+                    read[k] = str(rng.choice(list("ACGTN")))
+        if i % 11 == 5:
+            k = int(rng.integers(5, L1 - 5))
+            del fwd[k]                                          # an indel
+        q1 = "".join(chr(33 + int(x)) for x in np.clip(38 - rng.integers(0, 36, len(fwd)) * (np.arange(len(fwd)) / len(fwd)), 0, 41))
+        q2 = "".join(chr(33 + int(x)) for x in np.clip(38 - rng.integers(0, 36, len(rev)) * (np.arange(len(rev)) / len(rev)), 0, 41))
+        h = "@M1:%d:p%d" % (i % 5, i if i >= 40 else i % 20)    # a few repeated names do no harm
+        f_recs.append("%s 1:N:0\n%s\n+\n%s\n" % (h, "".join(fwd), q1))
+        r_recs.append("%s 2:N:0\n%s\n+\n%s\n" % (h, "".join(rev), q2))
+    dup = list(range(0, n, 6))                                   # exact duplicates so that collapse has groups
+    return "".join(f_recs + [f_recs[i] for i in dup]), "".join(r_recs + [r_recs[i] for i in dup])
+
+
+PAIRED_CASES = [
+    dict(),
+    dict(collapse=True),
+    dict(collapse=True, output_format="fastq", min_overlap=30),
+    dict(min_overlap=40, truncate=120, relabel="c"),
+    dict(collapse=True, pipeline="USEARCH", consensus_qscore="sum", qscore_cap=0),
+    dict(consensus_qscore="posterior", ambigs="disallow", trim_overlap=True),
+    dict(collapse=True, maxerrors=2.0, truncate=100, min_overlap=35),
+]
+
+
+@pytest.mark.parametrize("case", range(len(PAIRED_CASES)))
+def test_cli_byte_level_path_equals_line_path_paired(tmp_path, oracle, monkeypatch, case):
+    f_text, r_text = make_pairs(np.random.default_rng(500 + case), 130)
+    (tmp_path / "f.fastq").write_bytes(f_text.encode())
+    with gzip.open(tmp_path / "r.fastq.gz", "wb") as fh:
+        fh.write(r_text.encode())
+    kw = dict(paired=True, reverse_fastq=str(tmp_path / "r.fastq.gz"), **PAIRED_CASES[case])
+    backend = matrix_backend(oracle)
+    calls = []
+    real = cli._run_fast_fastq
+    monkeypatch.setattr(cli, "_run_fast_fastq", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(cli, "PAIR_CHUNK_READS", 37)             # several chunks
+    src = str(tmp_path / "f.fastq")
+    assert cli.main(args_for(src, str(tmp_path / "fast"), **kw), backend=backend, out=open(os.devnull, "w")) == 0
+    assert calls == [1]
+    monkeypatch.setenv("MOIRA_NO_FASTIO", "1")
+    assert cli.main(args_for(src, str(tmp_path / "slow"), **kw), backend=backend, out=open(os.devnull, "w")) == 0
+    assert calls == [1]
+    fast, slow = outputs_of(str(tmp_path / "fast")), outputs_of(str(tmp_path / "slow"))
+    assert fast.keys() == slow.keys() and "contigs.report" in fast
+    for k in fast:
+        assert fast[k] == slow[k], k
+    assert sum(len(v) for v in fast.values()) > 5000
+
+
+def test_paired_errors_are_the_line_parsers(tmp_path, oracle):
+    ok_f, ok_r = "@a\nACGTACGTAC\n+\nIIIIIIIIII\n", "@a\nGTACGTACGT\n+\nIIIIIIIIII\n"
+    cases = [
+        (ok_f + "@b\nACGT\n+\nIIII\n", ok_r + "@c\nACGT\n+\nIIII\n", cli.NameMismatchError, "'b'"),
+        (ok_f + "@b\nACGT\n+\nIIII\n", ok_r + "@b:x\nACGT\n+\nIII\n", cli.LengthMismatchError, "b_x"),
+        (ok_f + "@b\nACGT\n+\nIII\n", ok_r + "@b\nACGT\n+\nIII\n", cli.LengthMismatchError, "f.fastq"),
+        (ok_f + "@bf\nACGT\n+\nIIII\n", ok_r + "@br\n\n+\nIIII\n", cli.EmptySeqError, "bf"),
+    ]
+    for f_text, r_text, exc, needle in cases:
+        (tmp_path / "f.fastq").write_bytes(f_text.encode())
+        (tmp_path / "r.fastq").write_bytes(r_text.encode())
+        msgs = []
+        for env in (None, "1"):
+            if env:
+                os.environ["MOIRA_NO_FASTIO"] = env
+            try:
+                with pytest.raises(exc) as e:
+                    cli.main(args_for(str(tmp_path / "f.fastq"), str(tmp_path / "o"), paired=True,
+                                      reverse_fastq=str(tmp_path / "r.fastq")),
+                             backend=matrix_backend(oracle), out=open(os.devnull, "w"))
+                msgs.append(str(e.value))
+            finally:
+                os.environ.pop("MOIRA_NO_FASTIO", None)
+        assert msgs[0] == msgs[1] and needle in msgs[0], msgs
+    # the shorter file ends the run, as zip() does
+    (tmp_path / "f.fastq").write_bytes((ok_f * 3).encode())
+    (tmp_path / "r.fastq").write_bytes((ok_r * 2).encode())
+    assert cli.main(args_for(str(tmp_path / "f.fastq"), str(tmp_path / "o"), paired=True,
+                             reverse_fastq=str(tmp_path / "r.fastq")), backend=matrix_backend(oracle),
+                    out=open(os.devnull, "w")) == 0
+    assert open(str(tmp_path / "o") + ".contigs.report").read().count("\n") == 3     # header + 2 pairs
