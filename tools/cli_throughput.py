@@ -44,9 +44,51 @@ def run(label, extra, env=None):
             os.environ["MOIRA_NO_FASTIO"] = old
 
 
+
+def paired_files(m, L=250, frag=380):
+    """m pairs of 2 x L bp reads off random fragments (overlap L*2-frag), ~1 % substitutions."""
+    rng = np.random.default_rng(7)
+    B = np.frombuffer(b"ACGT", np.uint8)
+    lut = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        lut[a] = b
+    frags = B[rng.integers(0, 4, (m, frag))]
+    fwd, rev = frags[:, :L].copy(), lut[frags[:, frag - L:][:, ::-1]]
+    for a in (fwd, rev):
+        pos = np.minimum((rng.random((m, 3)) ** 0.4 * L).astype(int), L - 1)
+        a[np.arange(m)[:, None], pos] = B[rng.integers(0, 4, (m, 3))]
+    qv = (np.maximum(q[:m, :L], 1) + 33).astype(np.uint8)
+    paths = []
+    for tag, arr in (("R1", fwd), ("R2", rev)):
+        pth = os.path.join(tmp, "synth_%s.fastq" % tag)
+        with open(pth, "w") as f:
+            for i in range(m):
+                f.write("@p%d\n%s\n+\n%s\n" % (i, arr[i].tobytes().decode(), qv[i].tobytes().decode()))
+        paths.append(pth)
+    return paths
+
+
 run("warm-up", ["-c", "false"])
 run("fastq in, fasta+qual out, no collapse", ["-c", "false"])
 run("fastq in, fastq out, no collapse", ["-c", "false", "-o", "fastq"])
 run("fastq in, fasta+qual out, collapse", ["-c", "true"])
 run("line parser: fasta+qual out, no collapse", ["-c", "false"], {"MOIRA_NO_FASTIO": "1"})
 run("line parser: fasta+qual out, collapse", ["-c", "true"], {"MOIRA_NO_FASTIO": "1"})
+
+m = min(n, 200_000)
+r1, r2 = paired_files(m)
+
+
+def run_paired(label, extra, env=None):
+    global path, n
+    keep = (path, n)
+    path, n = r1, m
+    try:
+        run(label, ["-rfq", r2, "--paired", "-p", str(os.cpu_count())] + extra, env)
+    finally:
+        path, n = keep
+
+
+run_paired("paired 2x250: contigs + filter, collapse", ["-c", "true"])
+run_paired("paired 2x250: contigs + filter, no collapse", ["-c", "false"])
+run_paired("line parser: paired, collapse", ["-c", "true"], {"MOIRA_NO_FASTIO": "1"})
