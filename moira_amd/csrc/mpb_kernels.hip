@@ -373,12 +373,12 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
 __device__ __forceinline__ double dpp_prev_row(double x, int keep)
 {
     // value of lane-1 (wave_shr:1, lane 0 reads 0 through bound_ctrl), ANDed with `keep`
-    // (0 in the first lane of every read, ~0 elsewhere).  Written so that the DPP-combine pass can
-    // fold shift and mask into one v_and_b32_dpp per 32-bit half.
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true) & keep;
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true) & keep;
-    return __hiloint2double(hi, lo);
+    // (0 in the first lane of every read, ~0 elsewhere).  Written as ONE 64-bit shift + mask so that
+    // the DPP-combine pass folds both halves into a v_and_b32_dpp each (the two-halves spelling left
+    // a v_mov_b32_dpp + v_and_b32 pair for the low half).
+    const long long k64 = ((long long)keep << 32) | (unsigned int)keep;
+    const long long y = __builtin_amdgcn_update_dpp(0ll, __double_as_longlong(x), 0x138, 0xf, 0xf, true) & k64;
+    return __longlong_as_double(y);
 }
 
 template <bool FMA>
