@@ -734,7 +734,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
             for stride in np.unique(strides):
                 sel = np.nonzero(strides == stride)[0]
                 q, ln, fl = F.pack(buf, idx, sel, args.fastq_offset, T, lower_n_is_base=(method == "poisson"),
-                                   stride=int(stride))
+                                   stride=int(stride), reuse=True)
                 ee[sel] = backend.matrix(q, ln, args.alpha, args.ambigs, args.round, method=method, fast_discard=fd)
                 has_n[sel] = fl
             nan = np.isnan(ee)

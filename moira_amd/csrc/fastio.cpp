@@ -174,8 +174,12 @@ void put_quals(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset)
 void put_qual_string(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset)
 {
     // chr(q + offset) of the clamped qualities = the input string with Q0 shown as Q1
-    if (o.n + L <= o.cap)
-        for (int64_t i = 0; i < L; i++) o.p[o.n + i] = (char)(ql[i] == fastq_offset ? ql[i] + 1 : ql[i]);
+    if (o.n + L <= o.cap) {
+        char *w = o.p + o.n;
+        memcpy(w, ql, (size_t)L);
+        for (char *z = (char *)memchr(w, fastq_offset, (size_t)L); z; z = (char *)memchr(z, fastq_offset, (size_t)(w + L - z)))
+            *z++ = (char)(fastq_offset + 1);
+    }
     o.n += L;
 }
 
@@ -253,17 +257,38 @@ int32_t mio_pack(const char *buf, const int64_t *idx, const int64_t *sel, int64_
         const unsigned char *sq = (const unsigned char *)buf + r[MIO_SEQ_OFF];
         const unsigned char *ql = (const unsigned char *)buf + r[MIO_QUAL_OFF];
         uint8_t *row = out + k * row_stride;
+        // branch-free per-byte form (the compiler turns it into byte-wide SIMD): qualities first, then
+        // the ambiguity markers over them
         int lo = 0, hi = 0;
         unsigned char any_n = 0;
-        for (int64_t i = 0; i < L; i++) {
-            int q = (int)ql[i] - fastq_offset;               // moira.py:1177
-            lo |= q;                                         // sign bit set <=> some q < 0
-            hi |= 254 - q;                                   // sign bit set <=> some q > 254
-            q = q == 0 ? 1 : q;                              // moira.py:814, bernoullimodule.c:104-107
-            const unsigned char b = sq[i];
-            const bool up = b == 'N', low = b == 'n' && !lower_n_is_base;   // bernoullimodule.c:196
-            any_n |= (unsigned char)up;
-            row[i] = up ? 0 : low ? 255 : (uint8_t)q;
+        if (fastq_offset >= 0 && fastq_offset <= 255) {
+            const unsigned char off = (unsigned char)fastq_offset;
+            unsigned char below = 0, above = 0;
+            for (int64_t i = 0; i < L; i++) {
+                const unsigned char c = ql[i];                       // q = c - off            moira.py:1177
+                below |= (unsigned char)(c < off);
+                above |= (unsigned char)(c > (unsigned)off + 254u);   // only possible for off == 0
+                unsigned char q = (unsigned char)(c - off);
+                q = q == 0 ? 1 : q;                                  // moira.py:814, bernoullimodule.c:104-107
+                const unsigned char b = sq[i];
+                const unsigned char up = (unsigned char)(b == 'N');                             // bernoullimodule.c:196
+                const unsigned char low = (unsigned char)((b == 'n') & (lower_n_is_base == 0));
+                any_n |= up;
+                row[i] = up ? 0 : low ? 255 : q;
+            }
+            lo = below ? -1 : 0;
+            hi = above ? -1 : 0;
+        } else {
+            for (int64_t i = 0; i < L; i++) {
+                int q = (int)ql[i] - fastq_offset;
+                lo |= q;                                         // sign bit set <=> some q < 0
+                hi |= 254 - q;                                   // sign bit set <=> some q > 254
+                q = q == 0 ? 1 : q;
+                const unsigned char b = sq[i];
+                const bool up = b == 'N', low = b == 'n' && !lower_n_is_base;
+                any_n |= (unsigned char)up;
+                row[i] = up ? 0 : low ? 255 : (uint8_t)q;
+            }
         }
         if ((lo | hi) < 0) {
             if (bad_record) *bad_record = k;

@@ -73,6 +73,18 @@ def _err():
     return load().mio_last_error().decode()
 
 
+_scratch = {}
+
+
+def _scratch_u8(name, nbytes):
+    """A grow-only uint8 work buffer per purpose: fresh pages for every chunk cost more than the loops
+    that fill them.  The returned view is valid until the next call with the same name."""
+    a = _scratch.get(name)
+    if a is None or len(a) < nbytes:
+        a = _scratch[name] = np.empty(max(nbytes, 1 << 20) * 5 // 4, np.uint8)
+    return a[:nbytes]
+
+
 def _ptr(buf):
     """bytes (a file chunk) or a uint8 numpy array (contigs built in C) as a C pointer argument."""
     return buf.ctypes.data if isinstance(buf, np.ndarray) else buf
@@ -99,8 +111,9 @@ def index(buf, final, max_records):
     return idx[:n], consumed.value, err
 
 
-def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, stride=None):
-    """-> (q uint8[nsel, stride], lens int32[nsel], has_upper_N bool[nsel])"""
+def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, stride=None, reuse=False):
+    """-> (q uint8[nsel, stride], lens int32[nsel], has_upper_N bool[nsel]).  reuse=True: q lives in a
+    work buffer that the next pack(reuse=True) overwrites."""
     L = load()
     if sel is not None:
         sel = np.ascontiguousarray(sel, np.int64)
@@ -111,7 +124,7 @@ def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, 
         if max_len > 0:
             longest = min(longest, max_len)
         stride = (max(longest, 1) + 15) // 16 * 16
-    q = np.empty((n, stride), np.uint8)
+    q = _scratch_u8("pack", n * stride).reshape(n, stride) if reuse else np.empty((n, stride), np.uint8)
     lens = np.empty(n, np.int32)
     flags = np.empty(n, np.uint8)
     bad = C.c_int64(-1)
@@ -140,7 +153,8 @@ def py2_hashes(buf, idx, max_len=0):
 
 def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None, relabel_index=None, ee=None,
                    labels=None, label_id=None):
-    """Selected records as one bytes-like object (kind: FMT_FASTA / FMT_QUAL / FMT_FASTQ)."""
+    """Selected records as one bytes-like object (kind: FMT_FASTA / FMT_QUAL / FMT_FASTQ), valid until the
+    next formatting call."""
     L = load()
     sel = np.ascontiguousarray(sel, np.int64)
     n = len(sel)
@@ -160,7 +174,7 @@ def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None
     per = 4 if kind == FMT_QUAL else (2 if kind == FMT_FASTQ else 1)
     cap = int(L_.sum()) * per + int(idx[sel, HDR_LEN].sum()) + n * (64 + (len(relabel) if relabel else 0)
                                                                    + (max(map(len, labels)) if labels else 0))
-    out = np.empty(cap, np.uint8)
+    out = _scratch_u8("format", cap)
     needed = C.c_int64(0)
     args = (_ptr(buf), idx.ctypes.data, sel.ctypes.data, n, kind, int(fastq_offset), int(max_len),
             relabel.encode() if relabel is not None else None,
@@ -171,7 +185,7 @@ def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None
     w = L.mio_format(*args, out.ctypes.data, cap, C.addressof(needed))
     if w == E_SPACE:
         cap = needed.value
-        out = np.empty(cap, np.uint8)
+        out = _scratch_u8("format", cap)
         w = L.mio_format(*args, out.ctypes.data, cap, C.addressof(needed))
     if w < 0:
         raise ValueError(_err())
@@ -263,11 +277,11 @@ class Collapse:
                 lstrip_gt.ctypes.data if lstrip_gt is not None else None)
         needed = C.c_int64(0)
         cap = int(self._len[sel].sum()) * (4 if kind == FMT_QUAL else 2) + n * 160
-        out = np.empty(cap, np.uint8)
+        out = _scratch_u8("format", cap)
         w = self.lib.mio_collapse_format(*args, out.ctypes.data, cap, C.addressof(needed))
         if w == E_SPACE:
             cap = needed.value
-            out = np.empty(cap, np.uint8)
+            out = _scratch_u8("format", cap)
             w = self.lib.mio_collapse_format(*args, out.ctypes.data, cap, C.addressof(needed))
         if w < 0:
             raise ValueError(_err())
