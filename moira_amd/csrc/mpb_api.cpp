@@ -298,7 +298,7 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
     const int64_t nb = (cap + MPB_PRE_READS - 1) / MPB_PRE_READS;
     const int64_t b_cls = align_up(cap, 256);
     const int64_t b_perm = align_up((cap + (int64_t)MPB_NCLS * 64) * 4, 256);
-    const int64_t b_hist = align_up(nb * MPB_NCLS * 4, 256);
+    const int64_t b_hist = align_up(nb * MPB_SKEYS * 4, 256);
     const int64_t b_ovf = align_up(cap * 4, 256);
     HIPCHK(hipMalloc(&c->ws_block, (size_t)(b_cls + b_perm + b_hist + b_ovf)));
     char *p = (char *)c->ws_block;
@@ -451,8 +451,8 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
     hipStream_t s = c->stream;
     { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
-    { Span t(c, MPB_K_SCAN);     mpb_launch_scan(n, c->ws, s); }
-    { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, c->ws, s); }
+    { Span t(c, MPB_K_SCAN);     mpb_launch_scan(n, d_len, c->ws, s); }
+    { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, d_len, prm, c->ws, s); }
     { Span t(c, MPB_K_DP);       mpb_launch_dp(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     { Span t(c, MPB_K_OVERFLOW); mpb_launch_overflow(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     HIPCHK(hipGetLastError());

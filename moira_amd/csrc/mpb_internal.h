@@ -36,6 +36,15 @@ struct MpbClass { int cap, G, R; };
 // class byte of a read the prepass already settled (MPB_FLAG_DECISION_ONLY): never scattered, never run
 #define MPB_CLS_SETTLED 0x7f
 
+// Sort key of a read = (class, length bin of 2^MPB_LEN_SHIFT bases): perm[] is grouped by class and, inside a class,
+// by length, because a DP tile runs as long as its longest read.  Batches with one fixed length use a
+// single bin.
+#ifndef MPB_LEN_SHIFT
+#define MPB_LEN_SHIFT 6               // bin width 2^6 bases
+#endif
+#define MPB_LEN_BINS (1024 >> MPB_LEN_SHIFT)
+#define MPB_SKEYS (MPB_NCLS * MPB_LEN_BINS)
+
 // Device-side tables produced by the scan kernel, consumed by scatter and DP kernels.
 struct MpbTables {
     int32_t count[MPB_NCLS];          // reads per class
@@ -43,6 +52,8 @@ struct MpbTables {
     int32_t tile_start[MPB_NCLS + 1]; // first tile of the class (tiles ordered widest class first)
     int32_t total_tiles;
     int32_t next_chunk;               // reserved
+    int32_t kcount[MPB_SKEYS];        // reads per sort key (class * bins + bin)
+    int32_t key_base[MPB_SKEYS];      // first slot of the key in perm[]
 };
 
 // consecutive tiles one wave processes: almost always of one class, so a wave enters a class body
@@ -65,7 +76,7 @@ struct MpbDevParams {
 struct MpbWorkspace {
     uint8_t  *cls;         // [n]   class id | 0x80 if the read has an upper-case N
     int32_t  *perm;        // [n + MPB_NCLS*64] read indices grouped by class
-    int32_t  *blockhist;   // [nblocks_pre][MPB_NCLS]
+    int32_t  *blockhist;   // [MPB_SKEYS][nblocks_pre], key-major
     MpbTables *tables;     // main pass
     MpbTables *tables2;    // overflow pass
     int32_t  *ovf_list;    // [n]
@@ -82,8 +93,8 @@ struct MpbWorkspace {
 void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
                         double *ee_out, uint8_t *pass_out, hipStream_t s);
-void mpb_launch_scan(int64_t n, const MpbWorkspace &ws, hipStream_t s);
-void mpb_launch_scatter(int64_t n, const MpbWorkspace &ws, hipStream_t s);
+void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s);
+void mpb_launch_scatter(int64_t n, const int32_t *len, const MpbDevParams &prm, const MpbWorkspace &ws, hipStream_t s);
 void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                    const MpbDevParams &prm, const MpbWorkspace &ws, const int32_t *ns,
                    double *ee, uint8_t *pass, hipStream_t s);

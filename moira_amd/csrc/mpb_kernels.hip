@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
 {
     __shared__ float2 s_tab[256];
     __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts}
-    __shared__ int s_hist[MPB_NCLS];
+    __shared__ int s_hist[MPB_SKEYS];
+    const int nb = len ? MPB_LEN_BINS : 1;          // length bins of the sort key (one fixed length: one bin)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     {
         const bool amb = tid == 0 || tid == 255;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         p = amb ? 0.0f : p;
         s_tab[tid] = make_float2(p, tid == 0 ? MPB_MARK_UPPER : tid == 255 ? MPB_MARK_LOWER : p * (1.0f - p));
     }
-    if (tid < MPB_NCLS) s_hist[tid] = 0;
+    for (int k = tid; k < MPB_NCLS * nb; k += 256) s_hist[k] = 0;
     __syncthreads();
 
     const int r16 = lane & 15, cl = lane >> 4;
@@ -245,18 +246,18 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                 pass_out[i] = 0;
             } else {
                 cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
-                atomicAdd(&s_hist[c], 1);
+                atomicAdd(&s_hist[c * nb + (len ? min(MPB_LEN_BINS - 1, li >> MPB_LEN_SHIFT) : 0)], 1);
             }
         }
     }
     wave_lds_fence();                             // s_row[w] is reused by the next round
     }   // rounds
     __syncthreads();
-    if (tid < MPB_NCLS) blockhist[(int64_t)tid * gridDim.x + blockIdx.x] = s_hist[tid];   // class-major
+    for (int k = tid; k < MPB_NCLS * nb; k += 256) blockhist[(int64_t)k * gridDim.x + blockIdx.x] = s_hist[k];   // key-major
 }
 
 // ------------------------------------------------------------------------------------------
-// k_scan: block c turns blockhist[c][.] into exclusive prefixes and writes count[c]
+// k_scan: block k turns blockhist[k][.] (one sort key) into exclusive prefixes and writes kcount[k]
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scan(int32_t *__restrict__ blockhist, int nblocks,
                                               MpbTables *__restrict__ tb)
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void k_scan(int32_t *__restrict__ blockhist, i
     const int seg = (nblocks + 255) / 256;
     const int b0 = tid * seg, b1 = min(nblocks, b0 + seg);
     int sum = 0;
-    int32_t *bh = blockhist + (int64_t)c * nblocks;     // this class's row (contiguous)
+    int32_t *bh = blockhist + (int64_t)c * nblocks;     // this key's row (contiguous)
     for (int b = b0; b < b1; b++) sum += bh[b];
     s_part[tid] = sum;
     __syncthreads();
@@ -283,17 +284,23 @@ __global__ __launch_bounds__(256) void k_scan(int32_t *__restrict__ blockhist, i
         bh[b] = run;
         run += h;
     }
-    if (tid == 255) tb->count[c] = s_part[255];
+    if (tid == 255) tb->kcount[c] = s_part[255];
 }
 
-__global__ void k_tables(MpbTables *__restrict__ tb, int32_t *__restrict__ ovf_count,
+__global__ void k_tables(MpbTables *__restrict__ tb, int nb, int32_t *__restrict__ ovf_count,
                          unsigned long long *__restrict__ pass_count)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int base = 0;
     for (int c = 0; c < MPB_NCLS; c++) {
         tb->perm_base[c] = base;
-        base += (tb->count[c] + 63) & ~63;
+        int cnt = 0;
+        for (int b = 0; b < nb; b++) {                   // a class's keys are consecutive, shortest reads first
+            tb->key_base[c * nb + b] = base + cnt;
+            cnt += tb->kcount[c * nb + b];
+        }
+        tb->count[c] = cnt;
+        base += (cnt + 63) & ~63;
     }
     tb->perm_base[MPB_NCLS] = base;
     int t = 0;
@@ -329,40 +336,48 @@ __global__ void k_tables_overflow(MpbTables *__restrict__ tb, const int32_t *__r
 // ------------------------------------------------------------------------------------------
 // k_scatter: stable scatter of read indices into perm[], grouped by class
 // ------------------------------------------------------------------------------------------
+// Key = (class, length bin), see MPB_SKEYS.  Position = start of the key in perm[] + reads of the key
+// in earlier blocks (the scanned histogram) + rank inside the block, taken from ballots in input
+// order: no atomics, deterministic perm.
 __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls, int64_t n,
+                                                 const int32_t *__restrict__ len, int max_len,
                                                  const int32_t *__restrict__ blockhist,
                                                  const MpbTables *__restrict__ tb,
                                                  int32_t *__restrict__ perm)
 {
-    __shared__ int s_wcnt[4][MPB_NCLS];
-    __shared__ int s_base[MPB_NCLS];              // next free offset of each class inside this block's range
+    __shared__ int s_wcnt[4][MPB_SKEYS];          // per wave and round: reads of each key
+    __shared__ int s_base[MPB_SKEYS];             // next free slot of each key for this block
+    const int nb = len ? MPB_LEN_BINS : 1;
+    const int nkeys = MPB_NCLS * nb;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    if (tid < MPB_NCLS) s_base[tid] = blockhist[(int64_t)tid * gridDim.x + blockIdx.x];
+    for (int k = tid; k < nkeys; k += 256) s_base[k] = tb->key_base[k] + blockhist[(int64_t)k * gridDim.x + blockIdx.x];
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
-        for (int k = tid; k < 4 * MPB_NCLS; k += 256) (&s_wcnt[0][0])[k] = 0;
+        for (int k = tid; k < 4 * MPB_SKEYS; k += 256) (&s_wcnt[0][0])[k] = 0;
         __syncthreads();
         const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + tid;
-        const bool valid = i < n;
-        int c = valid ? (cls[i] & 0x7f) : -1;
+        int c = i < n ? (cls[i] & 0x7f) : -1;
         if (c == MPB_CLS_SETTLED) c = -1;         // settled by the prepass: not part of any tile
+        int kk = -1;
+        if (c >= 0) kk = c * nb + (len ? min(MPB_LEN_BINS - 1, clamp_len(len[i], max_len) >> MPB_LEN_SHIFT) : 0);
         int rank = 0;
-        unsigned long long remaining = __ballot(c >= 0);
+        unsigned long long remaining = __ballot(kk >= 0);
         while (remaining) {
             const int leader = __ffsll((long long)remaining) - 1;
-            const int cc = __shfl(c, leader);
-            const unsigned long long m = __ballot(c == cc);
-            if (c == cc) rank = __popcll(m & ((1ull << lane) - 1ull));
+            const int cc = __shfl(kk, leader);
+            const unsigned long long m = __ballot(kk == cc);
+            if (kk == cc) rank = __popcll(m & ((1ull << lane) - 1ull));
             if (lane == leader) s_wcnt[w][cc] = __popcll(m);
             remaining &= ~m;
         }
         __syncthreads();
-        if (c >= 0) {
-            int off = s_base[c];
-            for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][c];
-            perm[tb->perm_base[c] + off + rank] = (int32_t)i;
+        if (kk >= 0) {
+            int off = s_base[kk];
+            for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][kk];
+            perm[off + rank] = (int32_t)i;
         }
         __syncthreads();
-        if (tid < MPB_NCLS) s_base[tid] += s_wcnt[0][tid] + s_wcnt[1][tid] + s_wcnt[2][tid] + s_wcnt[3][tid];
+        for (int k = tid; k < nkeys; k += 256)
+            s_base[k] += s_wcnt[0][k] + s_wcnt[1][k] + s_wcnt[2][k] + s_wcnt[3][k];
         __syncthreads();                          // before the next round clears s_wcnt
     }
 }
@@ -799,15 +814,16 @@ void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32
                        ws.cls, ws.blockhist, ns_out, ee_out, pass_out);
 }
 
-void mpb_launch_scan(int64_t n, const MpbWorkspace &ws, hipStream_t s)
+void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan, dim3(MPB_NCLS), dim3(256), 0, s, ws.blockhist, pre_blocks(n), ws.tables);
-    hipLaunchKernelGGL(k_tables, dim3(1), dim3(64), 0, s, ws.tables, ws.ovf_count, ws.pass_count);
+    const int nb = len ? MPB_LEN_BINS : 1;
+    hipLaunchKernelGGL(k_scan, dim3(MPB_NCLS * nb), dim3(256), 0, s, ws.blockhist, pre_blocks(n), ws.tables);
+    hipLaunchKernelGGL(k_tables, dim3(1), dim3(64), 0, s, ws.tables, nb, ws.ovf_count, ws.pass_count);
 }
 
-void mpb_launch_scatter(int64_t n, const MpbWorkspace &ws, hipStream_t s)
+void mpb_launch_scatter(int64_t n, const int32_t *len, const MpbDevParams &prm, const MpbWorkspace &ws, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scatter, dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, ws.blockhist,
+    hipLaunchKernelGGL(k_scatter, dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len, ws.blockhist,
                        ws.tables, ws.perm);
 }
 
