@@ -365,29 +365,12 @@ def parse_fasta_and_qual(ff, fq, rf=None, rq=None):
 
 
 # ---------------------------------------------------------------------------------------------
-# host-side error calculators that are NOT the accelerated path (ref: moira/moira.py:1637-1733)
+# the bootstrap calculator stays a host loop: deprecated in the reference and random by construction
+# (ref: moira/moira.py:1682-1733)
 # ---------------------------------------------------------------------------------------------
 def interpolate(e1, p1, e2, p2, alpha):
     r = e1 + ((e2 - e1) * ((1 - alpha) - p1) / (p2 - p1))
     return 0 if r < 0 else r
-
-
-def calculate_errors_poisson(sequence, quals, alpha):
-    lam, ns = 0, 0
-    for base, q in zip(sequence, quals):
-        if q < 0:
-            raise ValueError("Qualities must have positive values.")
-        if base == "N":
-            ns += 1
-        else:
-            lam += 10 ** (q / -10.0)
-    acc, j = [0], 0
-    while True:
-        acc.append(acc[-1] + (math.exp(-lam) * (lam ** j)) / math.factorial(j))
-        if acc[-1] > (1 - alpha):
-            break
-        j += 1
-    return interpolate(j - 1, acc[-2], j, acc[-1], alpha), ns
 
 
 def calculate_errors_bootstrap(sequence, quals, alpha, bootstrap):
@@ -475,14 +458,13 @@ def process_chunk(records, args, backend):
             ee = [float(x) for x in ee]
         elif args.error_calc == "poisson" and "poisson" in getattr(backend, "methods", ()):
             ee = [float(x) for x in backend(seqs, quals, args.alpha, args.ambigs, args.round, method="poisson")]
+        elif args.error_calc == "poisson":
+            raise RuntimeError("this backend has no Poisson method (the HIP library provides it; there is no CPU path)")
         else:
             ee = []
             for s, ql in zip(seqs, quals):
                 ql = ql.ints() if isinstance(ql, QualStr) else ql
-                if args.error_calc == "poisson":
-                    e, ns = calculate_errors_poisson(s, ql, args.alpha)
-                else:
-                    e, ns = calculate_errors_bootstrap(s, ql, args.alpha, args.bootstrap)
+                e, ns = calculate_errors_bootstrap(s, ql, args.alpha, args.bootstrap)
                 if args.ambigs == "treat_as_errors":
                     e = e + ns
                 if args.round:

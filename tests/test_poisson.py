@@ -7,7 +7,7 @@ import pytest
 
 import golden_io as G
 from moira_amd import _lib as L
-from moira_amd.cli import calculate_errors_poisson
+from poisson_ref import calculate_errors_poisson          # oracle/: the reference's formula restated
 
 
 def finish(lams, ns, lens, **kw):
