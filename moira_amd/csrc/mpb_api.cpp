@@ -59,6 +59,9 @@ struct mpb_ctx {
     int64_t one_cap = 0;
     void *stage_dev = nullptr;
     int64_t stage_cap = 0;
+    // pinned host scratch of the small-batch path (inputs and outputs of one call, back to back)
+    void *pin_host = nullptr;
+    int64_t pin_cap = 0;
 };
 
 extern "C" {
@@ -134,6 +137,7 @@ int mpb_destroy(mpb_ctx *c)
     if (c->ws_small) (void)hipFree(c->ws_small);
     if (c->one_dev) (void)hipFree(c->one_dev);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
+    if (c->pin_host) (void)hipHostFree(c->pin_host);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -494,6 +498,59 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
     return MPB_OK;
 }
 
+// Batches of at most MPB_SMALL_N reads: one host-to-device copy from pinned memory, one kernel (one read
+// per wave), one copy back -- the batched pipeline's ten launches and six copies cost ~160 us whatever
+// the size, which is all a per-read caller (bernoulli.calculate_errors_PB) would ever see.
+#define MPB_SMALL_N 2048
+
+static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
+                             int32_t fixed_len, const mpb_filter_params *params, double *ee, int32_t *ns,
+                             uint8_t *pass, mpb_filter_counts *counts, bool *done)
+{
+    *done = false;
+    const int32_t max_len = len ? (int32_t)(row_stride < MPB_MAX_LEN ? row_stride : MPB_MAX_LEN) : fixed_len;
+    const int64_t b_q = align_up(n * row_stride, 256), b_len = align_up(n * 4, 256);
+    const int64_t b_ee = align_up(n * 8, 256), b_ns = align_up(n * 4, 256), b_pass = align_up(n, 256);
+    const int64_t in_bytes = b_q + b_len, out_bytes = b_ee + b_ns + b_pass;
+    int rc = ensure_stage(c, in_bytes + out_bytes);
+    if (rc) return rc;
+    rc = ensure_workspace(c, n);
+    if (rc) return rc;
+    if (in_bytes + out_bytes > c->pin_cap) {
+        if (c->pin_host) { HIPCHK(hipHostFree(c->pin_host)); c->pin_host = nullptr; c->pin_cap = 0; }
+        const int64_t cap = 2 * (in_bytes + out_bytes);
+        HIPCHK(hipHostMalloc(&c->pin_host, (size_t)cap, hipHostMallocDefault));
+        c->pin_cap = cap;
+    }
+    char *h = (char *)c->pin_host, *d = (char *)c->stage_dev;
+    memcpy(h, q, (size_t)(n * row_stride));
+    if (len) memcpy(h + b_q, len, (size_t)(n * 4));
+    uint8_t *d_q = (uint8_t *)d;
+    int32_t *d_len = (int32_t *)(d + b_q);
+    double *d_ee = (double *)(d + in_bytes);
+    int32_t *d_ns = (int32_t *)(d + in_bytes + b_ee);
+    uint8_t *d_pass = (uint8_t *)(d + in_bytes + b_ee + b_ns);
+    HIPCHK(hipMemcpyAsync(d, h, (size_t)(len ? in_bytes : n * row_stride), hipMemcpyHostToDevice, c->stream));
+    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
+    { Span t(c, MPB_K_DP); mpb_launch_small(d_q, n, row_stride, len ? d_len : nullptr, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
+    HIPCHK(hipGetLastError());
+    char *ho = h + in_bytes;
+    HIPCHK(hipMemcpyAsync(ho, d + in_bytes, (size_t)out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint8_t *hp = (const uint8_t *)(ho + b_ee + b_ns);
+    int64_t np = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (hp[i] == 2) return MPB_OK;                     // budget missed: the caller takes the batched path
+        np += hp[i];
+    }
+    memcpy(ee, ho, (size_t)(n * 8));
+    memcpy(ns, ho + b_ee, (size_t)(n * 4));
+    memcpy(pass, hp, (size_t)n);
+    if (counts) { counts->n_reads = n; counts->n_pass = np; counts->n_fail = n - np; counts->n_overflow = 0; }
+    *done = true;
+    return MPB_OK;
+}
+
 int mpb_filter_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
                     int32_t fixed_len, const mpb_filter_params *params, double *ee, int32_t *ns,
                     uint8_t *pass, mpb_filter_counts *counts)
@@ -504,6 +561,12 @@ int mpb_filter_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride,
     if (n < 0) return fail(MPB_E_INVALID, "n < 0");
     if (row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "row_stride must be a positive multiple of 16");
     if (n > 0 && (!q || !ee || !ns || !pass)) return fail(MPB_E_INVALID, "NULL host buffer");
+    if (n > 0 && n <= MPB_SMALL_N && !(params->flags & MPB_FLAG_BATCHED_ONLY) && row_stride <= MPB_MAX_LEN + 1 &&
+        (len || (fixed_len >= 0 && fixed_len <= row_stride && fixed_len <= MPB_MAX_LEN))) {
+        bool done = false;
+        rc = filter_host_small(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts, &done);
+        if (rc || done) return rc;
+    }
     mpb_filter_counts total = {n, 0, 0, 0};
     // chunk so that the staging area stays bounded (<= ~1 GiB of qualities per chunk)
     int64_t chunk = (int64_t)(1ll << 30) / row_stride;

@@ -613,9 +613,11 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
         writer = valid && (mine || never_crossed);
     }
     if (writer) {
-        if (never_crossed && !A.final_pass) {
+        if (never_crossed && A.final_pass == 0) {
             const int pos = atomicAdd(A.ovf_count, 1);
             A.ovf_list[pos] = idx;
+        } else if (never_crossed && A.final_pass == 2) {
+            A.pass[idx] = 2;                                   // small-batch path: the host re-runs the batch
         } else {
             double e;
             if (never_crossed) {
@@ -676,6 +678,88 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(const DpArgs *_
             default: break;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_small: prediction + DP of ONE read per wave, one launch for the whole (small) batch.
+// The batched pipeline costs ten launches and a sort whatever the batch size; a caller that hands
+// over one read at a time (bernoulli.calculate_errors_PB from an unchanged moira.py) pays only
+// latency.  Same prediction formula, same class bodies, same results; a read whose CDF does not
+// cross inside its class is marked pass = 2 and the host sends the batch down the batched path.
+// ------------------------------------------------------------------------------------------
+template <bool FMA>
+__global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args, const double2 *__restrict__ lut_g,
+                                                                    int64_t n, int32_t *__restrict__ ns_out,
+                                                                    uint8_t *__restrict__ cls_out,
+                                                                    int32_t *__restrict__ ident)
+{
+    __shared__ float2 s_tab[256];
+    __shared__ DpArgs s_args;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    mpb_s_lut[tid] = lut_g[tid];
+    {
+        const bool amb = tid == 0 || tid == 255;
+        float p = __builtin_amdgcn_exp2f(-0.33219281f * (float)tid);      // 10^(-q/10)
+        p = amb ? 0.0f : p;
+        s_tab[tid] = make_float2(p, tid == 0 ? MPB_MARK_UPPER : tid == 255 ? MPB_MARK_LOWER : p * (1.0f - p));
+    }
+    if (tid == 0) s_args = args;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= n) return;                                   // wave-uniform; no barrier below
+    const MpbDevParams &prm = args.prm;
+    const int li = args.len ? clamp_len(args.len[i], prm.max_len) : prm.fixed_len;
+    // lane k takes the 16-byte chunk k of the row (stride <= 1024: at most 64 chunks)
+    f32x2 a01 = {0.f, 0.f};
+    float s3 = 0.f;
+    const int nv = li - lane * 16;
+    if (nv > 0) {
+        uint4 y = *reinterpret_cast<const uint4 *>(args.q + i * args.stride + lane * 16);
+        y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
+        y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
+        pre_chunk(s_tab, y, a01, s3);
+    }
+    const float n255 = floorf(a01.y * (1.0f / MPB_MARK_LOWER));
+    const float rem = a01.y - MPB_MARK_LOWER * n255;
+    const float nzero_f = floorf(rem * (1.0f / MPB_MARK_UPPER));
+    float mu = a01.x, var = rem - MPB_MARK_UPPER * nzero_f;
+    float k3 = var - 2.0f * s3, amb = nzero_f + 1024.0f * n255;
+#pragma unroll
+    for (int off = 1; off <= 32; off <<= 1) {
+        mu += __shfl_xor(mu, off);
+        var += __shfl_xor(var, off);
+        k3 += __shfl_xor(k3, off);
+        amb += __shfl_xor(amb, off);
+    }
+    const int ambi = (int)amb;
+    const int nzero = ambi & 1023, n_lower = ambi >> 10;
+    const float v = fmaxf(var, 1e-12f);
+    const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;           // as k_prepass
+    int rows = (int)floorf(x + 0.5f) + 1;
+    if (prm.flags & 4u) rows = rows / 2;                                  // MPB_FLAG_TEST_UNDERPREDICT
+    rows = max(min(rows, li - nzero - n_lower + 1), 1);
+    const int c = c_class_of_rows.t[min(rows, MPB_MAX_LEN + 1)];
+    bool settled = false;
+    if (prm.flags & 8u) {                                                 // MPB_FLAG_DECISION_ONLY, as k_prepass
+        const float t = mu * (1.0f - 1e-4f) - prm.clow * sqrtf(mu) - 0.02f;
+        const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
+        settled = mu > 1.0f && (double)floorf(t) > limit;
+    }
+    if (lane == 0) {
+        ns_out[i] = nzero + n_lower;
+        cls_out[i] = (uint8_t)((settled ? MPB_CLS_SETTLED : c) | (nzero > 0 ? 0x80 : 0));
+        ident[i] = (int32_t)i;
+        if (settled) { args.ee[i] = __builtin_nan(""); args.pass[i] = 0; }
+    }
+    if (settled) return;
+    __threadfence();                                      // the class body reads ns / cls / ident back
+    const int32_t *pc = ident + i;
+    switch (c) {
+#define MPB_CASE(ID, RR, GG) case ID: dp_tiles<RR, GG, FMA>(&s_args, pc, 1, 0, 1); break;
+        MPB_CLASSES(MPB_CASE)
+#undef MPB_CASE
+    default: break;
     }
 }
 
@@ -913,4 +997,16 @@ void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, 
     const int64_t blocks = (chunks + 255) / 256;
     hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len,
                        min_len, max_len, len, seed, first_read);
+}
+
+// Small batches: one launch, one read per wave (k_small).  Overflow is reported through pass == 2.
+void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
+                      const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s)
+{
+    DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 2);
+    const int blocks = (int)((n + 3) / 4);
+    if (prm.flags & 2u)
+        hipLaunchKernelGGL((k_small<true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm);
+    else
+        hipLaunchKernelGGL((k_small<false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm);
 }

@@ -60,6 +60,8 @@ class FilterResult:
 class Engine:
     """One context on one MI355X (one per process/rank; not thread-safe)."""
 
+    batched_only = False      # True: never take the one-read-per-wave path for small batches (tests, diagnostics)
+
     def __init__(self, device=0):
         self.lib = L.load()
         ctx = C.c_void_p()
@@ -85,14 +87,16 @@ class Engine:
         self.close()
 
     # ---- parameters -------------------------------------------------------------------------
-    @staticmethod
-    def params(alpha=0.005, uncert=0.01, maxerrors=None, ambigs="treat_as_errors", round_=False,
-               fast_fma=False, test_underpredict=False, decision_only=False):
+    def params(self=None, alpha=0.005, uncert=0.01, maxerrors=None, ambigs="treat_as_errors", round_=False,
+               fast_fma=False, test_underpredict=False, decision_only=False, batched_only=None):
         if ambigs not in L.AMBIG:
             raise ValueError("ambigs must be one of %s" % sorted(L.AMBIG))
         flags = (L.FLAG_ROUND if round_ else 0) | (L.FLAG_FAST_FMA if fast_fma else 0) | \
                 (L.FLAG_TEST_UNDERPREDICT if test_underpredict else 0) | \
                 (L.FLAG_DECISION_ONLY if decision_only else 0)
+        if batched_only is None:
+            batched_only = bool(getattr(self, "batched_only", False))
+        flags |= L.FLAG_BATCHED_ONLY if batched_only else 0
         return L.FilterParams(float(alpha), float(uncert),
                               math.nan if maxerrors is None else float(maxerrors),
                               L.AMBIG[ambigs], flags)
