@@ -63,6 +63,7 @@ with Engine(0) as eng:
             extra["test_underpredict"] = True
         if rng.random() < 0.15:
             extra["decision_only"] = True
+        eng.batched_only = bool(rng.random() < 0.5)                  # small batches: pipeline or one-read-per-wave path
         ee, ns, ps, rows = O.filter_batch(q, lens=lens, threads=threads, **kw)
         r = eng.filter(q, lens=None if fixed else lens, fixed_len=int(lens[0]) if fixed else None, **kw, **extra)
         ok = np.array_equal(r.ns, ns) and np.array_equal(r.passed, ps.astype(bool))
@@ -74,7 +75,7 @@ with Engine(0) as eng:
         if not ok:
             bad += 1
             d = np.nonzero(~((r.ee == ee) | (np.isnan(r.ee) & np.isnan(ee))))[0]
-            print("MISMATCH round %d: n=%d stride=%d fixed=%s kind=%d kw=%s extra=%s first diffs %s rows %s"
-                  % (it, n, stride, fixed, kind, kw, extra, d[:5], rows[d[:5]]), flush=True)
+            print("MISMATCH round %d: n=%d stride=%d fixed=%s kind=%d kw=%s extra=%s batched_only=%s first diffs %s rows %s"
+                  % (it, n, stride, fixed, kind, kw, extra, eng.batched_only, d[:5], rows[d[:5]]), flush=True)
 print("fuzz: %d rounds, %d mismatching rounds, %.1f s (oracle threads %d)" % (rounds, bad, time.time() - t0, threads))
 sys.exit(1 if bad else 0)
