@@ -30,12 +30,18 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    """gpurun merges every call's files into the same tree: take the most recent run's."""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
 out = {}
 for sub in ("fetch", "write", "tccrd", "tccwr", "sq"):
-    files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     if not files:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
