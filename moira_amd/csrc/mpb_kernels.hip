@@ -123,8 +123,9 @@ __device__ __forceinline__ void pre_chunk(const float2 *tab, const uint4 x, f32x
         }
 }
 
+template <bool RAGGED>     // RAGGED <=> len != nullptr; the fixed-length instance has one length bin and no len loads
 __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, int64_t n,
-                                                 int64_t stride, const int32_t *__restrict__ len,
+                                                 int64_t stride, const int32_t *__restrict__ len_arg,
                                                  MpbDevParams prm, uint8_t *__restrict__ cls,
                                                  int32_t *__restrict__ blockhist,
                                                  int32_t *__restrict__ ns_out,
@@ -133,8 +134,9 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
 {
     __shared__ float2 s_tab[256];
     __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts}
-    __shared__ int s_hist[MPB_SKEYS];
-    const int nb = len ? MPB_LEN_BINS : 1;          // length bins of the sort key (one fixed length: one bin)
+    __shared__ int s_hist[RAGGED ? MPB_SKEYS : MPB_NCLS];
+    const int32_t *__restrict__ len = RAGGED ? len_arg : nullptr;
+    constexpr int nb = RAGGED ? MPB_LEN_BINS : 1;   // length bins of the sort key (one fixed length: one bin)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     {
         const bool amb = tid == 0 || tid == 255;
@@ -339,20 +341,22 @@ __global__ void k_tables_overflow(MpbTables *__restrict__ tb, const int32_t *__r
 // Key = (class, length bin), see MPB_SKEYS.  Position = start of the key in perm[] + reads of the key
 // in earlier blocks (the scanned histogram) + rank inside the block, taken from ballots in input
 // order: no atomics, deterministic perm.
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls, int64_t n,
-                                                 const int32_t *__restrict__ len, int max_len,
+                                                 const int32_t *__restrict__ len_arg, int max_len,
                                                  const int32_t *__restrict__ blockhist,
                                                  const MpbTables *__restrict__ tb,
                                                  int32_t *__restrict__ perm)
 {
-    __shared__ int s_wcnt[4][MPB_SKEYS];          // per wave and round: reads of each key
-    __shared__ int s_base[MPB_SKEYS];             // next free slot of each key for this block
-    const int nb = len ? MPB_LEN_BINS : 1;
-    const int nkeys = MPB_NCLS * nb;
+    constexpr int nb = RAGGED ? MPB_LEN_BINS : 1;
+    constexpr int nkeys = MPB_NCLS * nb;
+    __shared__ int s_wcnt[4][nkeys];              // per wave and round: reads of each key
+    __shared__ int s_base[nkeys];                 // next free slot of each key for this block
+    const int32_t *__restrict__ len = RAGGED ? len_arg : nullptr;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     for (int k = tid; k < nkeys; k += 256) s_base[k] = tb->key_base[k] + blockhist[(int64_t)k * gridDim.x + blockIdx.x];
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
-        for (int k = tid; k < 4 * MPB_SKEYS; k += 256) (&s_wcnt[0][0])[k] = 0;
+        for (int k = tid; k < 4 * nkeys; k += 256) (&s_wcnt[0][0])[k] = 0;
         __syncthreads();
         const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + tid;
         int c = i < n ? (cls[i] & 0x7f) : -1;
@@ -894,8 +898,12 @@ void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
                         double *ee_out, uint8_t *pass_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_prepass, dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm,
-                       ws.cls, ws.blockhist, ns_out, ee_out, pass_out);
+    if (len)
+        hipLaunchKernelGGL((k_prepass<true>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm,
+                           ws.cls, ws.blockhist, ns_out, ee_out, pass_out);
+    else
+        hipLaunchKernelGGL((k_prepass<false>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm,
+                           ws.cls, ws.blockhist, ns_out, ee_out, pass_out);
 }
 
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s)
@@ -907,8 +915,12 @@ void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipS
 
 void mpb_launch_scatter(int64_t n, const int32_t *len, const MpbDevParams &prm, const MpbWorkspace &ws, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scatter, dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len, ws.blockhist,
-                       ws.tables, ws.perm);
+    if (len)
+        hipLaunchKernelGGL((k_scatter<true>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len,
+                           ws.blockhist, ws.tables, ws.perm);
+    else
+        hipLaunchKernelGGL((k_scatter<false>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len,
+                           ws.blockhist, ws.tables, ws.perm);
 }
 
 // cap of the DP grid (blocks of 4 waves); beyond it the chunk loop strides
