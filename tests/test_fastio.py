@@ -355,3 +355,56 @@ def test_paired_errors_are_the_line_parsers(tmp_path, oracle):
                              reverse_fastq=str(tmp_path / "r.fastq")), backend=matrix_backend(oracle),
                     out=open(os.devnull, "w")) == 0
     assert open(str(tmp_path / "o") + ".contigs.report").read().count("\n") == 3     # header + 2 pairs
+
+
+def test_random_text_noise_fast_equals_line_path(tmp_path, oracle):
+    """Randomly mangled FASTQ text (blank lines, stray whitespace, CRLF, '@'/'+' in odd places, Q0 bases,
+    truncated tails, headers made of marks only): both paths must write the same files or raise the
+    same exception."""
+    backend = matrix_backend(oracle)
+    rng = np.random.default_rng(2024)
+    ws = [" ", "\t", " \t ", "\x0b", "\x0c", "\x1c", ""]
+    outcomes = {"same_files": 0, "same_error": 0}
+    for trial in range(60):
+        lines = []
+        for i in range(int(rng.integers(1, 30))):
+            L = int(rng.integers(1, 70))
+            seq = "".join(rng.choice(list("ACGTNn"), L, p=[.23, .23, .23, .23, .05, .03]))
+            qual = "".join(chr(33 + int(x)) for x in rng.integers(0, 42, L))
+            hdr = str(rng.choice(["@r%d" % i, "@@r:%d x" % i, "@", "@@@", "r%d" % i, "@a:b:c\td", "  @sp%d  " % i]))
+            rec = [hdr, seq, str(rng.choice(["+", "+" + hdr[1:], "+ junk"])), qual]
+            r = rng.random()
+            if r < 0.04:
+                rec[1] = ""                          # empty sequence line
+            elif r < 0.08:
+                rec[3] = ""                          # empty quality line
+            elif r < 0.12:
+                rec[3] = rec[3][:-1]                 # length mismatch
+            elif r < 0.16:
+                rec.insert(int(rng.integers(0, 4)), "")      # a blank line shifts the 4-line framing
+            lines += rec
+        eol = str(rng.choice(["\n", "\r\n"]))
+        text = "".join(str(rng.choice(ws)) + ln + str(rng.choice(ws)) + eol for ln in lines)
+        if rng.random() < 0.3:
+            text = text.rstrip("\r\n")
+        if rng.random() < 0.2:
+            text = text[:int(len(text) * rng.random())]     # cut anywhere
+        src = tmp_path / ("t%d.fastq" % trial)
+        src.write_bytes(text.encode())
+        kw = dict(collapse=bool(trial % 2), output_format="fastq" if trial % 3 == 0 else "fasta")
+        res = []
+        for mode in ("fast", "slow"):
+            if mode == "slow":
+                os.environ["MOIRA_NO_FASTIO"] = "1"
+            try:
+                try:
+                    rc = cli.main(args_for(str(src), str(tmp_path / ("%s%d" % (mode, trial))), **kw), backend=backend,
+                                  out=open(os.devnull, "w"))
+                    res.append(("ok", rc, outputs_of(str(tmp_path / ("%s%d" % (mode, trial))))))
+                except (cli.EmptySeqError, cli.EmptyQualError, cli.LengthMismatchError, ValueError) as e:
+                    res.append(("err", type(e).__name__, str(e)))
+            finally:
+                os.environ.pop("MOIRA_NO_FASTIO", None)
+        assert res[0] == res[1], (trial, text[:300], res[0][:2], res[1][:2])
+        outcomes["same_files" if res[0][0] == "ok" else "same_error"] += 1
+    assert outcomes["same_files"] >= 10 and outcomes["same_error"] >= 10, outcomes
