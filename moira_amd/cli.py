@@ -669,6 +669,55 @@ def _fast_chunks(args):
         rfh.close()
 
 
+def _prefetched(gen, depth=2):
+    """Run a generator in a background thread, `depth` items ahead.  The chunk producers spend their time
+    in C calls that release the GIL (decompression, indexing, contig construction), so reading chunk
+    k+1 overlaps packing, filtering and writing chunk k.  Exceptions travel with the items."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    stop = threading.Event()
+    END = object()
+
+    def work():
+        try:
+            for item in gen:
+                while not stop.is_set():
+                    try:
+                        q.put((item, None), timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+                if stop.is_set():
+                    break
+            else:
+                q.put((END, None))
+                return
+        except BaseException as e:          # noqa: B902 -- re-raised in the consumer
+            q.put((END, e))
+            return
+        finally:
+            gen.close()
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    try:
+        while True:
+            item, err = q.get()
+            if err is not None:
+                raise err
+            if item is END:
+                return
+            yield item
+    finally:
+        stop.set()
+        while t.is_alive():                  # drain so that a producer blocked on put() can finish
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                t.join(0.05)
+
+
 def _run_fast_fastq(args, backend, o, say, t0):
     """Chunks of the input as (buffer, record index); contig construction, packing, collapse and record
     formatting in C (moira_amd/fastio.py, moira_amd/contig.py).  Decisions are write_results'
@@ -707,7 +756,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
     disc_err = disc_len = disc_ov = 0.0
     groups = F.Collapse() if args.collapse else None
     try:
-        for buf, idx, aux in _fast_chunks(args):
+        for buf, idx, aux in _prefetched(_fast_chunks(args)):
             n = len(idx)
             lens = np.minimum(idx[:, F.SEQ_LEN], T) if T else idx[:, F.SEQ_LEN].copy()
             strides = bucket_of(lens, 64)
