@@ -35,6 +35,7 @@ def load():
         L.mct_reverse_complement.argtypes = [C.c_char_p, vp, i32, vp, vp]
         L.mct_nw_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, vp, vp, vp, vp]
         L.mct_nw_align_scalar.argtypes = L.mct_nw_align.argtypes
+        L.mct_contigs_from_fastq.argtypes = [C.c_int64, vp, vp, vp, vp] + [i32] * 10 + [C.c_int64, vp, vp, vp, vp, vp]
         L.mct_make_contig.argtypes = [C.c_char_p, vp, C.c_char_p, vp, i32, i32, i32, i32, i32, i32,
                                       vp, vp, vp, vp, vp, vp]
         L.mct_contigs_batch.argtypes = [C.c_int64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
@@ -148,10 +149,6 @@ def contigs_from_fastq(fbuf, fidx, rbuf, ridx, fastq_offset=33, match=1, mismatc
     moira_amd.fastio).  Returns (cbuf uint8[n * rec_cap], cidx int64[n, 6], aux int32[n, 3]): contigs as a
     buffer + record index again (qualities as bytes q + offset), aux = overlap length, gaps, mismatches."""
     L = load()
-    if not hasattr(L.mct_contigs_from_fastq, "_ready"):
-        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
-        L.mct_contigs_from_fastq.argtypes = [i64, vp, vp, vp, vp] + [i32] * 10 + [i64, vp, vp, vp, vp, vp]
-        L.mct_contigs_from_fastq._ready = True
     if consensus_qscore not in CONSENSUS:
         raise ValueError('consensus_qscore must be "best", "sum" or "posterior".')
     fidx, ridx = np.ascontiguousarray(fidx), np.ascontiguousarray(ridx)

@@ -87,16 +87,15 @@ class Engine:
         self.close()
 
     # ---- parameters -------------------------------------------------------------------------
-    def params(self=None, alpha=0.005, uncert=0.01, maxerrors=None, ambigs="treat_as_errors", round_=False,
-               fast_fma=False, test_underpredict=False, decision_only=False, batched_only=None):
+    @staticmethod
+    def params(alpha=0.005, uncert=0.01, maxerrors=None, ambigs="treat_as_errors", round_=False,
+               fast_fma=False, test_underpredict=False, decision_only=False, batched_only=False):
         if ambigs not in L.AMBIG:
             raise ValueError("ambigs must be one of %s" % sorted(L.AMBIG))
         flags = (L.FLAG_ROUND if round_ else 0) | (L.FLAG_FAST_FMA if fast_fma else 0) | \
                 (L.FLAG_TEST_UNDERPREDICT if test_underpredict else 0) | \
-                (L.FLAG_DECISION_ONLY if decision_only else 0)
-        if batched_only is None:
-            batched_only = bool(getattr(self, "batched_only", False))
-        flags |= L.FLAG_BATCHED_ONLY if batched_only else 0
+                (L.FLAG_DECISION_ONLY if decision_only else 0) | \
+                (L.FLAG_BATCHED_ONLY if batched_only else 0)
         return L.FilterParams(float(alpha), float(uncert),
                               math.nan if maxerrors is None else float(maxerrors),
                               L.AMBIG[ambigs], flags)
@@ -174,6 +173,7 @@ class Engine:
 
     def filter(self, q, lens=None, fixed_len=None, **kw):
         """Filter a packed host matrix q (n x stride uint8).  Returns FilterResult."""
+        kw.setdefault("batched_only", self.batched_only)
         params = kw.pop("params", None) or self.params(**kw)
         q = np.ascontiguousarray(q, dtype=np.uint8)
         if q.ndim != 2:
