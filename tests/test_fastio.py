@@ -408,3 +408,31 @@ def test_random_text_noise_fast_equals_line_path(tmp_path, oracle):
         assert res[0] == res[1], (trial, text[:300], res[0][:2], res[1][:2])
         outcomes["same_files" if res[0][0] == "ok" else "same_error"] += 1
     assert outcomes["same_files"] >= 10 and outcomes["same_error"] >= 10, outcomes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(collapse=True), dict(error_calc="poisson"), dict(fast_discard=True),
+                                dict(paired=True, collapse=True, min_overlap=30)])
+def test_byte_level_path_equals_line_path_on_the_gpu(tmp_path, kw):
+    """Product path (HIP library, no injected backend): both CLI paths write the same files."""
+    rng = np.random.default_rng(77)
+    kw = dict(kw)
+    if kw.get("paired"):
+        f_text, r_text = make_pairs(rng, 3000)
+        (tmp_path / "r.fastq").write_bytes(r_text.encode())
+        kw["reverse_fastq"] = str(tmp_path / "r.fastq")
+    else:
+        f_text = make_fastq(rng, 6000, quirks=True, lo=30, hi=320)
+    (tmp_path / "f.fastq").write_bytes(f_text.encode())
+    src = str(tmp_path / "f.fastq")
+    assert cli.main(args_for(src, str(tmp_path / "fast"), processors=4, **kw), out=open(os.devnull, "w")) == 0
+    os.environ["MOIRA_NO_FASTIO"] = "1"
+    try:
+        assert cli.main(args_for(src, str(tmp_path / "slow"), processors=4, **kw), out=open(os.devnull, "w")) == 0
+    finally:
+        del os.environ["MOIRA_NO_FASTIO"]
+    fast, slow = outputs_of(str(tmp_path / "fast")), outputs_of(str(tmp_path / "slow"))
+    assert fast.keys() == slow.keys()
+    for k in fast:
+        assert fast[k] == slow[k], k
+    assert sum(len(v) for v in fast.values()) > 100000
