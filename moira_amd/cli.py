@@ -718,6 +718,42 @@ def _prefetched(gen, depth=2):
                 t.join(0.05)
 
 
+class _InOrder:
+    """Calls run one after the other in a background thread (formatting + writing chunk k while chunk
+    k+1 is packed and filtered; the C formatters and file writes release the GIL).  An exception of a
+    call is raised by the next submit() or by close()."""
+
+    def __init__(self, depth=2):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=depth)
+        self.err = None
+        self.t = threading.Thread(target=self._work, daemon=True)
+        self.t.start()
+
+    def _work(self):
+        while True:
+            fn = self.q.get()
+            if fn is None:
+                return
+            if self.err is None:
+                try:
+                    fn()
+                except BaseException as e:      # noqa: B902 -- re-raised in the submitting thread
+                    self.err = e
+
+    def submit(self, fn):
+        if self.err is not None:
+            raise self.err
+        self.q.put(fn)
+
+    def close(self, raise_errors=True):
+        self.q.put(None)
+        self.t.join()
+        if raise_errors and self.err is not None:
+            raise self.err
+
+
 def _run_fast_fastq(args, backend, o, say, t0):
     """Chunks of the input as (buffer, record index); contig construction, packing, collapse and record
     formatting in C (moira_amd/fastio.py, moira_amd/contig.py).  Decisions are write_results'
@@ -755,6 +791,8 @@ def _run_fast_fastq(args, backend, o, say, t0):
     processed = 0
     disc_err = disc_len = disc_ov = 0.0
     groups = F.Collapse() if args.collapse else None
+    emit = _InOrder()
+    ok = False
     try:
         for buf, idx, aux in _prefetched(_fast_chunks(args)):
             n = len(idx)
@@ -772,32 +810,37 @@ def _run_fast_fastq(args, backend, o, say, t0):
             if nan.any():
                 raise ReturnedNaNError(F.header_of(buf, idx[int(np.argmax(nan))]))
             if args.collapse:
-                groups.add(buf, idx, ee, has_n, T, aux)
+                emit.submit(lambda buf=buf, idx=idx, ee=ee, has_n=has_n, aux=aux: groups.add(buf, idx, ee, has_n, T, aux))
             else:
                 label = decide(ee, lens, has_n, aux[:, 0] if aux is not None else None)
                 disc_len += int((label == 0).sum())
                 disc_ov += int((label == 3).sum())
                 disc_err += int(((label == 1) | (label == 2)).sum())
-                hdr = dict(relabel=args.relabel or None)
-                if args.paired:
-                    everything = np.arange(n)
-                    o.report.write(F.format_report(buf, idx, everything, aux, relabel_index=processed + everything,
-                                                   ee=ee if usearch else None, **hdr))
-                good, bad = np.nonzero(label < 0)[0], np.nonzero(label >= 0)[0]
-                for sel, main_f, qual_f, lab in ((good, o.contig, o.qual, None), (bad, o.bad_contig, o.bad_qual, label)):
-                    if not len(sel):
-                        continue
-                    kw = dict(fastq_offset=args.fastq_offset, max_len=T, relabel_index=processed + sel,
-                              ee=ee[sel] if usearch else None, labels=labels if lab is not None else None,
-                              label_id=lab[sel] if lab is not None else None, **hdr)
-                    if fq:
-                        main_f.write(F.format_records(buf, idx, sel, F.FMT_FASTQ, **kw))
-                    else:
-                        main_f.write(F.format_records(buf, idx, sel, F.FMT_FASTA, **kw))
-                        qual_f.write(F.format_records(buf, idx, sel, F.FMT_QUAL, **kw))
+
+                def write_chunk(buf=buf, idx=idx, aux=aux, ee=ee, label=label, first=processed, n=n):
+                    hdr = dict(relabel=args.relabel or None)
+                    if args.paired:
+                        everything = np.arange(n)
+                        o.report.write(F.format_report(buf, idx, everything, aux, relabel_index=first + everything,
+                                                       ee=ee if usearch else None, **hdr))
+                    good, bad = np.nonzero(label < 0)[0], np.nonzero(label >= 0)[0]
+                    for sel, main_f, qual_f, lab in ((good, o.contig, o.qual, None), (bad, o.bad_contig, o.bad_qual, label)):
+                        if not len(sel):
+                            continue
+                        kw = dict(fastq_offset=args.fastq_offset, max_len=T, relabel_index=first + sel,
+                                  ee=ee[sel] if usearch else None, labels=labels if lab is not None else None,
+                                  label_id=lab[sel] if lab is not None else None, **hdr)
+                        if fq:
+                            main_f.write(F.format_records(buf, idx, sel, F.FMT_FASTQ, **kw))
+                        else:
+                            main_f.write(F.format_records(buf, idx, sel, F.FMT_FASTA, **kw))
+                            qual_f.write(F.format_records(buf, idx, sel, F.FMT_QUAL, **kw))
+                emit.submit(write_chunk)
             processed += n
             if not args.silent:
                 say("%d sequences processed in %.1f seconds." % (processed, time.time() - t0))
+        emit.close()
+        ok = True
         if args.collapse:
             # the groups by decreasing abundance (moira.py:490-493), then write_results' decisions per group
             gee, glen, gsize, g_n, gaux = groups.export()
@@ -824,6 +867,8 @@ def _run_fast_fastq(args, backend, o, say, t0):
                 if names:
                     names_f.write(groups.format(sel, F.FMT_NAMES, lstrip_gt=strip[sel], **hdr))
     finally:
+        if not ok:
+            emit.close(raise_errors=False)         # an exception is already on its way
         if groups is not None:
             groups.close()
     return processed, disc_err, disc_len, disc_ov
