@@ -77,6 +77,20 @@ int32_t mio_pack(const char *buf, const int64_t *idx, const int64_t *sel, int64_
                  int32_t fastq_offset, int32_t max_len, int32_t lower_n_is_base, int64_t row_stride,
                  uint8_t *out, int32_t *lens_out, uint8_t *flags_out, int64_t *bad_record);
 
+/*
+ * fasta + qual input (ref: moira/moira.py:1093-1150 parse_fasta_and_qual: one header line and ONE data
+ * line per record in each file).  Records complete in both buffers are copied into `out` as
+ * header token | sequence | one byte per quality (the integer itself, i.e. FASTQ offset 0), with their
+ * index rows in out_idx -- the same shape mio_fastq_index gives, so that everything downstream is
+ * shared.  Anything the line parser treats specially (names that differ, empty lines, unequal
+ * lengths, tokens that are not plain decimal integers 0..254 separated by single blanks, lone CR,
+ * non-ASCII) returns MIO_E_UNSUPPORTED: the caller re-runs the file with the line parser, which raises
+ * the reference's exception.  Returns the number of records; *_consumed / *out_used report progress.
+ */
+int64_t mio_fasta_qual_index(const char *fbuf, int64_t flen, const char *qbuf, int64_t qlen, int32_t final,
+                             int64_t max_records, char *out, int64_t out_cap, int64_t *out_idx,
+                             int64_t *f_consumed, int64_t *q_consumed, int64_t *out_used);
+
 /* Paired input: position of the first pair whose header tokens differ (the reference's
  * forward_header != reverse_header, ref: moira/moira.py:1197-1198), or -1. */
 int64_t mio_first_header_mismatch(const char *fbuf, const int64_t *fidx, const char *rbuf, const int64_t *ridx, int64_t n);
@@ -101,13 +115,15 @@ int32_t mio_py2_hash(const char *buf, const int64_t *idx, int64_t n, int32_t max
  *   ee          double[nsel] or NULL: when non-NULL ";ee=%.2f;size=1;" is appended to the header
  *               (USEARCH pipeline, ref: moira/moira.py:858-863)
  *   labels / label_id   label_id int32[nsel] or NULL; label_id[k] >= 0 appends "\t" + labels[label_id[k]]
+ *   out_offset  FASTQ offset of the quality string MIO_FMT_FASTQ writes (= fastq_offset for FASTQ input;
+ *               records built by mio_fasta_qual_index carry fastq_offset 0)
  *   max_len     bases written (--truncate; <= 0: all)
  *   qualities are shown after the Q0 -> 1 clamp, as the reference's writer sees them
  *   (ref: moira/moira.py:814).
  * Returns the bytes written, or MIO_E_SPACE with *needed set when cap is too small.
  */
 int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel, int32_t kind,
-                   int32_t fastq_offset, int32_t max_len, const char *relabel, const int64_t *relabel_index,
+                   int32_t fastq_offset, int32_t out_offset, int32_t max_len, const char *relabel, const int64_t *relabel_index,
                    const double *ee, const char *const *labels, const int32_t *label_id,
                    char *out, int64_t cap, int64_t *needed);
 
@@ -150,7 +166,7 @@ int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *
  * writes the mothur names line of each group; lstrip_gt uint8[nsel] (may be NULL) drops leading '>'
  * from that line's header where the reference does (ref: moira/moira.py:880,894,907,943). */
 int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t nsel, int32_t kind,
-                            int32_t fastq_offset, const char *relabel, int32_t usearch,
+                            int32_t fastq_offset, int32_t out_offset, const char *relabel, int32_t usearch,
                             const char *const *labels, const int32_t *label_id, const uint8_t *lstrip_gt,
                             char *out, int64_t cap, int64_t *needed);
 

@@ -605,7 +605,7 @@ PAIR_CHUNK_READS = 65536      # a contig slot is header + 2 x (l1 + l2) bytes
 
 
 def _fast_eligible(args, backend):
-    return bool(args.forward_fastq and not args.only_contig
+    return bool((args.forward_fastq or (args.forward_fasta and args.forward_qual)) and not args.only_contig
                 and (args.paired or not args.min_overlap)
                 and args.error_calc in ("poisson_binomial", "poisson_binomial_py", "poisson")
                 and getattr(backend, "matrix", None) is not None
@@ -634,6 +634,9 @@ def _record_error(which, e, args):
 def _fast_chunks(args):
     """(buf, idx, aux) per chunk: reads as they are in the file, or contigs built from the two files."""
     from . import fastio as F
+    if not args.forward_fastq:
+        yield from _fast_chunks_fasta_qual(args)
+        return
     if not args.paired:
         fh = open_input_binary(args.forward_fastq)
         try:
@@ -754,6 +757,39 @@ class _InOrder:
             raise self.err
 
 
+def _fast_chunks_fasta_qual(args):
+    """fasta + qual input: records rebuilt as header | sequence | quality bytes (offset 0) by
+    mio_fasta_qual_index, so that the rest of the path is the FASTQ one."""
+    from . import fastio as F
+    files = [open_input_binary(args.forward_fasta), open_input_binary(args.forward_qual)]
+    try:
+        if not args.paired:
+            for buf, idx in F.FastaQualChunks(files[0], files[1], CHUNK_READS):
+                yield buf, idx, None
+            return
+        from . import contig as CT
+        files += [open_input_binary(args.reverse_fasta), open_input_binary(args.reverse_qual)]
+        fwd = iter(F.FastaQualChunks(files[0], files[1], PAIR_CHUNK_READS))
+        rev = iter(F.FastaQualChunks(files[2], files[3], PAIR_CHUNK_READS))
+        while True:
+            a, b = next(fwd, None), next(rev, None)
+            if a is None and b is None:
+                return
+            # a file that ends early, or names that differ, are NameMismatchErrors of the line parser
+            if a is None or b is None or len(a[1]) != len(b[1]) or F.first_header_mismatch(a[0], a[1], b[0], b[1]) >= 0:
+                raise F.Unsupported("forward and reverse records do not pair up")
+            try:
+                cbuf, cidx, aux = CT.contigs_from_fastq(
+                    a[0], a[1], b[0], b[1], 0, args.match, args.mismatch, args.gap, args.insert, args.deltaq,
+                    args.consensus_qscore, args.qscore_cap, args.trim_overlap, threads=args.processors)
+            except CT.QualityRange as e:
+                raise F.Unsupported(str(e))
+            yield cbuf, cidx, aux
+    finally:
+        for f in files:
+            f.close()
+
+
 def _run_fast_fastq(args, backend, o, say, t0):
     """Chunks of the input as (buffer, record index); contig construction, packing, collapse and record
     formatting in C (moira_amd/fastio.py, moira_amd/contig.py).  Decisions are write_results'
@@ -762,6 +798,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
     from . import fastio as F
     from .buckets import bucket_of
     T = args.truncate or 0
+    in_off = args.fastq_offset if args.forward_fastq else 0      # fasta+qual records carry the integers themselves
     method = "poisson" if args.error_calc == "poisson" else "poisson_binomial"
     fd = None
     if getattr(args, "fast_discard", False) and not args.collapse and args.pipeline == "mothur" \
@@ -802,7 +839,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
             has_n = np.empty(n, bool)
             for stride in np.unique(strides):
                 sel = np.nonzero(strides == stride)[0]
-                q, ln, fl = F.pack(buf, idx, sel, args.fastq_offset, T, lower_n_is_base=(method == "poisson"),
+                q, ln, fl = F.pack(buf, idx, sel, in_off, T, lower_n_is_base=(method == "poisson"),
                                    stride=int(stride), reuse=True)
                 ee[sel] = backend.matrix(q, ln, args.alpha, args.ambigs, args.round, method=method, fast_discard=fd)
                 has_n[sel] = fl
@@ -827,7 +864,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
                     for sel, main_f, qual_f, lab in ((good, o.contig, o.qual, None), (bad, o.bad_contig, o.bad_qual, label)):
                         if not len(sel):
                             continue
-                        kw = dict(fastq_offset=args.fastq_offset, max_len=T, relabel_index=first + sel,
+                        kw = dict(fastq_offset=in_off, out_offset=args.fastq_offset, max_len=T, relabel_index=first + sel,
                                   ee=ee[sel] if usearch else None, labels=labels if lab is not None else None,
                                   label_id=lab[sel] if lab is not None else None, **hdr)
                         if fq:
@@ -849,7 +886,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
             disc_ov += int(gsize[label == 3].sum())
             disc_err += int(gsize[(label == 1) | (label == 2)].sum())
             names = args.pipeline == "mothur"
-            hdr = dict(fastq_offset=args.fastq_offset, relabel=args.relabel or None, usearch=usearch)
+            hdr = dict(fastq_offset=in_off, out_offset=args.fastq_offset, relabel=args.relabel or None, usearch=usearch)
             if args.paired:
                 o.report.write(groups.format(np.arange(len(gee)), F.FMT_REPORT, **hdr))
             # header.lstrip('>') on the names line of three kinds of bad groups (moira.py:880,894,943)

@@ -171,14 +171,23 @@ void put_quals(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset)
     }
 }
 
-void put_qual_string(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset)
+void put_qual_string(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset, int32_t out_offset)
 {
-    // chr(q + offset) of the clamped qualities = the input string with Q0 shown as Q1
+    // chr(q + offset) of the clamped qualities; with equal offsets that is the input string with Q0
+    // shown as Q1
     if (o.n + L <= o.cap) {
         char *w = o.p + o.n;
-        memcpy(w, ql, (size_t)L);
-        for (char *z = (char *)memchr(w, fastq_offset, (size_t)L); z; z = (char *)memchr(z, fastq_offset, (size_t)(w + L - z)))
-            *z++ = (char)(fastq_offset + 1);
+        if (out_offset == fastq_offset) {
+            memcpy(w, ql, (size_t)L);
+            for (char *z = (char *)memchr(w, fastq_offset, (size_t)L); z; z = (char *)memchr(z, fastq_offset, (size_t)(w + L - z)))
+                *z++ = (char)(fastq_offset + 1);
+        } else {
+            for (int64_t i = 0; i < L; i++) {
+                int q = (int)ql[i] - fastq_offset;
+                q = q <= 0 ? 1 : q;
+                w[i] = (char)(q + out_offset);
+            }
+        }
     }
     o.n += L;
 }
@@ -302,6 +311,93 @@ int32_t mio_pack(const char *buf, const int64_t *idx, const int64_t *sel, int64_
     return MIO_OK;
 }
 
+// one line of buf starting at p: [a, b) stripped; returns the position after the line, or -1 when the
+// line is not complete yet, or -2 for content the byte-level path declines
+static int64_t take_line(const char *buf, int64_t len, int64_t p, int final, Span *out)
+{
+    if (p >= len) return -1;
+    const char *nl = (const char *)memchr(buf + p, '\n', (size_t)(len - p));
+    int64_t e;
+    if (nl) e = nl - buf;
+    else if (final) e = len;
+    else return -1;
+    const char *cr = (const char *)memchr(buf + p, '\r', (size_t)(e - p));
+    if (cr && !(nl && cr == nl - 1)) return -2;
+    unsigned char any = 0;
+    for (int64_t t = p; t < e; t++) any |= (unsigned char)buf[t];
+    if (any & 0x80) return -2;
+    *out = strip(buf, p, e);
+    return nl ? e + 1 : e;
+}
+
+int64_t mio_fasta_qual_index(const char *fbuf, int64_t flen, const char *qbuf, int64_t qlen, int32_t final,
+                             int64_t max_records, char *out, int64_t out_cap, int64_t *out_idx,
+                             int64_t *f_consumed, int64_t *q_consumed, int64_t *out_used)
+{
+    if (!fbuf || !qbuf || flen < 0 || qlen < 0 || max_records < 0 || !out || !out_idx || !f_consumed || !q_consumed || !out_used)
+        return fail(MIO_E_INVALID, "mio_fasta_qual_index: bad arguments");
+    *f_consumed = *q_consumed = *out_used = 0;
+    int64_t n = 0, fp = 0, qp = 0, w = 0;
+    while (n < max_records) {
+        Span fh, fs, qh, ql;
+        int64_t a = take_line(fbuf, flen, fp, final, &fh);
+        int64_t b = a >= 0 ? take_line(fbuf, flen, a, final, &fs) : a;
+        int64_t c = take_line(qbuf, qlen, qp, final, &qh);
+        int64_t d = c >= 0 ? take_line(qbuf, qlen, c, final, &ql) : c;
+        if (a == -2 || b == -2 || c == -2 || d == -2) return fail(MIO_E_UNSUPPORTED, "lone carriage return or non-ASCII byte");
+        if (b < 0 || d < 0) {
+            // at the end of the files anything but "both exhausted" is the line parser's business
+            if (final && !(fp >= flen && qp >= qlen)) return fail(MIO_E_UNSUPPORTED, "truncated record at the end of the files");
+            break;
+        }
+        // header tokens: replace('\t',' ').split(' ')[0].lstrip('>')                 moira.py:1121-1123
+        Span tok[2];
+        const char *bufs[2] = {fbuf, qbuf};
+        const Span hd[2] = {fh, qh};
+        for (int k = 0; k < 2; k++) {
+            int64_t h0 = hd[k].off, h1 = h0;
+            const int64_t hend = hd[k].off + hd[k].len;
+            while (h1 < hend && bufs[k][h1] != ' ' && bufs[k][h1] != '\t') h1++;
+            while (h0 < h1 && bufs[k][h0] == '>') h0++;
+            tok[k] = {h0, h1 - h0};
+        }
+        if (tok[0].len != tok[1].len || memcmp(fbuf + tok[0].off, qbuf + tok[1].off, (size_t)tok[0].len) != 0)
+            return fail(MIO_E_UNSUPPORTED, "fasta and qual headers differ");          // NameMismatchError: line parser
+        if (fs.len == 0 || ql.len == 0) return fail(MIO_E_UNSUPPORTED, "empty sequence or quality line");
+        if (w + tok[0].len + 2 * fs.len > out_cap) break;                             // caller's buffer is full
+        char *slot = out + w;
+        memcpy(slot, fbuf + tok[0].off, (size_t)tok[0].len);
+        memcpy(slot + tok[0].len, fbuf + fs.off, (size_t)fs.len);
+        // qualities: decimal integers 0..254 separated by single spaces or tabs (moira.py:1124: map(int, ...split(' ')))
+        unsigned char *qo = (unsigned char *)slot + tok[0].len + fs.len;
+        int64_t nq = 0;
+        const char *t = qbuf + ql.off, *tend = t + ql.len;
+        while (t < tend) {
+            if (*t < '0' || *t > '9') return fail(MIO_E_UNSUPPORTED, "quality token the byte-level path declines");
+            int v = 0;
+            while (t < tend && *t >= '0' && *t <= '9' && v <= 254) v = v * 10 + (*t++ - '0');
+            if (v > 254) return fail(MIO_E_UNSUPPORTED, "quality above 254");
+            if (nq >= fs.len) return fail(MIO_E_UNSUPPORTED, "sequence and qualities differ in length");
+            qo[nq++] = (unsigned char)v;
+            if (t < tend) {
+                if (*t != ' ' && *t != '\t') return fail(MIO_E_UNSUPPORTED, "quality token the byte-level path declines");
+                t++;
+                if (t == tend) return fail(MIO_E_UNSUPPORTED, "trailing separator");
+            }
+        }
+        if (nq != fs.len) return fail(MIO_E_UNSUPPORTED, "sequence and qualities differ in length");
+        int64_t *r = out_idx + n * MIO_IDX_COLS;
+        r[MIO_HDR_OFF] = w; r[MIO_HDR_LEN] = tok[0].len;
+        r[MIO_SEQ_OFF] = w + tok[0].len; r[MIO_SEQ_LEN] = fs.len;
+        r[MIO_QUAL_OFF] = w + tok[0].len + fs.len; r[MIO_QUAL_LEN] = fs.len;
+        w += tok[0].len + 2 * fs.len;
+        n++;
+        fp = b; qp = d;
+        *f_consumed = fp; *q_consumed = qp; *out_used = w;
+    }
+    return n;
+}
+
 int64_t mio_first_header_mismatch(const char *fbuf, const int64_t *fidx, const char *rbuf, const int64_t *ridx, int64_t n)
 {
     for (int64_t k = 0; k < n; k++) {
@@ -327,7 +423,7 @@ int32_t mio_py2_hash(const char *buf, const int64_t *idx, int64_t n, int32_t max
 }
 
 int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel, int32_t kind,
-                   int32_t fastq_offset, int32_t max_len, const char *relabel, const int64_t *relabel_index,
+                   int32_t fastq_offset, int32_t out_offset, int32_t max_len, const char *relabel, const int64_t *relabel_index,
                    const double *ee, const char *const *labels, const int32_t *label_id,
                    char *out, int64_t cap, int64_t *needed)
 {
@@ -366,7 +462,7 @@ int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int6
         if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); }
         if (kind != MIO_FMT_FASTA) {
             const unsigned char *ql = (const unsigned char *)buf + r[MIO_QUAL_OFF];
-            if (kind == MIO_FMT_FASTQ) put_qual_string(o, ql, L, fastq_offset);
+            if (kind == MIO_FMT_FASTQ) put_qual_string(o, ql, L, fastq_offset, out_offset);
             else put_quals(o, ql, L, fastq_offset);
             o.ch('\n');
         }
@@ -482,7 +578,7 @@ int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *
 }
 
 int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t nsel, int32_t kind,
-                            int32_t fastq_offset, const char *relabel, int32_t usearch,
+                            int32_t fastq_offset, int32_t out_offset, const char *relabel, int32_t usearch,
                             const char *const *labels, const int32_t *label_id, const uint8_t *lstrip_gt,
                             char *out, int64_t cap, int64_t *needed)
 {
@@ -541,7 +637,7 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
         }
         o.ch('\n');
         if (kind != MIO_FMT_QUAL) { o.put(A + u.seq_off, u.len); o.ch('\n'); }
-        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); put_qual_string(o, (const unsigned char *)A + u.qual_off, u.len, fastq_offset); o.ch('\n'); }
+        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); put_qual_string(o, (const unsigned char *)A + u.qual_off, u.len, fastq_offset, out_offset); o.ch('\n'); }
         if (kind == MIO_FMT_QUAL) { put_quals(o, (const unsigned char *)A + u.qual_off, u.len, fastq_offset); o.ch('\n'); }
     }
     if (needed) *needed = o.n;

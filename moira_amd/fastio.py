@@ -46,10 +46,12 @@ PROTOTYPES = {
     "mio_collapse_export": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mio_format_report": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "mio_collapse_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
+    "mio_collapse_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mio_first_header_mismatch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
-    "mio_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+    "mio_fasta_qual_index": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
+                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mio_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p]),
 }
@@ -152,7 +154,7 @@ def py2_hashes(buf, idx, max_len=0):
 
 
 def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None, relabel_index=None, ee=None,
-                   labels=None, label_id=None):
+                   labels=None, label_id=None, out_offset=None):
     """Selected records as one bytes-like object (kind: FMT_FASTA / FMT_QUAL / FMT_FASTQ), valid until the
     next formatting call."""
     L = load()
@@ -176,7 +178,8 @@ def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None
                                                                    + (max(map(len, labels)) if labels else 0))
     out = _scratch_u8("format", cap)
     needed = C.c_int64(0)
-    args = (_ptr(buf), idx.ctypes.data, sel.ctypes.data, n, kind, int(fastq_offset), int(max_len),
+    args = (_ptr(buf), idx.ctypes.data, sel.ctypes.data, n, kind, int(fastq_offset),
+            int(fastq_offset if out_offset is None else out_offset), int(max_len),
             relabel.encode() if relabel is not None else None,
             relabel_index.ctypes.data if relabel is not None else None,
             ee.ctypes.data if ee is not None else None,
@@ -259,7 +262,7 @@ class Collapse:
         return ee, ln, size, fl.astype(bool), aux
 
     def format(self, sel, kind, fastq_offset=33, relabel=None, usearch=False, labels=None, label_id=None,
-               lstrip_gt=None):
+               lstrip_gt=None, out_offset=None):
         sel = np.ascontiguousarray(sel, np.int64)
         n = len(sel)
         if n == 0:
@@ -271,7 +274,8 @@ class Collapse:
             lab_arr = (C.c_char_p * len(enc))(*enc)
         if lstrip_gt is not None:
             lstrip_gt = np.ascontiguousarray(lstrip_gt, np.uint8)
-        args = (self.h, sel.ctypes.data, n, kind, int(fastq_offset), relabel.encode() if relabel else None,
+        args = (self.h, sel.ctypes.data, n, kind, int(fastq_offset),
+                int(fastq_offset if out_offset is None else out_offset), relabel.encode() if relabel else None,
                 1 if usearch else 0, C.cast(lab_arr, C.c_void_p) if lab_arr is not None else None,
                 label_id.ctypes.data if label_id is not None else None,
                 lstrip_gt.ctypes.data if lstrip_gt is not None else None)
@@ -369,3 +373,57 @@ class PairedFastqChunks:
             if any(not has_next[k] and eof[k] for k in (0, 1)):
                 return                                       # one file is exhausted: zip() stops here
             want = [not has_next[k] for k in (0, 1)]
+
+
+class FastaQualChunks:
+    """A fasta file and its qual file as (buf, idx) chunks of exactly `max_records` records (fewer only at
+    the end): buf is a uint8 array built by mio_fasta_qual_index (header | sequence | one byte per quality,
+    FASTQ offset 0).  Raises Unsupported for anything the line parser treats specially."""
+
+    def __init__(self, ffh, qfh, max_records, block_bytes=1 << 24):
+        self.fh, self.max_records, self.block = (ffh, qfh), max_records, block_bytes
+
+    def __iter__(self):
+        L = load()
+        tail, eof = [b"", b""], [False, False]
+        out = idx = None
+        have = used = 0
+        starved = True
+        while True:
+            for k in (0, 1):
+                if not eof[k] and (starved or len(tail[k]) < self.block):
+                    more = self.fh[k].read(self.block)
+                    if more:
+                        tail[k] = tail[k] + more if tail[k] else more
+                    else:
+                        eof[k] = True
+            final = eof[0] and eof[1]
+            if out is None:
+                out = np.empty(self.max_records * 64 + 4 * self.block, np.uint8)
+                idx = np.empty((self.max_records, IDX_COLS), np.int64)
+                have = used = 0
+            fc, qc, ou = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            n = L.mio_fasta_qual_index(tail[0], len(tail[0]), tail[1], len(tail[1]), 1 if final else 0,
+                                       self.max_records - have, out.ctypes.data + used, len(out) - used,
+                                       idx.ctypes.data + have * IDX_COLS * 8, C.addressof(fc), C.addressof(qc),
+                                       C.addressof(ou))
+            if n == E_UNSUPPORTED:
+                raise Unsupported(_err())
+            if n < 0:
+                raise ValueError(_err())
+            idx[have:have + n, [HDR_OFF, SEQ_OFF, QUAL_OFF]] += used      # offsets were relative to this call's slice
+            have += n
+            used += ou.value
+            tail = [tail[0][fc.value:], tail[1][qc.value:]]
+            starved = n == 0                                             # nothing complete in what is buffered
+            full = have == self.max_records
+            if full or (final and n == 0):
+                if have:
+                    yield out, idx[:have]
+                out = None
+                if final and not full:
+                    return
+            elif n == 0 and not final and len(out) - used < 2 * self.block:
+                bigger = np.empty(2 * len(out), np.uint8)                 # records longer than expected: more room
+                bigger[:used] = out[:used]
+                out = bigger

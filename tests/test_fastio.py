@@ -436,3 +436,71 @@ def test_byte_level_path_equals_line_path_on_the_gpu(tmp_path, kw):
     for k in fast:
         assert fast[k] == slow[k], k
     assert sum(len(v) for v in fast.values()) > 100000
+
+
+# ---- fasta + qual input --------------------------------------------------------------------------------
+def fastq_to_fasta_qual(text, offset=33):
+    fa, qu = [], []
+    lines = text.split("\n")
+    for i in range(0, len(lines) - 3, 4):
+        h, s, _, q = lines[i:i + 4]
+        fa.append(">%s\n%s\n" % (h[1:], s))
+        qu.append(">%s\n%s\n" % (h[1:], " ".join(str(ord(c) - offset) for c in q)))
+    return "".join(fa), "".join(qu)
+
+
+FQ_CASES = [dict(), dict(collapse=True, output_format="fastq"), dict(output_format="fastq", fastq_offset=64, truncate=70),
+            dict(collapse=True, pipeline="USEARCH", ambigs="disallow")]
+
+
+@pytest.mark.parametrize("case", range(len(FQ_CASES)))
+def test_fasta_qual_byte_level_path_equals_line_path(tmp_path, oracle, monkeypatch, case):
+    text = make_fastq(np.random.default_rng(900 + case), 400, quirks=False, lo=30, hi=150)
+    text += make_fastq(np.random.default_rng(900 + case), 80, quirks=False, lo=30, hi=150)       # duplicates
+    fa, qu = fastq_to_fasta_qual(text)
+    (tmp_path / "in.fasta").write_bytes(fa.encode())
+    (tmp_path / "in.qual").write_bytes(qu.replace(" ", "\t", 3).encode())                       # a few tabs
+    kw = dict(forward_fasta=str(tmp_path / "in.fasta"), forward_qual=str(tmp_path / "in.qual"), **FQ_CASES[case])
+    backend = matrix_backend(oracle)
+    calls = []
+    real = cli._run_fast_fastq
+    monkeypatch.setattr(cli, "_run_fast_fastq", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(cli, "CHUNK_READS", 97)
+    assert cli.main(args_for(None, str(tmp_path / "fast"), **kw), backend=backend, out=open(os.devnull, "w")) == 0
+    assert calls == [1]
+    monkeypatch.setenv("MOIRA_NO_FASTIO", "1")
+    assert cli.main(args_for(None, str(tmp_path / "slow"), **kw), backend=backend, out=open(os.devnull, "w")) == 0
+    fast, slow = outputs_of(str(tmp_path / "fast")), outputs_of(str(tmp_path / "slow"))
+    assert fast.keys() == slow.keys() and len(fast) >= 2
+    for k in fast:
+        assert fast[k] == slow[k], k
+    assert sum(len(v) for v in fast.values()) > 20000
+
+
+def test_fasta_qual_paired_and_fallbacks(tmp_path, oracle, monkeypatch):
+    f_text, r_text = make_pairs(np.random.default_rng(31), 120)
+    names = {}
+    for tag, text in (("f", f_text), ("r", r_text)):
+        fa, qu = fastq_to_fasta_qual(text)
+        (tmp_path / (tag + ".fasta")).write_bytes(fa.encode())
+        (tmp_path / (tag + ".qual")).write_bytes(qu.encode())
+        names[tag] = (str(tmp_path / (tag + ".fasta")), str(tmp_path / (tag + ".qual")))
+    kw = dict(paired=True, collapse=True, forward_fasta=names["f"][0], forward_qual=names["f"][1],
+              reverse_fasta=names["r"][0], reverse_qual=names["r"][1], min_overlap=25)
+    backend = matrix_backend(oracle)
+    monkeypatch.setattr(cli, "PAIR_CHUNK_READS", 41)
+    assert cli.main(args_for(None, str(tmp_path / "fast"), **kw), backend=backend, out=open(os.devnull, "w")) == 0
+    monkeypatch.setenv("MOIRA_NO_FASTIO", "1")
+    assert cli.main(args_for(None, str(tmp_path / "slow"), **kw), backend=backend, out=open(os.devnull, "w")) == 0
+    monkeypatch.delenv("MOIRA_NO_FASTIO")
+    fast, slow = outputs_of(str(tmp_path / "fast")), outputs_of(str(tmp_path / "slow"))
+    assert fast == slow and "contigs.report" in fast and sum(len(v) for v in fast.values()) > 10000
+    # what the byte-level parser declines goes to the line parser, which raises the reference's exceptions
+    (tmp_path / "bad.fasta").write_bytes(b">a\nACGT\n>b\nACGT\n")
+    for qual, exc in ((b">a\n30 30 30 30\n>c\n30 30 30 30\n", cli.NameMismatchError),
+                      (b">a\n30 30 30 30\n>b\n30 30 30\n", cli.LengthMismatchError),
+                      (b">a\n30 30 30 30\n>b\n30 x 30 30\n", ValueError)):
+        (tmp_path / "bad.qual").write_bytes(qual)
+        with pytest.raises(exc):
+            cli.main(args_for(None, str(tmp_path / "o"), forward_fasta=str(tmp_path / "bad.fasta"),
+                              forward_qual=str(tmp_path / "bad.qual")), backend=backend, out=open(os.devnull, "w"))
