@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -82,7 +83,10 @@ struct mio_collapse {
     };
     struct Name { int64_t off; int32_t len; int64_t next; };
     struct Slot { uint64_t hash; int64_t uid; };             // uid < 0: empty
-    std::vector<char> arena;
+    // append-only byte store in 64 MiB blocks (no reallocation copies; an item never straddles blocks)
+    static constexpr int ARENA_SHIFT = 26;
+    std::vector<std::unique_ptr<char[]>> blocks;
+    int64_t block_used = 0;
     std::vector<Uniq> uniq;
     std::vector<Name> names;
     std::vector<Slot> slots;                                 // CPython 2.7 dict layout: PyDict_MINSIZE 8
@@ -90,12 +94,26 @@ struct mio_collapse {
     std::vector<int64_t> order;                              // output order, built by mio_collapse_export
     mio_collapse() : slots(8, Slot{0, -1}) {}
 
+    char *reserve(int64_t n, int64_t *off)
+    {
+        const int64_t cap = (int64_t)1 << ARENA_SHIFT;
+        if (n > cap) throw std::bad_alloc();
+        if (blocks.empty() || block_used + n > cap) {
+            blocks.emplace_back(new char[(size_t)cap]);
+            block_used = 0;
+        }
+        *off = ((int64_t)(blocks.size() - 1) << ARENA_SHIFT) | block_used;
+        char *p = blocks.back().get() + block_used;
+        block_used += n;
+        return p;
+    }
     int64_t put(const char *p, int64_t n)
     {
-        const int64_t off = (int64_t)arena.size();
-        arena.insert(arena.end(), p, p + n);
+        int64_t off;
+        memcpy(reserve(n, &off), p, (size_t)n);
         return off;
     }
+    const char *at(int64_t off) const { return blocks[(size_t)(off >> ARENA_SHIFT)].get() + (off & (((int64_t)1 << ARENA_SHIFT) - 1)); }
     // lookdict / insertdict_clean of CPython 2.7 (no deletions): first empty slot of the probe sequence
     int64_t *find(uint64_t h, const char *key, int64_t len, Slot **where)
     {
@@ -105,7 +123,7 @@ struct mio_collapse {
             if (sl.uid < 0) { *where = &sl; return nullptr; }
             if (sl.hash == h) {
                 const Uniq &u = uniq[sl.uid];
-                if (u.len == len && memcmp(arena.data() + u.seq_off, key, (size_t)len) == 0) return &sl.uid;
+                if (u.len == len && memcmp(at(u.seq_off), key, (size_t)len) == 0) return &sl.uid;
             }
             i = (i << 2) + i + perturb + 1;
             perturb >>= 5;
@@ -513,17 +531,46 @@ int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, i
     if (!c || !buf || !idx || n < 0 || (n > 0 && !ee)) return fail(MIO_E_INVALID, "mio_collapse_add: bad arguments");
     try {
         c->order.clear();
-        std::vector<char> hdr;
+        // the string hash is one dependent multiply-xor per byte: four records' chains run interleaved
+        std::vector<uint64_t> hashes((size_t)n);
+        auto seq_of = [&](int64_t k, int64_t *L) {
+            const int64_t *r = idx + k * MIO_IDX_COLS;
+            *L = r[MIO_SEQ_LEN];
+            if (max_len > 0 && *L > max_len) *L = max_len;
+            return (const unsigned char *)buf + r[MIO_SEQ_OFF];
+        };
+        int64_t k4 = 0;
+        for (; k4 + 4 <= n; k4 += 4) {
+            const unsigned char *p[4];
+            int64_t len4[4], common = INT64_MAX;
+            for (int j = 0; j < 4; j++) { p[j] = seq_of(k4 + j, &len4[j]); common = len4[j] < common ? len4[j] : common; }
+            if (common <= 0) { for (int j = 0; j < 4; j++) hashes[(size_t)(k4 + j)] = py2_hash(p[j], len4[j]); continue; }
+            uint64_t x0 = (uint64_t)p[0][0] << 7, x1 = (uint64_t)p[1][0] << 7, x2 = (uint64_t)p[2][0] << 7, x3 = (uint64_t)p[3][0] << 7;
+            for (int64_t i = 0; i < common; i++) {
+                x0 = (1000003ull * x0) ^ p[0][i]; x1 = (1000003ull * x1) ^ p[1][i];
+                x2 = (1000003ull * x2) ^ p[2][i]; x3 = (1000003ull * x3) ^ p[3][i];
+            }
+            uint64_t x[4] = {x0, x1, x2, x3};
+            for (int j = 0; j < 4; j++) {
+                for (int64_t i = common; i < len4[j]; i++) x[j] = (1000003ull * x[j]) ^ p[j][i];
+                x[j] ^= (uint64_t)len4[j];
+                hashes[(size_t)(k4 + j)] = x[j] == ~0ull ? ~0ull - 1 : x[j];
+            }
+        }
+        for (; k4 < n; k4++) { int64_t L; const unsigned char *q = seq_of(k4, &L); hashes[(size_t)k4] = py2_hash(q, L); }
         for (int64_t k = 0; k < n; k++) {
             const int64_t *r = idx + k * MIO_IDX_COLS;
             int64_t L = r[MIO_SEQ_LEN];
             if (max_len > 0 && L > max_len) L = max_len;
             const char *seq = buf + r[MIO_SEQ_OFF];
-            hdr.assign(buf + r[MIO_HDR_OFF], buf + r[MIO_HDR_OFF] + r[MIO_HDR_LEN]);
-            for (char &ch : hdr) if (ch == ':') ch = '_';                           // moira.py:1175
+            const int64_t hl = r[MIO_HDR_LEN];
+            int64_t hoff;
+            char *hw = c->reserve(hl, &hoff);
+            const char *hs = buf + r[MIO_HDR_OFF];
+            for (int64_t i = 0; i < hl; i++) hw[i] = hs[i] == ':' ? '_' : hs[i];      // moira.py:1175
             const int64_t name_id = (int64_t)c->names.size();
-            c->names.push_back({c->put(hdr.data(), (int64_t)hdr.size()), (int32_t)hdr.size(), -1});
-            const uint64_t h = py2_hash((const unsigned char *)seq, L);
+            c->names.push_back({hoff, (int32_t)hl, -1});
+            const uint64_t h = hashes[(size_t)k];
             mio_collapse::Slot *where = nullptr;
             int64_t *hit = c->find(h, seq, L, &where);
             if (!hit) {                                                             // moira.py:461-464
@@ -588,7 +635,6 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
     if (c->order.size() != c->uniq.size()) return fail(MIO_E_INVALID, "call mio_collapse_export first");
     Out o{out, cap, 0};
     const int64_t relabel_len = relabel ? (int64_t)strlen(relabel) : 0;
-    const char *A = c->arena.data();
     char num[96];
     std::vector<char> hdr;
     for (int64_t k = 0; k < nsel; k++) {
@@ -601,7 +647,7 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
             const int m = snprintf(num, sizeof(num), "%lld", (long long)(sel[k] + 1));
             hdr.insert(hdr.end(), num, num + m);
         } else {
-            hdr.insert(hdr.end(), A + rep.off, A + rep.off + rep.len);
+            hdr.insert(hdr.end(), c->at(rep.off), c->at(rep.off) + rep.len);
         }
         if (usearch) {                                                              // moira.py:858-863
             const int m = snprintf(num, sizeof(num), ";ee=%.2f;size=%lld;", u.ee, (long long)u.size);
@@ -623,7 +669,7 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
                 for (int64_t id = pass == 0 ? u.front : u.back_head; id >= 0; id = c->names[id].next) {
                     if (!first) o.ch(',');
                     first = false;
-                    o.put(A + c->names[id].off, c->names[id].len);
+                    o.put(c->at(c->names[id].off), c->names[id].len);
                 }
             o.ch('\n');
             continue;
@@ -636,9 +682,9 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
             o.put(lab, (int64_t)strlen(lab));
         }
         o.ch('\n');
-        if (kind != MIO_FMT_QUAL) { o.put(A + u.seq_off, u.len); o.ch('\n'); }
-        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); put_qual_string(o, (const unsigned char *)A + u.qual_off, u.len, fastq_offset, out_offset); o.ch('\n'); }
-        if (kind == MIO_FMT_QUAL) { put_quals(o, (const unsigned char *)A + u.qual_off, u.len, fastq_offset); o.ch('\n'); }
+        if (kind != MIO_FMT_QUAL) { o.put(c->at(u.seq_off), u.len); o.ch('\n'); }
+        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); put_qual_string(o, (const unsigned char *)c->at(u.qual_off), u.len, fastq_offset, out_offset); o.ch('\n'); }
+        if (kind == MIO_FMT_QUAL) { put_quals(o, (const unsigned char *)c->at(u.qual_off), u.len, fastq_offset); o.ch('\n'); }
     }
     if (needed) *needed = o.n;
     if (o.n > cap) return fail(MIO_E_SPACE, "output needs %lld bytes", (long long)o.n);
