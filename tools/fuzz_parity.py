@@ -72,6 +72,8 @@ with Engine(0) as eng:
             ok = ok and np.array_equal(r.ee[~sk], ee[~sk], equal_nan=True) and not ps[sk].any()
         else:
             ok = ok and np.array_equal(r.ee, ee, equal_nan=True)
+        if (it + 1) % 100 == 0:
+            print("fuzz: %d rounds done, %d mismatching, %.0f s" % (it + 1, bad, time.time() - t0), flush=True)
         if not ok:
             bad += 1
             d = np.nonzero(~((r.ee == ee) | (np.isnan(r.ee) & np.isnan(ee))))[0]
