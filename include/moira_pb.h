@@ -63,7 +63,7 @@ extern "C" {
                                     pipelines that never look at the ee of a discarded read. */
 #define MPB_FLAG_TEST_UNDERPREDICT 4u /* test hook: halve every predicted row budget so that the
                                          overflow (second) pass is exercised; results are unchanged */
-#define MPB_FLAG_BATCHED_ONLY 16u /* mpb_filter_host sends batches of <= 2048 reads through one launch with one
+#define MPB_FLAG_BATCHED_ONLY 16u /* mpb_filter_host sends batches of <= 4096 reads through one launch with one
                                      read per wave (latency: what a per-read caller sees) instead of the sorted,
                                      tiled pipeline; this flag forces the pipeline.  Results are identical. */
 

@@ -498,10 +498,12 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
     return MPB_OK;
 }
 
-// Batches of at most MPB_SMALL_N reads: one host-to-device copy from pinned memory, one kernel (one read
+// Batches of at most MPB_SMALL_N reads (the two paths cost the same at about 8 k reads): one host-to-device copy from pinned memory, one kernel (one read
 // per wave), one copy back -- the batched pipeline's ten launches and six copies cost ~160 us whatever
 // the size, which is all a per-read caller (bernoulli.calculate_errors_PB) would ever see.
-#define MPB_SMALL_N 2048
+#ifndef MPB_SMALL_N
+#define MPB_SMALL_N 4096
+#endif
 
 static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
                              int32_t fixed_len, const mpb_filter_params *params, double *ee, int32_t *ns,

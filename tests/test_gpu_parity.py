@@ -17,7 +17,7 @@ REL_TOL = 1e-9      # north_star: "within 1e-9 relative"
 @pytest.fixture(scope="module", params=["batched", "small"])
 def eng(request):
     """Every parity test runs twice: through the sorted, tiled pipeline whatever the batch size, and with
-    mpb_filter_host free to send batches of <= 2048 reads through the one-read-per-wave launch."""
+    mpb_filter_host free to send batches of <= 4096 reads through the one-read-per-wave launch."""
     from moira_amd.engine import Engine
     e = Engine(0)
     e.batched_only = request.param == "batched"

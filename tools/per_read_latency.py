@@ -23,7 +23,7 @@ for _ in range(n):
 dt = time.perf_counter() - t
 print("calculate_errors_PB: %.1f us per call = %.0f reads/s" % (dt / n * 1e6, n / dt))
 eng = default_engine()
-for m in (1, 64, 1024, 16384):
+for m in (1, 64, 1024, 2048, 4096, 8192, 16384, 32768):
     q = np.tile(np.array(quals, np.uint8), (m, 1))
     q = np.pad(q, ((0, 0), (0, 20)))
     for _ in range(5):
