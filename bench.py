@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--fast-fma", action="store_true", help="non-bit-exact FMA mode (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stride", type=int, default=0, help="row stride in bytes (default: length rounded up to 64; experiments)")
     ap.add_argument("--no-extras", action="store_true", help="skip the opt-in-mode extra runs (profiling)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank dry run on a 1-GPU box: every rank uses device 0 and the (tiny) "
@@ -120,7 +121,7 @@ def main():
         torch.cuda.synchronize()
 
     n, L = args.reads, args.length
-    stride = (L + 63) // 64 * 64          # 300 -> 320
+    stride = args.stride or (L + 63) // 64 * 64          # 300 -> 320
     eng = Engine(local_rank)
     d_q = eng.alloc(n * stride)
     d_ee, d_ns, d_pass = eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)

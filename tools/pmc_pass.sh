@@ -5,7 +5,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 D=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $D
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $D -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $D/run.log 2>&1
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $D -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $BENCH_ARGS > $D/run.log 2>&1
 python3 - "$D" <<'PY'
 import sys, glob, csv, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
