@@ -304,10 +304,12 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
     const int64_t b_perm = align_up((cap + (int64_t)MPB_NCLS * 64) * 4, 256);
     const int64_t b_hist = align_up(nb * MPB_SKEYS * 4, 256);
     const int64_t b_ovf = align_up(cap * 4, 256);
-    HIPCHK(hipMalloc(&c->ws_block, (size_t)(b_cls + b_perm + b_hist + b_ovf)));
+    const int64_t b_pns = align_up((cap + (int64_t)MPB_NCLS * 64) * 2, 256);
+    HIPCHK(hipMalloc(&c->ws_block, (size_t)(b_cls + b_perm + b_pns + b_hist + b_ovf)));
     char *p = (char *)c->ws_block;
     c->ws.cls = (uint8_t *)p; p += b_cls;
     c->ws.perm = (int32_t *)p; p += b_perm;
+    c->ws.perm_ns = (uint16_t *)p; p += b_pns;
     c->ws.blockhist = (int32_t *)p; p += b_hist;
     c->ws.ovf_list = (int32_t *)p;
     c->ws_cap = cap;
@@ -456,7 +458,7 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     hipStream_t s = c->stream;
     { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     { Span t(c, MPB_K_SCAN);     mpb_launch_scan(n, d_len, c->ws, s); }
-    { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, d_len, prm, c->ws, s); }
+    { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, d_len, d_ns, prm, c->ws, s); }
     { Span t(c, MPB_K_DP);       mpb_launch_dp(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     { Span t(c, MPB_K_OVERFLOW); mpb_launch_overflow(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     HIPCHK(hipGetLastError());

@@ -76,6 +76,8 @@ struct MpbDevParams {
 struct MpbWorkspace {
     uint8_t  *cls;         // [n]   class id | 0x80 if the read has an upper-case N
     int32_t  *perm;        // [n + MPB_NCLS*64] read indices grouped by class
+    uint16_t *perm_ns;     // [n + MPB_NCLS*64] ambiguity count of perm[k]'s read, so that the DP epilogue reads it
+                           // next to the index instead of gathering ns[idx] (one line request per read)
     int32_t  *blockhist;   // [MPB_SKEYS][nblocks_pre], key-major
     MpbTables *tables;     // main pass
     MpbTables *tables2;    // overflow pass
@@ -96,7 +98,8 @@ void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32
 void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                       const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s);
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s);
-void mpb_launch_scatter(int64_t n, const int32_t *len, const MpbDevParams &prm, const MpbWorkspace &ws, hipStream_t s);
+void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const MpbDevParams &prm, const MpbWorkspace &ws,
+                        hipStream_t s);
 void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                    const MpbDevParams &prm, const MpbWorkspace &ws, const int32_t *ns,
                    double *ee, uint8_t *pass, hipStream_t s);

@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
                                                  const int32_t *__restrict__ len_arg, int max_len,
                                                  const int32_t *__restrict__ blockhist,
                                                  const MpbTables *__restrict__ tb,
-                                                 int32_t *__restrict__ perm)
+                                                 const int32_t *__restrict__ ns,
+                                                 int32_t *__restrict__ perm, uint16_t *__restrict__ perm_ns)
 {
     constexpr int nb = RAGGED ? MPB_LEN_BINS : 1;
     constexpr int nkeys = MPB_NCLS * nb;
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
             int off = s_base[kk];
             for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][kk];
             perm[off + rank] = (int32_t)i;
+            perm_ns[off + rank] = (uint16_t)ns[i];
         }
         __syncthreads();
         for (int k = tid; k < nkeys; k += 256)
@@ -470,6 +472,8 @@ struct DpArgs {
     uint8_t *pass;
     int32_t *ovf_list;
     int32_t *ovf_count;
+    const int32_t *perm;        // with perm_ns: the sorted index array the tiles walk (main pass only)
+    const uint16_t *perm_ns;    // ns of perm[k]'s read, or nullptr: gather ns[idx]
     MpbDevParams prm;
     int final_pass;
 };
@@ -631,7 +635,7 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
                 e = (double)(js - 1) + ((thr - lo) / (hi - lo));
                 if (e < 0) e = 0;
             }
-            const int nsv = A.ns[idx];
+            const int nsv = A.perm_ns ? (int)A.perm_ns[(perm_cls - A.perm) + slot] : A.ns[idx];
             if (A.prm.ambig_mode == 0) e = e + (double)nsv;              // moira.py:827-828
             if (A.prm.flags & 1u) e = floor(e);                          // moira.py:830-831
             bool keep_read;
@@ -913,14 +917,15 @@ void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipS
     hipLaunchKernelGGL(k_tables, dim3(1), dim3(64), 0, s, ws.tables, nb, ws.ovf_count, ws.pass_count);
 }
 
-void mpb_launch_scatter(int64_t n, const int32_t *len, const MpbDevParams &prm, const MpbWorkspace &ws, hipStream_t s)
+void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const MpbDevParams &prm, const MpbWorkspace &ws,
+                        hipStream_t s)
 {
     if (len)
         hipLaunchKernelGGL((k_scatter<true>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len,
-                           ws.blockhist, ws.tables, ws.perm);
+                           ws.blockhist, ws.tables, ns, ws.perm, ws.perm_ns);
     else
         hipLaunchKernelGGL((k_scatter<false>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len,
-                           ws.blockhist, ws.tables, ws.perm);
+                           ws.blockhist, ws.tables, ns, ws.perm, ws.perm_ns);
 }
 
 // cap of the DP grid (blocks of 4 waves); beyond it the chunk loop strides
@@ -934,6 +939,7 @@ static DpArgs make_args(const uint8_t *q, int64_t stride, const int32_t *len, co
     DpArgs A;
     A.q = q; A.stride = stride; A.len = len; A.ns = ns; A.cls = ws.cls; A.ee = ee; A.pass = pass;
     A.ovf_list = ws.ovf_list; A.ovf_count = ws.ovf_count; A.prm = prm; A.final_pass = final_pass;
+    A.perm = ws.perm; A.perm_ns = final_pass == 0 ? ws.perm_ns : nullptr;   // overflow / small-batch passes walk other lists
     return A;
 }
 
