@@ -828,6 +828,11 @@ def _run_fast_fastq(args, backend, o, say, t0):
     processed = 0
     disc_err = disc_len = disc_ov = 0.0
     groups = F.Collapse() if args.collapse else None
+    threads = max(1, min(8, int(args.processors or 1)))  # --processors (at most 8 here): packing / formatting calls in flight
+    pool = None
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(threads)
     emit = _InOrder()
     ok = False
     try:
@@ -839,8 +844,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
             has_n = np.empty(n, bool)
             for stride in np.unique(strides):
                 sel = np.nonzero(strides == stride)[0]
-                q, ln, fl = F.pack(buf, idx, sel, in_off, T, lower_n_is_base=(method == "poisson"),
-                                   stride=int(stride), reuse=True)
+                q, ln, fl = F.pack_parallel(pool, threads, buf, idx, sel, in_off, T, method == "poisson", int(stride))
                 ee[sel] = backend.matrix(q, ln, args.alpha, args.ambigs, args.round, method=method, fast_discard=fd)
                 has_n[sel] = fl
             nan = np.isnan(ee)
@@ -867,11 +871,9 @@ def _run_fast_fastq(args, backend, o, say, t0):
                         kw = dict(fastq_offset=in_off, out_offset=args.fastq_offset, max_len=T, relabel_index=first + sel,
                                   ee=ee[sel] if usearch else None, labels=labels if lab is not None else None,
                                   label_id=lab[sel] if lab is not None else None, **hdr)
-                        if fq:
-                            main_f.write(F.format_records(buf, idx, sel, F.FMT_FASTQ, **kw))
-                        else:
-                            main_f.write(F.format_records(buf, idx, sel, F.FMT_FASTA, **kw))
-                            qual_f.write(F.format_records(buf, idx, sel, F.FMT_QUAL, **kw))
+                        for kind, f in (((F.FMT_FASTQ, main_f),) if fq else ((F.FMT_FASTA, main_f), (F.FMT_QUAL, qual_f))):
+                            for piece in F.format_parallel(pool, threads, buf, idx, sel, kind, **kw):
+                                f.write(piece)
                 emit.submit(write_chunk)
             processed += n
             if not args.silent:
@@ -906,6 +908,8 @@ def _run_fast_fastq(args, backend, o, say, t0):
     finally:
         if not ok:
             emit.close(raise_errors=False)         # an exception is already on its way
+        if pool is not None:
+            pool.shutdown(wait=True)
         if groups is not None:
             groups.close()
     return processed, disc_err, disc_len, disc_ov

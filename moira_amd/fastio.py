@@ -113,7 +113,7 @@ def index(buf, final, max_records):
     return idx[:n], consumed.value, err
 
 
-def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, stride=None, reuse=False):
+def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, stride=None, reuse=False, out=None):
     """-> (q uint8[nsel, stride], lens int32[nsel], has_upper_N bool[nsel]).  reuse=True: q lives in a
     work buffer that the next pack(reuse=True) overwrites."""
     L = load()
@@ -126,9 +126,12 @@ def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, 
         if max_len > 0:
             longest = min(longest, max_len)
         stride = (max(longest, 1) + 15) // 16 * 16
-    q = _scratch_u8("pack", n * stride).reshape(n, stride) if reuse else np.empty((n, stride), np.uint8)
-    lens = np.empty(n, np.int32)
-    flags = np.empty(n, np.uint8)
+    if out is not None:                 # rows of a matrix the caller owns (pack_parallel)
+        q, lens, flags = out
+    else:
+        q = _scratch_u8("pack", n * stride).reshape(n, stride) if reuse else np.empty((n, stride), np.uint8)
+        lens = np.empty(n, np.int32)
+        flags = np.empty(n, np.uint8)
     bad = C.c_int64(-1)
     idx = np.ascontiguousarray(idx)
     rc = L.mio_pack(_ptr(buf), idx.ctypes.data, sel.ctypes.data if sel is not None else None, n, int(fastq_offset),
@@ -136,6 +139,29 @@ def pack(buf, idx, sel=None, fastq_offset=33, max_len=0, lower_n_is_base=False, 
                     flags.ctypes.data, C.addressof(bad))
     if rc:
         raise ValueError(_err())
+    return q, lens, (flags if out is not None else flags.astype(bool))
+
+
+PARALLEL_MIN = 4096       # records below which splitting a call over threads is not worth it
+
+
+def _parts(n, k):
+    k = max(1, min(k, n))
+    return [(n * t // k, n * (t + 1) // k) for t in range(k)]
+
+
+def pack_parallel(pool, threads, buf, idx, sel, fastq_offset, max_len, lower_n_is_base, stride):
+    """pack() with the records split over `threads` calls (the C loop releases the GIL)."""
+    sel = np.ascontiguousarray(sel, np.int64)
+    n = len(sel)
+    if pool is None or threads <= 1 or n < PARALLEL_MIN:
+        return pack(buf, idx, sel, fastq_offset, max_len, lower_n_is_base, stride, reuse=True)
+    q = _scratch_u8("pack", n * stride).reshape(n, stride)
+    lens, flags = np.empty(n, np.int32), np.empty(n, np.uint8)
+    jobs = [pool.submit(pack, buf, idx, sel[a:b], fastq_offset, max_len, lower_n_is_base, stride, False,
+                        (q[a:b], lens[a:b], flags[a:b])) for a, b in _parts(n, threads)]
+    for j in jobs:
+        j.result()
     return q, lens, flags.astype(bool)
 
 
@@ -143,6 +169,18 @@ def first_header_mismatch(fbuf, fidx, rbuf, ridx):
     """Position of the first pair whose header tokens differ, or -1."""
     fidx, ridx = np.ascontiguousarray(fidx), np.ascontiguousarray(ridx)
     return load().mio_first_header_mismatch(_ptr(fbuf), fidx.ctypes.data, _ptr(rbuf), ridx.ctypes.data, len(fidx))
+
+
+def format_parallel(pool, threads, buf, idx, sel, kind, relabel_index=None, ee=None, label_id=None, **kw):
+    """format_records() with the selection split over `threads` calls; returns the pieces in order."""
+    n = len(sel)
+    if pool is None or threads <= 1 or n < PARALLEL_MIN:
+        return [format_records(buf, idx, sel, kind, relabel_index=relabel_index, ee=ee, label_id=label_id, **kw)]
+    cut = lambda a, lo, hi: None if a is None else a[lo:hi]
+    jobs = [pool.submit(format_records, buf, idx, sel[a:b], kind, relabel_index=cut(relabel_index, a, b),
+                        ee=cut(ee, a, b), label_id=cut(label_id, a, b), scratch="format%d" % t, **kw)
+            for t, (a, b) in enumerate(_parts(n, threads))]
+    return [j.result() for j in jobs]
 
 
 def py2_hashes(buf, idx, max_len=0):
@@ -154,7 +192,7 @@ def py2_hashes(buf, idx, max_len=0):
 
 
 def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None, relabel_index=None, ee=None,
-                   labels=None, label_id=None, out_offset=None):
+                   labels=None, label_id=None, out_offset=None, scratch="format"):
     """Selected records as one bytes-like object (kind: FMT_FASTA / FMT_QUAL / FMT_FASTQ), valid until the
     next formatting call."""
     L = load()
@@ -176,7 +214,7 @@ def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None
     per = 4 if kind == FMT_QUAL else (2 if kind == FMT_FASTQ else 1)
     cap = int(L_.sum()) * per + int(idx[sel, HDR_LEN].sum()) + n * (64 + (len(relabel) if relabel else 0)
                                                                    + (max(map(len, labels)) if labels else 0))
-    out = _scratch_u8("format", cap)
+    out = _scratch_u8(scratch, cap)
     needed = C.c_int64(0)
     args = (_ptr(buf), idx.ctypes.data, sel.ctypes.data, n, kind, int(fastq_offset),
             int(fastq_offset if out_offset is None else out_offset), int(max_len),
@@ -188,7 +226,7 @@ def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None
     w = L.mio_format(*args, out.ctypes.data, cap, C.addressof(needed))
     if w == E_SPACE:
         cap = needed.value
-        out = _scratch_u8("format", cap)
+        out = _scratch_u8(scratch, cap)
         w = L.mio_format(*args, out.ctypes.data, cap, C.addressof(needed))
     if w < 0:
         raise ValueError(_err())

@@ -223,7 +223,9 @@ def test_cli_byte_level_path_equals_line_path(tmp_path, oracle, monkeypatch, cas
     calls = []
     real = cli._run_fast_fastq
     monkeypatch.setattr(cli, "_run_fast_fastq", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
-    assert cli.main(args_for(str(src), str(tmp_path / "fast"), **kw), backend=backend, out=open(os.devnull, "w")) == 0
+    monkeypatch.setattr(F, "PARALLEL_MIN", 16 if case % 2 else 4096)      # odd cases: packing/formatting split over threads
+    assert cli.main(args_for(str(src), str(tmp_path / "fast"), processors=3, **kw), backend=backend,
+                    out=open(os.devnull, "w")) == 0
     assert calls == [1]                                                  # the byte-level path really ran
     monkeypatch.setenv("MOIRA_NO_FASTIO", "1")
     assert cli.main(args_for(str(src), str(tmp_path / "slow"), **kw), backend=backend, out=open(os.devnull, "w")) == 0

@@ -70,6 +70,7 @@ def paired_files(m, L=250, frag=380):
 
 run("warm-up", ["-c", "false"])
 run("fastq in, fasta+qual out, no collapse", ["-c", "false"])
+run("fastq in, fasta+qual out, no collapse, -p 8", ["-c", "false", "-p", "8"])
 run("fastq in, fastq out, no collapse", ["-c", "false", "-o", "fastq"])
 run("fastq in, fasta+qual out, collapse", ["-c", "true"])
 run("line parser: fasta+qual out, no collapse", ["-c", "false"], {"MOIRA_NO_FASTIO": "1"})
