@@ -183,9 +183,11 @@ int mpb_filter_device(mpb_ctx *ctx,
                       mpb_filter_counts *counts);
 
 /*
- * Same for a batch in HOST memory: chunks it, overlaps H2D / kernels / D2H on
- * the context's streams, writes host outputs.  Replaces the per-read
- * Pool.apply_async dispatch + .get() barrier of ref: moira/moira.py:431-454.
+ * Same for a batch in HOST memory: copies it in (in chunks of <= 1 GiB of qualities), runs the
+ * kernels, writes host outputs; synchronous.  Replaces the per-read Pool.apply_async dispatch
+ * + .get() barrier of ref: moira/moira.py:431-454.  Batches of <= 4096 reads take one launch
+ * with one read per wave (what a per-read caller needs is latency; MPB_FLAG_BATCHED_ONLY forces
+ * the batched pipeline); results are identical either way.
  */
 int mpb_filter_host(mpb_ctx *ctx,
                     const uint8_t *q, int64_t n, int64_t row_stride,
@@ -248,7 +250,8 @@ int mpb_synth_fill_device(mpb_ctx *ctx, uint8_t *d_q, int64_t n, int64_t row_str
 int mpb_timing_enable(mpb_ctx *ctx, int on);
 int mpb_timing_reset(mpb_ctx *ctx);
 int mpb_kernel_time(mpb_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
-/* Histogram of the DP row-budget classes of the last mpb_filter_device call:
+/* Histogram of the DP row-budget classes of the last mpb_filter_device call (or mpb_filter_host call
+ * that went through the batched pipeline; the one-read-per-wave path keeps no table):
  * caps[i] = rows (J_cap) of class i, counts[i] = reads in it.  Returns the
  * number of classes written (<= max_classes).  Synchronises. */
 int mpb_last_class_histogram(mpb_ctx *ctx, int32_t *caps, int64_t *counts, int32_t max_classes);
