@@ -118,12 +118,14 @@ int32_t mio_py2_hash(const char *buf, const int64_t *idx, int64_t n, int32_t max
  *   out_offset  FASTQ offset of the quality string MIO_FMT_FASTQ writes (= fastq_offset for FASTQ input;
  *               records built by mio_fasta_qual_index carry fastq_offset 0)
  *   max_len     bases written (--truncate; <= 0: all)
- *   qualities are shown after the Q0 -> 1 clamp, as the reference's writer sees them
- *   (ref: moira/moira.py:814).
+ *   clamp_q0    != 0: qualities are shown after the Q0 -> 1 clamp, as the reference's writer sees them
+ *               after quality control (ref: moira/moira.py:814); 0: as they are (--only_contig never
+ *               clamps, ref: moira/moira.py:809-810)
  * Returns the bytes written, or MIO_E_SPACE with *needed set when cap is too small.
  */
 int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel, int32_t kind,
-                   int32_t fastq_offset, int32_t out_offset, int32_t max_len, const char *relabel, const int64_t *relabel_index,
+                   int32_t fastq_offset, int32_t out_offset, int32_t clamp_q0, int32_t max_len, const char *relabel,
+                   const int64_t *relabel_index,
                    const double *ee, const char *const *labels, const int32_t *label_id,
                    char *out, int64_t cap, int64_t *needed);
 
@@ -166,7 +168,7 @@ int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *
  * writes the mothur names line of each group; lstrip_gt uint8[nsel] (may be NULL) drops leading '>'
  * from that line's header where the reference does (ref: moira/moira.py:880,894,907,943). */
 int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t nsel, int32_t kind,
-                            int32_t fastq_offset, int32_t out_offset, const char *relabel, int32_t usearch,
+                            int32_t fastq_offset, int32_t out_offset, int32_t clamp_q0, const char *relabel, int32_t usearch,
                             const char *const *labels, const int32_t *label_id, const uint8_t *lstrip_gt,
                             char *out, int64_t cap, int64_t *needed);
 

@@ -605,12 +605,15 @@ PAIR_CHUNK_READS = 65536      # a contig slot is header + 2 x (l1 + l2) bytes
 
 
 def _fast_eligible(args, backend):
-    return bool((args.forward_fastq or (args.forward_fasta and args.forward_qual)) and not args.only_contig
-                and (args.paired or not args.min_overlap)
-                and args.error_calc in ("poisson_binomial", "poisson_binomial_py", "poisson")
+    if os.environ.get("MOIRA_NO_FASTIO") or not (args.forward_fastq or (args.forward_fasta and args.forward_qual)):
+        return False
+    if not args.paired and args.min_overlap:
+        return False
+    if args.only_contig:
+        return True                                   # no error calculation at all: contigs straight to the writers
+    return bool(args.error_calc in ("poisson_binomial", "poisson_binomial_py", "poisson")
                 and getattr(backend, "matrix", None) is not None
-                and (args.error_calc != "poisson" or "poisson" in getattr(backend, "methods", ()))
-                and not os.environ.get("MOIRA_NO_FASTIO"))
+                and (args.error_calc != "poisson" or "poisson" in getattr(backend, "methods", ())))
 
 
 def _record_error(which, e, args):
@@ -798,6 +801,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
     from . import fastio as F
     from .buckets import bucket_of
     T = args.truncate or 0
+    only = bool(args.only_contig)                                # moira.py:809-810, :898-908: contigs, no quality control
     in_off = args.fastq_offset if args.forward_fastq else 0      # fasta+qual records carry the integers themselves
     method = "poisson" if args.error_calc == "poisson" else "poisson_binomial"
     fd = None
@@ -815,10 +819,11 @@ def _run_fast_fastq(args, backend, o, say, t0):
     def decide(ee, length, has_n, ov):
         """write_results' branch per record or group: -1 good, else the index of its label."""
         label = np.full(len(ee), -1, np.int32)
-        keep = (ee <= args.maxerrors) if args.maxerrors else (ee <= length * args.uncert)   # len(sequence) * uncert
-        label[~keep] = 2
-        if args.ambigs == "disallow":
-            label[has_n] = 1
+        if not only:
+            keep = (ee <= args.maxerrors) if args.maxerrors else (ee <= length * args.uncert)   # len(sequence) * uncert
+            label[~keep] = 2
+            if args.ambigs == "disallow":
+                label[has_n] = 1
         if min_ov:
             label[ov < min_ov] = 3
         if T:
@@ -840,9 +845,9 @@ def _run_fast_fastq(args, backend, o, say, t0):
             n = len(idx)
             lens = np.minimum(idx[:, F.SEQ_LEN], T) if T else idx[:, F.SEQ_LEN].copy()
             strides = bucket_of(lens, 64)
-            ee = np.empty(n, np.float64)
-            has_n = np.empty(n, bool)
-            for stride in np.unique(strides):
+            ee = np.zeros(n, np.float64)                 # --only_contig: process_data returns 0 (moira.py:809-810)
+            has_n = np.zeros(n, bool)
+            for stride in (np.unique(strides) if not only else ()):
                 sel = np.nonzero(strides == stride)[0]
                 q, ln, fl = F.pack_parallel(pool, threads, buf, idx, sel, in_off, T, method == "poisson", int(stride))
                 ee[sel] = backend.matrix(q, ln, args.alpha, args.ambigs, args.round, method=method, fast_discard=fd)
@@ -868,7 +873,8 @@ def _run_fast_fastq(args, backend, o, say, t0):
                     for sel, main_f, qual_f, lab in ((good, o.contig, o.qual, None), (bad, o.bad_contig, o.bad_qual, label)):
                         if not len(sel):
                             continue
-                        kw = dict(fastq_offset=in_off, out_offset=args.fastq_offset, max_len=T, relabel_index=first + sel,
+                        kw = dict(fastq_offset=in_off, out_offset=args.fastq_offset, clamp_q0=not only, max_len=T,
+                                  relabel_index=first + sel,
                                   ee=ee[sel] if usearch else None, labels=labels if lab is not None else None,
                                   label_id=lab[sel] if lab is not None else None, **hdr)
                         for kind, f in (((F.FMT_FASTQ, main_f),) if fq else ((F.FMT_FASTA, main_f), (F.FMT_QUAL, qual_f))):
@@ -888,11 +894,13 @@ def _run_fast_fastq(args, backend, o, say, t0):
             disc_ov += int(gsize[label == 3].sum())
             disc_err += int(gsize[(label == 1) | (label == 2)].sum())
             names = args.pipeline == "mothur"
-            hdr = dict(fastq_offset=in_off, out_offset=args.fastq_offset, relabel=args.relabel or None, usearch=usearch)
+            hdr = dict(fastq_offset=in_off, out_offset=args.fastq_offset, clamp_q0=not only, relabel=args.relabel or None,
+                       usearch=usearch)
             if args.paired:
                 o.report.write(groups.format(np.arange(len(gee)), F.FMT_REPORT, **hdr))
-            # header.lstrip('>') on the names line of three kinds of bad groups (moira.py:880,894,943)
-            strip = (label == 0) | (label == 3) | ((label == 2) & bool(args.maxerrors))
+            # header.lstrip('>') on the names line of three kinds of bad groups, and of every group with
+            # --only_contig (moira.py:880,894,907,943)
+            strip = (label == 0) | (label == 3) | ((label == 2) & bool(args.maxerrors)) | ((label < 0) & only)
             for sel, main_f, qual_f, names_f, lab in ((np.nonzero(label < 0)[0], o.contig, o.qual, o.names, None),
                                                       (np.nonzero(label >= 0)[0], o.bad_contig, o.bad_qual, o.bad_names, label)):
                 if not len(sel):

@@ -167,13 +167,13 @@ uint64_t py2_hash(const unsigned char *s, int64_t L)
     return x;
 }
 
-void put_quals(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset)
+void put_quals(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset, int floor_q)
 {
     if (o.n + 4 * L <= o.cap) {                               // ' '.join(map(str, quals)); fast when it fits
         char *w = o.p + o.n;
         for (int64_t i = 0; i < L; i++) {
             int q = (int)ql[i] - fastq_offset;
-            q = q <= 0 ? 1 : q > 255 ? 255 : q;               // (packing has already rejected q < 0 / > 254)
+            q = q <= floor_q ? floor_q : q > 255 ? 255 : q;   // (packing has already rejected q < 0 / > 254)
             memcpy(w, g_qt.txt[q], 4);
             w += g_qt.len[q];
             *w++ = ' ';
@@ -183,13 +183,13 @@ void put_quals(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset)
     } else {
         for (int64_t i = 0; i < L; i++) {
             int q = (int)ql[i] - fastq_offset;
-            q = q <= 0 ? 1 : q > 255 ? 255 : q;
+            q = q <= floor_q ? floor_q : q > 255 ? 255 : q;
             o.n += g_qt.len[q] + (i + 1 < L ? 1 : 0);
         }
     }
 }
 
-void put_qual_string(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset, int32_t out_offset)
+void put_qual_string(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_offset, int32_t out_offset, int floor_q)
 {
     // chr(q + offset) of the clamped qualities; with equal offsets that is the input string with Q0
     // shown as Q1
@@ -197,12 +197,13 @@ void put_qual_string(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_o
         char *w = o.p + o.n;
         if (out_offset == fastq_offset) {
             memcpy(w, ql, (size_t)L);
+            if (floor_q > 0)
             for (char *z = (char *)memchr(w, fastq_offset, (size_t)L); z; z = (char *)memchr(z, fastq_offset, (size_t)(w + L - z)))
                 *z++ = (char)(fastq_offset + 1);
         } else {
             for (int64_t i = 0; i < L; i++) {
                 int q = (int)ql[i] - fastq_offset;
-                q = q <= 0 ? 1 : q;
+                q = q <= floor_q ? floor_q : q;
                 w[i] = (char)(q + out_offset);
             }
         }
@@ -441,7 +442,8 @@ int32_t mio_py2_hash(const char *buf, const int64_t *idx, int64_t n, int32_t max
 }
 
 int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel, int32_t kind,
-                   int32_t fastq_offset, int32_t out_offset, int32_t max_len, const char *relabel, const int64_t *relabel_index,
+                   int32_t fastq_offset, int32_t out_offset, int32_t clamp_q0, int32_t max_len, const char *relabel,
+                   const int64_t *relabel_index,
                    const double *ee, const char *const *labels, const int32_t *label_id,
                    char *out, int64_t cap, int64_t *needed)
 {
@@ -480,8 +482,8 @@ int64_t mio_format(const char *buf, const int64_t *idx, const int64_t *sel, int6
         if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); }
         if (kind != MIO_FMT_FASTA) {
             const unsigned char *ql = (const unsigned char *)buf + r[MIO_QUAL_OFF];
-            if (kind == MIO_FMT_FASTQ) put_qual_string(o, ql, L, fastq_offset, out_offset);
-            else put_quals(o, ql, L, fastq_offset);
+            if (kind == MIO_FMT_FASTQ) put_qual_string(o, ql, L, fastq_offset, out_offset, clamp_q0 ? 1 : 0);
+            else put_quals(o, ql, L, fastq_offset, clamp_q0 ? 1 : 0);
             o.ch('\n');
         }
     }
@@ -625,7 +627,7 @@ int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *
 }
 
 int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t nsel, int32_t kind,
-                            int32_t fastq_offset, int32_t out_offset, const char *relabel, int32_t usearch,
+                            int32_t fastq_offset, int32_t out_offset, int32_t clamp_q0, const char *relabel, int32_t usearch,
                             const char *const *labels, const int32_t *label_id, const uint8_t *lstrip_gt,
                             char *out, int64_t cap, int64_t *needed)
 {
@@ -683,8 +685,8 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
         }
         o.ch('\n');
         if (kind != MIO_FMT_QUAL) { o.put(c->at(u.seq_off), u.len); o.ch('\n'); }
-        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); put_qual_string(o, (const unsigned char *)c->at(u.qual_off), u.len, fastq_offset, out_offset); o.ch('\n'); }
-        if (kind == MIO_FMT_QUAL) { put_quals(o, (const unsigned char *)c->at(u.qual_off), u.len, fastq_offset); o.ch('\n'); }
+        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); put_qual_string(o, (const unsigned char *)c->at(u.qual_off), u.len, fastq_offset, out_offset, clamp_q0 ? 1 : 0); o.ch('\n'); }
+        if (kind == MIO_FMT_QUAL) { put_quals(o, (const unsigned char *)c->at(u.qual_off), u.len, fastq_offset, clamp_q0 ? 1 : 0); o.ch('\n'); }
     }
     if (needed) *needed = o.n;
     if (o.n > cap) return fail(MIO_E_SPACE, "output needs %lld bytes", (long long)o.n);

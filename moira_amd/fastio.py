@@ -46,13 +46,14 @@ PROTOTYPES = {
     "mio_collapse_export": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mio_format_report": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "mio_collapse_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
+    "mio_collapse_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p,
+                                        C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mio_first_header_mismatch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "mio_fasta_qual_index": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mio_format": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                               C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_int32, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p]),
 }
 
@@ -192,7 +193,7 @@ def py2_hashes(buf, idx, max_len=0):
 
 
 def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None, relabel_index=None, ee=None,
-                   labels=None, label_id=None, out_offset=None, scratch="format"):
+                   labels=None, label_id=None, out_offset=None, scratch="format", clamp_q0=True):
     """Selected records as one bytes-like object (kind: FMT_FASTA / FMT_QUAL / FMT_FASTQ), valid until the
     next formatting call."""
     L = load()
@@ -217,7 +218,7 @@ def format_records(buf, idx, sel, kind, fastq_offset=33, max_len=0, relabel=None
     out = _scratch_u8(scratch, cap)
     needed = C.c_int64(0)
     args = (_ptr(buf), idx.ctypes.data, sel.ctypes.data, n, kind, int(fastq_offset),
-            int(fastq_offset if out_offset is None else out_offset), int(max_len),
+            int(fastq_offset if out_offset is None else out_offset), 1 if clamp_q0 else 0, int(max_len),
             relabel.encode() if relabel is not None else None,
             relabel_index.ctypes.data if relabel is not None else None,
             ee.ctypes.data if ee is not None else None,
@@ -300,7 +301,7 @@ class Collapse:
         return ee, ln, size, fl.astype(bool), aux
 
     def format(self, sel, kind, fastq_offset=33, relabel=None, usearch=False, labels=None, label_id=None,
-               lstrip_gt=None, out_offset=None):
+               lstrip_gt=None, out_offset=None, clamp_q0=True):
         sel = np.ascontiguousarray(sel, np.int64)
         n = len(sel)
         if n == 0:
@@ -313,7 +314,8 @@ class Collapse:
         if lstrip_gt is not None:
             lstrip_gt = np.ascontiguousarray(lstrip_gt, np.uint8)
         args = (self.h, sel.ctypes.data, n, kind, int(fastq_offset),
-                int(fastq_offset if out_offset is None else out_offset), relabel.encode() if relabel else None,
+                int(fastq_offset if out_offset is None else out_offset), 1 if clamp_q0 else 0,
+                relabel.encode() if relabel else None,
                 1 if usearch else 0, C.cast(lab_arr, C.c_void_p) if lab_arr is not None else None,
                 label_id.ctypes.data if label_id is not None else None,
                 lstrip_gt.ctypes.data if lstrip_gt is not None else None)

@@ -298,6 +298,9 @@ PAIRED_CASES = [
     dict(collapse=True, pipeline="USEARCH", consensus_qscore="sum", qscore_cap=0),
     dict(consensus_qscore="posterior", ambigs="disallow", trim_overlap=True),
     dict(collapse=True, maxerrors=2.0, truncate=100, min_overlap=35),
+    dict(only_contig=True, collapse=True),
+    dict(only_contig=True, output_format="fastq", truncate=110, min_overlap=30),
+    dict(only_contig=True, collapse=True, pipeline="USEARCH", relabel="ctg", min_overlap=40),
 ]
 
 
