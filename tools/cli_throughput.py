@@ -92,4 +92,5 @@ def run_paired(label, extra, env=None):
 
 run_paired("paired 2x250: contigs + filter, collapse", ["-c", "true"])
 run_paired("paired 2x250: contigs + filter, no collapse", ["-c", "false"])
+run_paired("paired 2x250: --only_contig, no collapse", ["-c", "false", "--only_contig"])
 run_paired("line parser: paired, collapse", ["-c", "true"], {"MOIRA_NO_FASTIO": "1"})
