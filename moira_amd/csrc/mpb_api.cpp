@@ -282,17 +282,16 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
 {
     if (!c->ws_small) {
         // tables (2), overflow counter, pass counter
-        const size_t bytes = 2 * align_up(sizeof(MpbTables), 256) + 512 + 2 * MPB_DPARGS_SLOT;
+        const size_t bytes = 2 * align_up(sizeof(MpbTables), 256) + 512;
         HIPCHK(hipMalloc(&c->ws_small, bytes));
         // on the context's stream, not the null stream: the stream is non-blocking, so a null-stream
-        // memset is unordered with the kernels below and can land after k_set_args has written dp_args
+        // memset is unordered with the kernels below and can land after they have written the tables
         HIPCHK(hipMemsetAsync(c->ws_small, 0, bytes, c->stream));
         char *p = (char *)c->ws_small;
         c->ws.tables = (MpbTables *)p;
         c->ws.tables2 = (MpbTables *)(p + align_up(sizeof(MpbTables), 256));
         c->ws.ovf_count = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256));
         c->ws.pass_count = (unsigned long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 256);
-        c->ws.dp_args = p + 2 * align_up(sizeof(MpbTables), 256) + 512;
         c->ws.lut = c->d_lut;
     }
     if (n <= c->ws_cap) return MPB_OK;
@@ -501,7 +500,7 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
 }
 
 // Batches of at most MPB_SMALL_N reads (the two paths cost the same at about 8 k reads): one host-to-device copy from pinned memory, one kernel (one read
-// per wave), one copy back -- the batched pipeline's ten launches and six copies cost ~160 us whatever
+// per wave), one copy back -- the batched pipeline's eight launches and six copies cost ~150 us whatever
 // the size, which is all a per-read caller (bernoulli.calculate_errors_PB) would ever see.
 #ifndef MPB_SMALL_N
 #define MPB_SMALL_N 4096

@@ -85,10 +85,8 @@ struct MpbWorkspace {
     int32_t  *ovf_count;   // [1]
     unsigned long long *pass_count;  // [1]
     const double2 *lut;    // [256] {1-p, p'} on device
-    char *dp_args;         // 2 slots of MPB_DPARGS_SLOT bytes: kernel arguments of the DP passes
 };
 
-#define MPB_DPARGS_SLOT 256
 #define MPB_LUT_BYTES   (256 * 16)
 
 // Launch wrappers (mpb_kernels.hip).  All asynchronous on `s`.

@@ -649,8 +649,8 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
     }   // tiles of this run
 }
 
-// DpArgs travel through device memory so that the non-inlined class bodies can take a pointer
-__global__ void k_set_args(DpArgs a, DpArgs *__restrict__ dst) { if (threadIdx.x == 0) *dst = a; }
+// DpArgs arrive as a kernel argument and are parked in LDS, so that the non-inlined class bodies can
+// take a pointer to them (no extra launch to put them into device memory)
 
 // One wave takes `chunk_tiles` consecutive tiles (almost always one class: one call, one save of
 // callee-saved VGPRs); chunks are dealt to blocks by the hardware dispatcher, which balances the very
@@ -659,13 +659,16 @@ __global__ void k_set_args(DpArgs a, DpArgs *__restrict__ dst) { if (threadIdx.x
 // from an upper bound that assumes one read per lane; every wave's loop ends when its chunk index
 // passes the tile count.
 template <bool FMA, bool OVERFLOW_PASS>
-__global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(const DpArgs *__restrict__ A,
+__global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(DpArgs args,
                                             const double2 *__restrict__ lut_g,
                                             MpbTables *__restrict__ tb,
                                             const int32_t *__restrict__ perm, int chunk_tiles)
 {
+    __shared__ DpArgs s_args;
     mpb_s_lut[threadIdx.x] = lut_g[threadIdx.x];
+    if (threadIdx.x == 0) s_args = args;
     __syncthreads();
+    const DpArgs *A = &s_args;
     const int total = tb->total_tiles;
     const int nchunks = (total + chunk_tiles - 1) / chunk_tiles;
     for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < nchunks; chunk += gridDim.x * 4) {
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(const DpArgs *_
 
 // ------------------------------------------------------------------------------------------
 // k_small: prediction + DP of ONE read per wave, one launch for the whole (small) batch.
-// The batched pipeline costs ten launches and a sort whatever the batch size; a caller that hands
+// The batched pipeline costs eight launches and a sort whatever the batch size; a caller that hands
 // over one read at a time (bernoulli.calculate_errors_PB from an unchanged moira.py) pays only
 // latency.  Same prediction formula, same class bodies, same results; a read whose CDF does not
 // cross inside its class is marked pass = 2 and the host sends the batch down the batched path.
@@ -931,7 +934,6 @@ void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const 
 // cap of the DP grid (blocks of 4 waves); beyond it the chunk loop strides
 #define MPB_DP_GRID (1 << 20)
 
-static_assert(sizeof(DpArgs) <= MPB_DPARGS_SLOT, "DpArgs slot too small");
 
 static DpArgs make_args(const uint8_t *q, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                         const MpbWorkspace &ws, const int32_t *ns, double *ee, uint8_t *pass, int final_pass)
@@ -956,12 +958,10 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
     int64_t want = (tiles + 4 * chunk_tiles - 1) / (4 * chunk_tiles);   // blocks if every wave took one chunk
     const int blocks = (int)(want < grid_cap ? (want > 0 ? want : 1) : grid_cap);
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 0);
-    DpArgs *dA = reinterpret_cast<DpArgs *>(ws.dp_args);
-    hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
     if (prm.flags & 2u)
-        hipLaunchKernelGGL((k_dp<true, false>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables, ws.perm, chunk_tiles);
+        hipLaunchKernelGGL((k_dp<true, false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, ws.tables, ws.perm, chunk_tiles);
     else
-        hipLaunchKernelGGL((k_dp<false, false>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables, ws.perm, chunk_tiles);
+        hipLaunchKernelGGL((k_dp<false, false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, ws.tables, ws.perm, chunk_tiles);
 }
 
 void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
@@ -975,13 +975,11 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
         if (classes[c].cap >= prm.max_len + 1) wc = c;
     hipLaunchKernelGGL(k_tables_overflow, dim3(1), dim3(64), 0, s, ws.tables2, ws.ovf_count, wc);
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 1);
-    DpArgs *dA = reinterpret_cast<DpArgs *>(ws.dp_args + MPB_DPARGS_SLOT);
-    hipLaunchKernelGGL(k_set_args, dim3(1), dim3(64), 0, s, A, dA);
     const int blocks = 256;
     if (prm.flags & 2u)
-        hipLaunchKernelGGL((k_dp<true, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list, MPB_DP_CHUNK);
+        hipLaunchKernelGGL((k_dp<true, true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, ws.tables2, ws.ovf_list, MPB_DP_CHUNK);
     else
-        hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), 0, s, dA, ws.lut, ws.tables2, ws.ovf_list, MPB_DP_CHUNK);
+        hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, ws.tables2, ws.ovf_list, MPB_DP_CHUNK);
 }
 
 void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, int32_t fixed_len,
