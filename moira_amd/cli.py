@@ -554,7 +554,7 @@ def write_results(index, header, sequence, quals, expected_errors, names_info, o
 def _open_outputs(args, output_name, binary=False):
     mode = "wb" if binary else "wt"
     if args.output_compression == "gz":
-        opener, suffix = (lambda p: gzip.open(p, mode)), ".gz"
+        opener, suffix = (lambda p: gzip.open(p, mode, compresslevel=4)), ".gz"    # same content, ~4x the speed of level 9
     elif args.output_compression == "bz2":
         opener, suffix = (lambda p: bz2.open(p, mode)), ".bz2"
     else:
