@@ -233,3 +233,54 @@ def test_reader_errors(tmp_path):
     open(fq, "w").write("@r1\nACGT\n+\nIIII\n")
     with pytest.raises(cli.NameMismatchError):
         list(cli.parse_fastq(cli.open_input(fq), cli.open_input(fq2)))
+
+
+def _config1_files(tmp_path):
+    """BASELINE configs[0]: the 1 000 synthetic single-end 250 bp reads (seed 1) as fasta + qual, with the
+    reference's own per-read results on exactly these reads (tests/golden/synth250.npz, produced by the
+    real bernoullimodule.c)."""
+    import golden_io as G
+    s = G.load_set("synth250")
+    q, lens = s["q"], s["lens"]
+    rng = np.random.default_rng(1)
+    fa, qu = [], []
+    for i in range(len(lens)):
+        L = int(lens[i])
+        row = q[i, :L]
+        seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+        seq[row == 0] = ord("N")
+        quals = np.where(row == 0, 2, row)                     # an N's quality is never looked at
+        fa.append(">s%d\n%s\n" % (i, seq.tobytes().decode()))
+        qu.append(">s%d\n%s\n" % (i, " ".join(map(str, quals))))
+    (tmp_path / "c1.fasta").write_text("".join(fa))
+    (tmp_path / "c1.qual").write_text("".join(qu))
+    ee = G.expected_value(s) + s["ns_ref"]                     # --ambigs treat_as_errors (moira.py:827-828)
+    return str(tmp_path / "c1.fasta"), str(tmp_path / "c1.qual"), ee, lens, float(s["alpha"])
+
+
+def _run_config1(tmp_path, backend):
+    fasta, qual, ee, lens, alpha = _config1_files(tmp_path)
+    out = str(tmp_path / "c1out")
+    a = reference_args(paired=False, forward_fasta=fasta, forward_qual=qual, output_prefix=out, collapse=False,
+                       pipeline="USEARCH", alpha=alpha)
+    assert cli.main(a, backend=backend, out=open(os.devnull, "w")) == 0
+    want_good = {"s%d" % i for i in range(len(ee)) if ee[i] <= lens[i] * 0.01}
+    got = {}
+    for kind in ("good", "bad"):
+        for line in open("%s.qc.%s.fasta" % (out, kind)):
+            if line.startswith(">"):
+                name, e = line[1:].split("\t")[0].split(";ee=")
+                got[name] = (kind, e.split(";")[0])
+    assert len(got) == len(ee)
+    assert {k for k, v in got.items() if v[0] == "good"} == want_good
+    for i in range(len(ee)):
+        assert got["s%d" % i][1] == "%.2f" % ee[i]              # the reference's expected errors, to the printed digits
+
+
+def test_config1_plumbing_host_logic(tmp_path, oracle):
+    _run_config1(tmp_path, oracle_backend(oracle))
+
+
+@pytest.mark.gpu
+def test_config1_plumbing_gpu(tmp_path):
+    _run_config1(tmp_path, None)
