@@ -107,7 +107,7 @@ def contigs_batch(fwd_seqs, fwd_quals, rev_seqs, rev_quals, match=1, mismatch=-1
     Returns (contigs list[str], quals int32[n, cap], lens, overlap, gaps, mismatches)."""
     L = load()
     n = len(fwd_seqs)
-    threads = threads or (os.cpu_count() or 1)
+    threads = threads or usable_cpus()
 
     def cat(seqs, quals):
         off = np.zeros(n + 1, np.int64)
@@ -139,6 +139,19 @@ def contigs_batch(fwd_seqs, fwd_quals, rev_seqs, rev_quals, match=1, mismatch=-1
     return seqs, cq, clen, ov, gaps, mism
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the cgroup quota when there is one (a GPU box hands out 16 of its
+    256 hardware threads), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 class QualityRange(Exception):
     """A quality that the byte-level contig path cannot carry (negative, or q + offset > 255)."""
 
@@ -153,7 +166,7 @@ def contigs_from_fastq(fbuf, fidx, rbuf, ridx, fastq_offset=33, match=1, mismatc
         raise ValueError('consensus_qscore must be "best", "sum" or "posterior".')
     fidx, ridx = np.ascontiguousarray(fidx), np.ascontiguousarray(ridx)
     n = len(fidx)
-    threads = threads or (os.cpu_count() or 1)
+    threads = threads or usable_cpus()
     rec_cap = int((fidx[:, 1] + 2 * (fidx[:, 3] + ridx[:, 3])).max()) + 8 if n else 8     # header + 2 x (l1 + l2)
     cbuf = np.empty(n * rec_cap, np.uint8)
     cidx = np.empty((n, 6), np.int64)

@@ -10,6 +10,8 @@
 #include "../../include/moira_io.h"      // MIO_* record-index columns
 
 #include <algorithm>
+#include <memory>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -403,10 +405,22 @@ extern "C" int mct_contigs_from_fastq(int64_t n, const char *fbuf, const int64_t
     if (threads > n && n > 0) threads = (int32_t)n;
     std::vector<int> rc(threads, MCT_OK);
     std::vector<std::string> msgs(threads);
-    auto work = [&](int t) {
+    // Scratch of worker t outlives the call: a fresh 300 KB score matrix per thread and call is mostly page
+    // faults, which do not scale over a few hundred threads.
+    struct Scratch {
         NwWork sc;
         std::vector<char> rseq, a1, a2, contig;
         std::vector<int32_t> fq, rq_raw, rq, qa, qb, cq;
+    };
+    static std::mutex pool_lock;
+    static std::vector<std::unique_ptr<Scratch>> scratch_pool;
+    std::unique_lock<std::mutex> busy(pool_lock);              // one batch at a time owns the pool
+    while ((int)scratch_pool.size() < threads) scratch_pool.emplace_back(new Scratch());
+    auto work = [&](int t) {
+        Scratch &S = *scratch_pool[t];
+        NwWork &sc = S.sc;
+        auto &rseq = S.rseq; auto &a1 = S.a1; auto &a2 = S.a2; auto &contig = S.contig;
+        auto &fq = S.fq; auto &rq_raw = S.rq_raw; auto &rq = S.rq; auto &qa = S.qa; auto &qb = S.qb; auto &cq = S.cq;
         // contiguous shares: neighbouring output slots belong to one thread
         const int64_t i0 = n * t / threads, i1 = n * (t + 1) / threads;
         for (int64_t i = i0; i < i1; i++) {

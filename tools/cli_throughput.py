@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np  # noqa: E402
 import pb_oracle as O  # noqa: E402
 from moira_amd import cli  # noqa: E402
+from moira_amd.contig import usable_cpus  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
 q, _ = O.synth_fill(n, 256, fixed_len=250, seed=1)
@@ -85,7 +86,7 @@ def run_paired(label, extra, env=None):
     keep = (path, n)
     path, n = r1, m
     try:
-        run(label, ["-rfq", r2, "--paired", "-p", str(os.cpu_count())] + extra, env)
+        run(label, ["-rfq", r2, "--paired", "-p", str(usable_cpus())] + extra, env)
     finally:
         path, n = keep
 

@@ -35,13 +35,14 @@ for tag, arr in (("R1", fwd), ("R2", rev)):
         for i in range(n):
             f.write(b"@p%d\n" % i + arr[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n")
     paths.append(p)
-threads = os.cpu_count()
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else CT.usable_cpus()
 t_index = t_contig = t_pack = t_filter = 0.0
 kept = total = 0
 with Engine(0) as eng:
     eng.filter(np.full((8, 608), 30, np.uint8), fixed_len=600)          # warm-up
     t0 = time.perf_counter()
-    it = iter(F.PairedFastqChunks(open(paths[0], "rb"), open(paths[1], "rb"), 65536))
+    chunk_pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+    it = iter(F.PairedFastqChunks(open(paths[0], "rb"), open(paths[1], "rb"), chunk_pairs, block_bytes=1 << 27))
     while True:
         t = time.perf_counter()
         chunk = next(it, None)
