@@ -54,7 +54,11 @@ extern "C" {
 
 /* flags for mpb_filter_params.flags */
 #define MPB_FLAG_ROUND      1u   /* --round: floor(ee) before the compare, ref: moira/moira.py:830-831 */
-#define MPB_FLAG_FAST_FMA   2u   /* NOT bit-exact: contract a*v+b*w into fma (|rel err| ~1e-13). Off by default. */
+#define MPB_FLAG_FAST_FMA   2u   /* contract a*v+b*w into one fma: 2 FP64 ops per cell instead of 3.  ee is then within
+                                    ~1e-13 relative of the reference instead of bit-identical (north_star allows 1e-9);
+                                    every pass/fail flag still EQUALS the exact computation's: a read whose ee lands
+                                    within 1e-9 relative of the threshold (or of an integer with MPB_FLAG_ROUND) is
+                                    recomputed with the three-rounding arithmetic.  Off by default. */
 #define MPB_FLAG_DECISION_ONLY 8u /* opt-in, NOT the reference's contract: a read whose expected errors are
                                     PROVABLY above the threshold (multiplicative Chernoff lower-tail bound on the
                                     Poisson-binomial quantile, from the prepass' mean) is reported pass = 0,

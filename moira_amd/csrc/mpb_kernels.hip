@@ -637,11 +637,25 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
             }
             const int nsv = A.perm_ns ? (int)A.perm_ns[(perm_cls - A.perm) + slot] : A.ns[idx];
             if (A.prm.ambig_mode == 0) e = e + (double)nsv;              // moira.py:827-828
+            const double limit = (A.prm.maxerrors == A.prm.maxerrors) ? A.prm.maxerrors          // moira.py:925-926
+                                                                      : (double)li * A.prm.uncert; // moira.py:949-950
+            if (FMA && A.final_pass != 1 && !never_crossed) {
+                // MPB_FLAG_FAST_FMA keeps the DECISIONS exact: an ee that lands within 1e-9 relative of the
+                // threshold (or, with --round, of an integer) is not trusted -- the read goes to the second
+                // pass, which always runs the three-rounding arithmetic
+                const double tol = 1e-9 * fmax(1.0, fabs(e));
+                bool unsure = fabs(e - limit) <= tol;
+                if (A.prm.flags & 1u) unsure = unsure || fabs(e - rint(e)) <= tol;
+                if (unsure) {
+                    if (A.final_pass == 0) { const int pos = atomicAdd(A.ovf_count, 1); A.ovf_list[pos] = idx; }
+                    else A.pass[idx] = 2;
+                    continue;
+                }
+            }
             if (A.prm.flags & 1u) e = floor(e);                          // moira.py:830-831
             bool keep_read;
             if (A.prm.ambig_mode == 2 && (A.cls[idx] & 0x80)) keep_read = false;           // moira.py:911
-            else if (A.prm.maxerrors == A.prm.maxerrors) keep_read = e <= A.prm.maxerrors; // moira.py:925-926
-            else keep_read = e <= (double)li * A.prm.uncert;                               // moira.py:949-950
+            else keep_read = e <= limit;
             A.ee[idx] = e;
             A.pass[idx] = keep_read ? 1 : 0;
         }
@@ -976,10 +990,9 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
     hipLaunchKernelGGL(k_tables_overflow, dim3(1), dim3(64), 0, s, ws.tables2, ws.ovf_count, wc);
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 1);
     const int blocks = 256;
-    if (prm.flags & 2u)
-        hipLaunchKernelGGL((k_dp<true, true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, ws.tables2, ws.ovf_list, MPB_DP_CHUNK);
-    else
-        hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, ws.tables2, ws.ovf_list, MPB_DP_CHUNK);
+    // always the three-rounding arithmetic: with MPB_FLAG_FAST_FMA this pass also settles the reads whose fma
+    // result was too close to the threshold to decide
+    hipLaunchKernelGGL((k_dp<false, true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, ws.tables2, ws.ovf_list, MPB_DP_CHUNK);
 }
 
 void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, int32_t fixed_len,

@@ -176,6 +176,29 @@ def test_fast_fma_mode_within_tolerance(eng, oracle):
     assert np.array_equal(r.passed, ps.astype(bool))
 
 
+def test_fast_fma_mode_keeps_decisions_exact_at_the_threshold(eng, oracle):
+    """Thresholds placed exactly ON reads' expected errors (ee <= maxerrors is then decided by the last
+    bit), and --round with thresholds on integers: the fma mode must still give the exact decisions."""
+    q, lens = oracle.synth_fill(6000, 320, fixed_len=300, seed=8)
+    ee0, _, _, _ = oracle.filter_batch(q, fixed_len=300, threads=8, ambigs="ignore")
+    picks = [float(x) for x in np.unique(ee0[(ee0 > 0.5) & (ee0 < 60)])[::97][:12]]
+    assert len(picks) >= 8
+    for me in picks:
+        for kw in (dict(maxerrors=me, ambigs="ignore"), dict(maxerrors=me, ambigs="ignore", round_=True)):
+            ee, ns, ps, _ = oracle.filter_batch(q, fixed_len=300, threads=8, **kw)
+            r = eng.filter(q, fixed_len=300, fast_fma=True, **kw)
+            assert np.array_equal(r.passed, ps.astype(bool)), (me, kw)
+            rel = np.abs(r.ee - ee) / np.maximum(np.abs(ee), 1e-300)
+            assert rel[ee > 0].max() <= REL_TOL
+    # uncert thresholds: L * uncert hit exactly by construction
+    for k in (10, 200, 999):
+        u = float(ee0[k] / 300.0)
+        if 0 < u <= 1:
+            ee, ns, ps, _ = oracle.filter_batch(q, fixed_len=300, threads=8, uncert=u, ambigs="ignore")
+            r = eng.filter(q, fixed_len=300, fast_fma=True, uncert=u, ambigs="ignore")
+            assert np.array_equal(r.passed, ps.astype(bool)), u
+
+
 def test_device_synth_matches_host_and_device_resident_filter(eng, oracle):
     n, stride, L = 50000, 320, 300
     d_q = eng.alloc(n * stride)
