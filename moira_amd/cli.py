@@ -906,13 +906,12 @@ def _run_fast_fastq(args, backend, o, say, t0):
                 if not len(sel):
                     continue
                 kw = dict(labels=labels if lab is not None else None, label_id=lab[sel] if lab is not None else None, **hdr)
-                if fq:
-                    main_f.write(groups.format(sel, F.FMT_FASTQ, **kw))
-                else:
-                    main_f.write(groups.format(sel, F.FMT_FASTA, **kw))
-                    qual_f.write(groups.format(sel, F.FMT_QUAL, **kw))
+                jobs = [(F.FMT_FASTQ, main_f, kw)] if fq else [(F.FMT_FASTA, main_f, kw), (F.FMT_QUAL, qual_f, kw)]
                 if names:
-                    names_f.write(groups.format(sel, F.FMT_NAMES, lstrip_gt=strip[sel], **hdr))
+                    jobs.append((F.FMT_NAMES, names_f, dict(lstrip_gt=strip[sel], **hdr)))
+                for kind, f, k in jobs:
+                    for piece in F.collapse_format_parallel(pool, threads, groups, sel, kind, **k):
+                        f.write(piece)
     finally:
         if not ok:
             emit.close(raise_errors=False)         # an exception is already on its way

@@ -301,7 +301,7 @@ class Collapse:
         return ee, ln, size, fl.astype(bool), aux
 
     def format(self, sel, kind, fastq_offset=33, relabel=None, usearch=False, labels=None, label_id=None,
-               lstrip_gt=None, out_offset=None, clamp_q0=True):
+               lstrip_gt=None, out_offset=None, clamp_q0=True, scratch="format"):
         sel = np.ascontiguousarray(sel, np.int64)
         n = len(sel)
         if n == 0:
@@ -321,15 +321,26 @@ class Collapse:
                 lstrip_gt.ctypes.data if lstrip_gt is not None else None)
         needed = C.c_int64(0)
         cap = int(self._len[sel].sum()) * (4 if kind == FMT_QUAL else 2) + n * 160
-        out = _scratch_u8("format", cap)
+        out = _scratch_u8(scratch, cap)
         w = self.lib.mio_collapse_format(*args, out.ctypes.data, cap, C.addressof(needed))
         if w == E_SPACE:
             cap = needed.value
-            out = _scratch_u8("format", cap)
+            out = _scratch_u8(scratch, cap)
             w = self.lib.mio_collapse_format(*args, out.ctypes.data, cap, C.addressof(needed))
         if w < 0:
             raise ValueError(_err())
         return memoryview(out)[:w]
+
+
+def collapse_format_parallel(pool, threads, groups, sel, kind, label_id=None, lstrip_gt=None, **kw):
+    """Collapse.format() with the selection split over `threads` calls (the object is only read)."""
+    n = len(sel)
+    if pool is None or threads <= 1 or n < PARALLEL_MIN:
+        return [groups.format(sel, kind, label_id=label_id, lstrip_gt=lstrip_gt, **kw)]
+    cut = lambda a, lo, hi: None if a is None else a[lo:hi]
+    jobs = [pool.submit(groups.format, sel[a:b], kind, label_id=cut(label_id, a, b), lstrip_gt=cut(lstrip_gt, a, b),
+                        scratch="format%d" % t, **kw) for t, (a, b) in enumerate(_parts(n, threads))]
+    return [j.result() for j in jobs]
 
 
 class FastqChunks:
