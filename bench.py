@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
-"""bench.py -- reads/s of the MI355X Poisson-binomial read filter on BASELINE.json's config.
+"""bench.py -- reads/s of the MI355X Poisson-binomial read filter on BASELINE.json's configs.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE.json configs[1] -- R = 10,000,000 synthetic single-end
-300 bp reads per GPU (row stride 320, seed 2, counter-based generator of include/mpb_synth.h,
-filled ON DEVICE so the inputs are resident in HBM when the timed region starts).  With N > 1
-every rank holds its own R reads (read ids rank*R .. rank*R+R-1: the host-side split of
-config 4), no data-path collective: weak scaling.
-A "step" = one pass of the whole hot path over the resident batch: prepass -> scan -> scatter
--> DP -> overflow pass, producing ee / Ns / pass for every read.
+Both launch shapes work for every N: started WITHOUT torchrun and with --gpus N > 1, this script
+starts `python -m torch.distributed.run ... bench.py <same args>` as a CHILD process (before anything
+in this process has touched the GPU) and exits with the child's return code.
+
+Workload (config.workload):
+  N = 1   BASELINE.json configs[1] -- 10,000,000 synthetic single-end 300 bp reads (row stride 320,
+          seed 2, counter-based generator of include/mpb_synth.h, filled ON DEVICE so the inputs are
+          resident in HBM when the timed region starts).
+  N > 1   BASELINE.json configs[3] -- "1 B synthetic 300 bp reads sharded host-side across 8 x
+          MI355X": every rank owns 125,000,000 reads (40 GB resident; read ids rank*R .. rank*R+R-1,
+          generated on its own device), no data-path collective: weak
+          scaling (N = 2, 4 are the partial node with the same per-GPU shard).
+A "step" = one pass of the whole hot path over the resident batch: prepass -> scan -> scatter ->
+DP -> overflow pass, producing ee / Ns / pass for every read.  The wall-clock region carries no
+per-kernel events; the per-kernel HIP-event timing behind `roofline` is taken in a separate pass
+right after it.  Without --steps the timed region is sized to last >= 1 s.
 
 One JSON line on rank 0.  Extra objects:
   roofline     dominant kernel (k_dp): algorithmic bytes (L + 13 per read) per launch
                / its mean duration measured with HIP events on the library's stream.
   cpu_baseline the real reference extension (oracle/_ref, kind "reference") called per read from
-               Python exactly as moira.py does with --processors 1, or the oracle's
-               reference-shaped port (kind "port"), on a bounded sample of the same reads.
+               Python exactly as moira.py does: on 1 core, and (`all_cores`) in P worker processes
+               with one contiguous shard each -- what `moira.py --processors P` amounts to --
+               P = the CPUs this box grants (cgroup quota); or the oracle's reference-shaped port
+               (kind "port") when oracle/_ref is absent.  Bounded samples of the same reads.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,14 +42,51 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK = 39.3e12       # v_mul/add_f64 lane-ops per second: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz
+CONFIG2_READS = 10_000_000     # BASELINE configs[1]
+CONFIG4_SHARD = 125_000_000    # BASELINE configs[3]: 1 B reads / 8 GPUs
 
 
-def cpu_baseline(seed, L, stride, budget_s=15.0):
-    """Time the CPU path on a bounded sample of the same workload (rank 0, N=1 only)."""
+def usable_cpus():
+    """CPUs this process may use: the cgroup quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# ---- CPU baseline (the checker's code, timed beside the GPU number; never the thing shipped) ----
+
+def _ref_worker(argv):
+    """Child process of the all-cores leg: one contiguous shard of the workload through the real reference
+    extension, one Python call per read (what a moira.py Pool worker does).  Prints one JSON line."""
+    first, n, seed, L, stride = (int(x) for x in argv)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
+    import pb_oracle as O
+    ref = O.reference_module()
+    q, _ = O.synth_fill(n, stride, fixed_len=L, seed=seed, first_read=first)
+    rows = q[:, :L]
+    seqs = ["".join("N" if v == 0 else "A" for v in r) for r in rows]
+    quals = [[int(v) if v else 20 for v in r] for r in rows]
+    sys.stdout.write("ready\n")
+    sys.stdout.flush()
+    sys.stdin.readline()                                  # common start signal
+    t0 = time.time()
+    for s, qq in zip(seqs, quals):
+        ref.calculate_errors_PB(s, qq, 0.005)
+    t1 = time.time()
+    print(json.dumps({"n": n, "t0": t0, "t1": t1}))
+
+
+def cpu_baseline(seed, L, stride, budget_s=8.0):
+    """Time the CPU path on bounded samples of the same workload (rank 0, N=1 only)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pb_oracle as O
     O.build()
+    P = usable_cpus()
     out = {}
     # port: reference-shaped loop nest, 1 thread
     probe = 2000
@@ -48,38 +97,96 @@ def cpu_baseline(seed, L, stride, budget_s=15.0):
     t = time.perf_counter(); O.filter_batch(q, fixed_len=L, shape=1, threads=1); dt = time.perf_counter() - t
     port = {"value": n_port / dt, "unit": "reads/s", "cores": 1, "kind": "port",
             "sample": "first %d reads of the workload, oracle/pb_oracle.c reference-shaped loop nest" % n_port}
+    # the same port on all granted cores (OpenMP, one contiguous shard per thread)
+    n_port_p = n_port * min(P, O.lib().pbo_max_threads())
+    qp, _ = O.synth_fill(n_port_p, stride, fixed_len=L, seed=seed)
+    pt = min(P, O.lib().pbo_max_threads())
+    t = time.perf_counter(); O.filter_batch(qp, fixed_len=L, shape=1, threads=pt); dtp = time.perf_counter() - t
+    port["all_cores"] = {"value": n_port_p / dtp, "unit": "reads/s", "cores": pt,
+                         "sample": "first %d reads, %d OpenMP threads, one contiguous shard each" % (n_port_p, pt)}
     # fast restatement on all cores (for orientation only)
-    nt = O.lib().pbo_max_threads()
-    n_fast = min(len(q), 400000)
-    t = time.perf_counter(); O.filter_batch(q[:n_fast], fixed_len=L, shape=0, threads=nt); dt = time.perf_counter() - t
-    out["cpu_fast_restatement"] = {"value": n_fast / dt, "unit": "reads/s", "cores": nt,
+    n_fast = min(len(qp), 400000)
+    t = time.perf_counter(); O.filter_batch(qp[:n_fast], fixed_len=L, shape=0, threads=pt); dt = time.perf_counter() - t
+    out["cpu_fast_restatement"] = {"value": n_fast / dt, "unit": "reads/s", "cores": pt,
                                    "note": "two-term recurrence (not the reference's algorithmic shape)"}
     ref = O.reference_module()
-    if ref is not None:
-        n_ref = int(max(500, min(200000, budget_s * 0.5 * port["value"] / 1.6)))
-        rows = q[:n_ref, :L]
-        seqs = ["".join("N" if v == 0 else "A" for v in r) for r in rows]
-        quals = [[int(v) if v else 20 for v in r] for r in rows]
-        t = time.perf_counter()
-        for s, qq in zip(seqs, quals):
-            ref.calculate_errors_PB(s, qq, 0.005)
-        dt = time.perf_counter() - t
-        out["cpu_baseline"] = {"value": n_ref / dt, "unit": "reads/s", "cores": 1, "kind": "reference",
-                               "sample": "first %d reads of the workload through oracle/_ref/bernoulli.so "
-                                         "(moira/bernoullimodule.c built unmodified), one Python call per read "
-                                         "as moira.py --processors 1 does" % n_ref}
-        out["cpu_port"] = port
-    else:
+    if ref is None:
         out["cpu_baseline"] = port
+        return out
+    n_ref = int(max(500, min(200000, budget_s * port["value"] / 1.6)))
+    rows = q[:n_ref, :L]
+    seqs = ["".join("N" if v == 0 else "A" for v in r) for r in rows]
+    quals = [[int(v) if v else 20 for v in r] for r in rows]
+    t = time.perf_counter()
+    for s, qq in zip(seqs, quals):
+        ref.calculate_errors_PB(s, qq, 0.005)
+    dt = time.perf_counter() - t
+    base = {"value": n_ref / dt, "unit": "reads/s", "cores": 1, "kind": "reference",
+            "sample": "first %d reads of the workload through oracle/_ref/bernoulli.so "
+                      "(moira/bernoullimodule.c built unmodified), one Python call per read "
+                      "as moira.py --processors 1 does" % n_ref}
+    # all granted cores: P worker processes, one contiguous shard of n_ref reads each, started together
+    procs = []
+    try:
+        for w in range(P):
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--_ref-worker",
+                                           str(w * n_ref), str(n_ref), str(seed), str(L), str(stride)],
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("reference worker failed to start")
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        res = [json.loads(p.stdout.readline()) for p in procs]
+        for p in procs:
+            p.wait(timeout=60)
+        wall = max(r["t1"] for r in res) - min(r["t0"] for r in res)
+        base["all_cores"] = {"value": sum(r["n"] for r in res) / wall, "unit": "reads/s", "cores": P,
+                             "processes": P,
+                             "sample": "first %d reads of the workload, %d worker processes with one contiguous shard "
+                                       "of %d reads each through oracle/_ref/bernoulli.so (what moira.py "
+                                       "--processors %d does, minus its per-read pickling)" % (P * n_ref, P, n_ref, P)}
+    except Exception as e:                                  # the 1-core figure stands on its own
+        base["all_cores"] = {"value": None, "cores": P, "error": repr(e)}
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out["cpu_baseline"] = base
+    out["cpu_baseline_all_cores"] = base["all_cores"]
+    out["cpu_port"] = port
     return out
 
 
+# ---- launch shape --------------------------------------------------------------------------------
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without torchrun: start the ranks as a child job and hand its exit code on.
+    Nothing in THIS process has initialised the GPU (no torch / HIP import yet)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--_ref-worker":
+        return _ref_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: as many as make the timed region >= 1 s)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 10 M at N=1 = configs[1]; "
+                                                          "125 M at N>1 = one eighth of configs[3])")
     ap.add_argument("--length", type=int, default=300)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--fast-fma", action="store_true", help="non-bit-exact FMA mode (not the headline)")
@@ -91,25 +198,27 @@ def main():
                          "collectives go over gloo; exercises the N>1 code path, not a scaling number")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            sys.exit(self_launch(args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
     import torch
     import torch.distributed as dist
     from moira_amd.engine import Engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
-        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     coll_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
+    backend = None
     if world > 1:
+        backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -120,7 +229,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    n, L = args.reads, args.length
+    def allmax(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    L = args.length
+    n = args.reads or (CONFIG2_READS if world == 1 else CONFIG4_SHARD)
     stride = args.stride or (L + 63) // 64 * 64          # 300 -> 320
     eng = Engine(local_rank)
     d_q = eng.alloc(n * stride)
@@ -132,34 +249,52 @@ def main():
         return eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass,
                                  params=params, want_counts=counts)
 
-    for _ in range(args.warmup):
+    t0 = time.perf_counter()
+    for _ in range(max(args.warmup, 1)):
         step()
     eng.synchronize()
-    eng.timing(True)
-    eng.timing_reset()
+    t_warm = (time.perf_counter() - t0) / max(args.warmup, 1)
+    steps = args.steps
+    if steps <= 0:                                        # >= 1 s of timed work, the same count on every rank
+        t1 = time.perf_counter(); step(); eng.synchronize(); t_one = time.perf_counter() - t1
+        steps = int(allmax(max(10.0, min(2000.0, 1.0 / max(min(t_one, t_warm), 1e-5) + 1))))
+    # ---- the timed region: no events, no host round trips ----
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     eng.synchronize()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = allmax(dt_local)
+    # ---- per-kernel HIP events on the library's stream, in a pass of their own ----
+    ev_steps = min(steps, 20)
+    eng.timing(True)
+    eng.timing_reset()
+    for _ in range(ev_steps):
+        step()
+    eng.synchronize()
     times = eng.kernel_times()
     eng.timing(False)
     counts = step(counts=True)
     hist = eng.class_histogram()
     # extra (NOT the headline, work is skipped by design): opt-in MPB_FLAG_DECISION_ONLY, same batch
     extras = {}
-    if not args.no_extras:
+    if not args.no_extras and rank == 0:
+        def rate(prm, reps=5, **kw):
+            a = dict(d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm)
+            a.update(kw)
+            for _ in range(2):
+                eng.filter_device(want_counts=False, **a)
+            eng.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                eng.filter_device(want_counts=False, **a)
+            eng.synchronize()
+            return (time.perf_counter() - t1) / reps
+
         prm_do = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", fast_fma=args.fast_fma, decision_only=True)
-        for _ in range(2):
-            eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_do, want_counts=False)
-        eng.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_do, want_counts=False)
-        eng.synchronize()
-        dt_do = (time.perf_counter() - t1) / 5
+        dt_do = rate(prm_do, d_q=d_q, n=n, stride=stride, fixed_len=L)
         counts_do = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_do)
         hist_do = eng.class_histogram()
         extras = {"decision_only_mode": {
@@ -171,56 +306,47 @@ def main():
             # opt-in MPB_FLAG_FAST_FMA: 2 FP64 ops per DP cell instead of 3; ee within 1e-9 relative (north_star's
             # tolerance), NOT bit-identical, so not the default and not the headline
             prm_f = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", fast_fma=True)
-            for _ in range(2):
-                eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_f, want_counts=False)
-            eng.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_f, want_counts=False)
-            eng.synchronize()
-            dt_f = (time.perf_counter() - t1) / 5
+            dt_f = rate(prm_f, d_q=d_q, n=n, stride=stride, fixed_len=L)
             c_f = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_f)
             extras["fast_fma_mode"] = {
                 "note": "opt-in MPB_FLAG_FAST_FMA (a*v + b*w contracted into one fma): ee within 1e-9 relative of the "
                         "reference instead of bit-identical; NOT the headline", "reads_per_s_this_rank": n / dt_f,
                 "ms_per_step": dt_f * 1e3, "pass": c_f.n_pass}
         # BASELINE configs[4] (ragged 50-600 bp) on the same GPU: a parity-test case, reported for reference
-        nr, sr = max(n // 2, 1), 608
+        nr, sr = max(min(n, CONFIG2_READS) // 2, 1), 608
         r_q, r_len = eng.alloc(nr * sr), eng.alloc(nr * 4)
         eng.synth_fill(r_q, nr, sr, fixed_len=0, min_len=50, max_len=600, d_len=r_len, seed=5)
-        for _ in range(2):
-            eng.filter_device(r_q, nr, sr, d_len=r_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=params, want_counts=False)
-        eng.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            eng.filter_device(r_q, nr, sr, d_len=r_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=params, want_counts=False)
-        eng.synchronize()
-        dt_r = (time.perf_counter() - t1) / 5
+        dt_r = rate(params, d_q=r_q, n=nr, stride=sr, d_len=r_len)
         extras["ragged_config5"] = {
             "note": "lengths U{50..600} in one stride-608 matrix, reads sorted by (class, length bin) on the device; "
                     "bit-exact mode; NOT the headline", "reads": nr, "reads_per_s_this_rank": nr / dt_r,
             "ms_per_step": dt_r * 1e3}
         r_q.free()
         r_len.free()
+        if world == 1:
+            extras["host_fed"] = host_fed_rate(eng, L, stride, args.seed)
 
+    per_rank = [n * steps / dt_local]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         cc = torch.tensor([counts.n_pass, counts.n_fail, counts.n_overflow], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(cc, op=dist.ReduceOp.SUM)      # the one optional collective: 24 bytes of totals
         n_pass, n_fail, n_ovf = (int(x) for x in cc.tolist())
+        pr = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        pr[rank] = per_rank[0]
+        dist.all_reduce(pr, op=dist.ReduceOp.SUM)
+        per_rank = [float(x) for x in pr.tolist()]
     else:
         n_pass, n_fail, n_ovf = counts.n_pass, counts.n_fail, counts.n_overflow
 
     if rank == 0:
-        total_reads = n * world * args.steps
+        total_reads = n * world * steps
         value = total_reads / dt
         dp_ms, dp_n = times["dp"]
         dp_avg_s = dp_ms / max(dp_n, 1) / 1e3
         alg_bytes = (L + 13) * n
         achieved = alg_bytes / dp_avg_s / 1e9 if dp_n else None
         cells = sum(cap * cnt for cap, cnt in hist.items()) * L        # DP cells one launch evaluates
+        opc = 2 if args.fast_fma else 3
         # HBM bytes of one k_dp launch from the PMC counters (collected by tools/collect_profiles.sh in
         # separate rocprofv3 passes, corrected as MI355X_MICROARCH.md prescribes); only valid for the
         # workload it was measured on
@@ -231,29 +357,50 @@ def main():
             w = t.get("workload", {})
             if (w.get("reads"), w.get("length"), w.get("seed")) == (n, L, args.seed):
                 traffic = t["hbm_bytes_per_launch"]
+        step_s = dt / steps
+        fp64_floor_ms = cells * opc / FP64_VALU_PEAK * 1e3
+        hbm40_ms = alg_bytes / (0.40 * HBM_PEAK_GBS * 1e9) * 1e3
+        if world == 1:
+            wl = ("BASELINE configs[1]: %d synthetic single-end %d bp reads, poisson_binomial filter, alpha 0.005, "
+                  "uncert 0.01, resident in HBM (uint8 %d x %d, seed %d)" % (n, L, n, stride, args.seed))
+        else:
+            wl = ("BASELINE configs[3]: %d synthetic %d bp reads sharded host-side across %d x MI355X, %d reads "
+                  "(%.1f GB resident, generated on device, read ids rank*R..) per GPU, poisson_binomial filter, "
+                  "alpha 0.005, uncert 0.01 (uint8 %d x %d per GPU, seed %d)"
+                  % (n * world, L, world, n, n * stride / 1e9, n, stride, args.seed))
         line = {
             "metric": "reads/sec filtered (300 bp synthetic)", "value": value, "unit": "reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic single-end %d bp reads per GPU, "
-                                   "poisson_binomial filter, alpha 0.005, uncert 0.01, resident in HBM "
-                                   "(uint8 %d x %d, seed %d)" % (n, L, n, stride, args.seed),
+            "config": {"workload": wl,
                        "reads_per_gpu": n, "read_length": L, "row_stride": stride,
                        "parallelism": "host-side split, %d rank(s), no data-path collective" % world,
+                       "collective_backend": ({"nccl": "RCCL", "gloo": "gloo (rehearsal)"}[backend] if backend else None),
+                       "world_size": world,
                        "mode": "fast_fma (NOT bit-exact)" if args.fast_fma else "bit-exact (no FMA)"},
+            "timed_region_s": dt,
+            "reads_per_s_per_rank": per_rank,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "bytes per k_dp launch (PMC, profiles/pmc_traffic.json)",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel": "k_dp", "avg_launch_ms": dp_avg_s * 1e3, "launches": dp_n,
-                         "algorithmic_bytes_per_read": L + 13},
-            "fp64_valu": {"cells_per_launch": cells, "ops_per_cell": 2 if args.fast_fma else 3,
-                          "achieved_ops_per_s": cells * (2 if args.fast_fma else 3) / dp_avg_s if dp_n else None,
+                         "algorithmic_bytes_per_read": L + 13,
+                         "frac_whole_step": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                         "unreachable_note": "exact (3-rounding) arithmetic makes this path FP64-VALU-issue bound, not HBM bound: "
+                                             "%.3g DP cells x %d FP64 ops / %.3g lane-op/s nominal peak = %.2f ms floor per "
+                                             "launch, vs the %.2f ms that 40 %% of the 8 TB/s HBM roof would need for these %.3g "
+                                             "algorithmic bytes; k_dp runs %.2f ms"
+                                             % (cells, opc, FP64_VALU_PEAK, fp64_floor_ms, hbm40_ms, alg_bytes, dp_avg_s * 1e3)},
+            "fp64_valu": {"cells_per_launch": cells, "ops_per_cell": opc,
+                          "achieved_ops_per_s": cells * opc / dp_avg_s if dp_n else None,
                           "peak_ops_per_s": FP64_VALU_PEAK,
-                          "frac": cells * (2 if args.fast_fma else 3) / dp_avg_s / FP64_VALU_PEAK if dp_n else None,
+                          "frac": cells * opc / dp_avg_s / FP64_VALU_PEAK if dp_n else None,
+                          "floor_ms_per_launch": fp64_floor_ms,
                           "note": "the binding roof: a scalar FP64 recurrence (SURVEY §8d)"},
-            "kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in times.items()},
+            "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in times.items()},
+            "kernel_event_pass": {"steps": ev_steps, "note": "HIP events on the library's stream, separate from the wall-clock region"},
             "outcome": {"pass": n_pass, "fail": n_fail, "overflow_reruns": n_ovf},
             "row_budget_histogram": {str(k): v for k, v in hist.items() if v},
             "extras": extras,
@@ -267,6 +414,38 @@ def main():
     for b in (d_q, d_ee, d_ns, d_pass):
         b.free()
     eng.close()
+
+
+def host_fed_rate(eng, L, stride, seed, n=3_000_000):
+    """PCIe-inclusive rate of the host-buffer entry (mpb_filter_host), never `value`: packed reads in host
+    memory in, ee / Ns / pass in host memory out, through the pinned double-buffered pipeline."""
+    import numpy as np
+    out = {"note": "mpb_filter_host on %d reads of the workload: H2D + kernels + D2H overlapped; PCIe-inclusive, "
+                   "NOT the headline" % n, "reads": n}
+    try:
+        d = eng.alloc(n * stride)
+        eng.synth_fill(d, n, stride, fixed_len=L, seed=seed)
+        for kind in ("pinned", "pageable"):
+            if kind == "pinned":
+                q = eng.host_alloc((n, stride), np.uint8)
+            else:
+                q = np.empty((n, stride), np.uint8)
+            q.reshape(-1)[:] = d.download(np.uint8, n * stride)
+            eng.filter(q[:200000], fixed_len=L)
+            best = None
+            for _ in range(3):
+                t = time.perf_counter()
+                eng.filter(q, fixed_len=L)
+                dt = time.perf_counter() - t
+                best = dt if best is None else min(best, dt)
+            out[kind + "_source"] = {"reads_per_s": n / best, "qscore_GBps": n * stride / best / 1e9}
+            if kind == "pinned":
+                eng.host_free(q)
+            del q
+        d.free()
+    except Exception as e:                                  # an extra must never cost the headline line
+        out["error"] = repr(e)
+    return out
 
 
 if __name__ == "__main__":

@@ -130,6 +130,13 @@ int mpb_free(mpb_ctx *ctx, void *dptr);
 int mpb_memcpy_h2d(mpb_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes);
 int mpb_memcpy_d2h(mpb_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes);
 int mpb_memset(mpb_ctx *ctx, void *dst_dev, int value, int64_t bytes);
+/* Pinned (page-locked) host memory.  A batch handed to mpb_filter_host from such a buffer is DMA-ed where
+ * it lies; one in ordinary pageable memory is first copied into the context's pinned staging blocks (by a few
+ * threads, overlapped with the GPU work of the chunks before).  A parser that packs its reads straight into a
+ * pinned matrix (ref: moira/moira.py:1177 builds one Python list per read instead) saves that copy.
+ * mpb_host_free waits for the context's streams first. */
+int mpb_host_alloc(mpb_ctx *ctx, int64_t bytes, void **hptr_out);
+int mpb_host_free(mpb_ctx *ctx, void *hptr);
 
 /* ---- packing (host, integer only) ---------------------------------------- */
 /* Encode one read into a row of the quality matrix.
@@ -187,11 +194,17 @@ int mpb_filter_device(mpb_ctx *ctx,
                       mpb_filter_counts *counts);
 
 /*
- * Same for a batch in HOST memory: copies it in (in chunks of <= 1 GiB of qualities), runs the
- * kernels, writes host outputs; synchronous.  Replaces the per-read Pool.apply_async dispatch
- * + .get() barrier of ref: moira/moira.py:431-454.  Batches of <= 4096 reads take one launch
- * with one read per wave (what a per-read caller needs is latency; MPB_FLAG_BATCHED_ONLY forces
- * the batched pipeline); results are identical either way.
+ * Same for a batch in HOST memory; synchronous (results are in the caller's arrays on return).
+ * Replaces the per-read Pool.apply_async dispatch + .get() barrier of ref: moira/moira.py:431-454
+ * with a chunked, double-buffered pipeline: the batch is cut into chunks of <= 128 MiB of qualities
+ * (at least four per batch where it is large enough) and the host-to-device copy of chunk k+1, the kernels
+ * of chunk k and the device-to-host copy of chunk k-1 run concurrently on three streams through three
+ * pinned/device slots.  Inputs in pinned memory (mpb_host_alloc) are copied by DMA from where they lie.
+ * Batches of <= 4096 reads take one launch with one read per wave (what a per-read caller needs is
+ * latency; MPB_FLAG_BATCHED_ONLY forces the batched pipeline); results are identical either way.
+ * Lengths are validated, never clamped: a len[i] < 0, > row_stride or > 1023 fails the call with
+ * MPB_E_INVALID before anything is computed (mpb_filter_device, whose lengths live on the device, reports
+ * the same condition from a device-side counter when `counts` is requested).
  */
 int mpb_filter_host(mpb_ctx *ctx,
                     const uint8_t *q, int64_t n, int64_t row_stride,

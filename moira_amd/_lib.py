@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmoira_pb.so")
 
+MAX_LEN = 1023      # MPB_MAX_LEN (csrc/mpb_internal.h): longest read the DP classes cover
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_RANGE = 0, -1, -2, -3, -4, -5
 AMBIG = {"treat_as_errors": 0, "ignore": 1, "disallow": 2}
 FLAG_ROUND, FLAG_FAST_FMA, FLAG_TEST_UNDERPREDICT, FLAG_DECISION_ONLY, FLAG_BATCHED_ONLY = 1, 2, 4, 8, 16
@@ -50,6 +51,8 @@ PROTOTYPES = {
     "mpb_memcpy_h2d": (C.c_int, [_VP, _VP, _VP, C.c_int64]),
     "mpb_memcpy_d2h": (C.c_int, [_VP, _VP, _VP, C.c_int64]),
     "mpb_memset": (C.c_int, [_VP, _VP, C.c_int, C.c_int64]),
+    "mpb_host_alloc": (C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
+    "mpb_host_free": (C.c_int, [_VP, _VP]),
     "mpb_pack_read": (C.c_int, [C.c_char_p, _VP, C.c_int32, _VP, C.c_int32]),
     "mpb_pack_read_ascii": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, _VP, C.c_int32]),
     "mpb_pack_batch_ascii": (C.c_int, [C.c_char_p, C.c_char_p, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _VP, _VP]),

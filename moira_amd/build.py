@@ -24,7 +24,7 @@ DEPS = SOURCES + [os.path.join(CSRC, "mpb_internal.h"),
                   os.path.join(ROOT, "include", "mpb_synth.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
-         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function",
          "-x", "hip"]
 
 

@@ -11,8 +11,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #define MPB_VERSION_STR "moira_pb 0.1.0 (gfx950)"
@@ -38,10 +41,25 @@ static int fail(int code, const char *fmt, ...)
 
 struct TimedSpan { int kid; hipEvent_t a, b; };
 
+// One of the MPB_HOST_SLOTS chunk buffers of the host pipeline (mpb_filter_host): a device block
+// (q | len | ee | ns | pass), a pinned staging block for inputs that arrive in pageable memory, a pinned
+// block the outputs land in, and the three events that hand the chunk from stream to stream.
+#define MPB_HOST_SLOTS 3
+struct HostSlot {
+    void *dev = nullptr;      int64_t dev_cap = 0;
+    void *pin_in = nullptr;   int64_t pin_in_cap = 0;
+    void *pin_out = nullptr;  int64_t pin_out_cap = 0;
+    hipEvent_t h2d_done = nullptr, k_done = nullptr, d2h_done = nullptr;
+    int64_t off = -1, m = 0;  // chunk in flight (off < 0: none)
+};
+
 struct mpb_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;
+    hipStream_t stream = nullptr;        // kernels (and every call that is not the host pipeline)
+    hipStream_t copy_stream = nullptr;   // host pipeline: H2D of the next chunk
+    hipStream_t out_stream = nullptr;    // host pipeline: D2H of the previous chunk
+    HostSlot slot[MPB_HOST_SLOTS];
+    int copy_threads = 1;
     double2 *d_lut = nullptr;
     // workspace, grown on demand
     int64_t ws_cap = 0;
@@ -63,6 +81,39 @@ struct mpb_ctx {
     void *pin_host = nullptr;
     int64_t pin_cap = 0;
 };
+
+// Threads that copy a pageable input chunk into its pinned staging block: half of the CPUs this process is
+// granted (cgroup quota, else the affinity mask), at most 8 -- one memcpy stream does not saturate PCIe 5.
+static int staging_threads()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64]; long long period = 0;
+        if (fscanf(f, "%63s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const int q = (int)((atoll(quota) + period / 2) / period);
+            if (q >= 1 && q < n) n = q;
+        }
+        fclose(f);
+    }
+    n = n / 2;
+    return n < 1 ? 1 : (n > 8 ? 8 : n);
+}
+
+static void parallel_copy(void *dst, const void *src, size_t bytes, int threads)
+{
+    if (threads <= 1 || bytes < (size_t)(8u << 20)) { memcpy(dst, src, bytes); return; }
+    const size_t per = ((bytes + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) {
+        const size_t lo = per * (size_t)t;
+        if (lo >= bytes) break;
+        const size_t len = bytes - lo < per ? bytes - lo : per;
+        th.emplace_back([=] { memcpy((char *)dst + lo, (const char *)src + lo, len); });
+    }
+    memcpy(dst, src, bytes < per ? bytes : per);
+    for (auto &t : th) t.join();
+}
 
 extern "C" {
 
@@ -110,6 +161,13 @@ int mpb_create(int device_id, mpb_ctx **out)
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking);
+    for (int k = 0; k < MPB_HOST_SLOTS && e == hipSuccess; k++) {
+        e = hipEventCreateWithFlags(&c->slot[k].h2d_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[k].k_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[k].d2h_done, hipEventDisableTiming);
+    }
+    c->copy_threads = staging_threads();
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 256 * sizeof(double2));
     if (e == hipSuccess) {
         double2 h[256];
@@ -131,6 +189,16 @@ int mpb_destroy(mpb_ctx *c)
     if (!c) return MPB_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->out_stream) (void)hipStreamSynchronize(c->out_stream);
+    for (auto &sl : c->slot) {
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.pin_in) (void)hipHostFree(sl.pin_in);
+        if (sl.pin_out) (void)hipHostFree(sl.pin_out);
+        if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
+        if (sl.k_done) (void)hipEventDestroy(sl.k_done);
+        if (sl.d2h_done) (void)hipEventDestroy(sl.d2h_done);
+    }
     for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->ws_block) (void)hipFree(c->ws_block);
@@ -141,6 +209,7 @@ int mpb_destroy(mpb_ctx *c)
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
     delete c;
     return MPB_OK;
 }
@@ -281,7 +350,7 @@ static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 static int ensure_workspace(mpb_ctx *c, int64_t n)
 {
     if (!c->ws_small) {
-        // tables (2), overflow counter, pass counter
+        // tables (2), overflow counter, bad-length counter, pass counter, overflow total of a host-pipeline call
         const size_t bytes = 2 * align_up(sizeof(MpbTables), 256) + 512;
         HIPCHK(hipMalloc(&c->ws_small, bytes));
         // on the context's stream, not the null stream: the stream is non-blocking, so a null-stream
@@ -291,7 +360,9 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
         c->ws.tables = (MpbTables *)p;
         c->ws.tables2 = (MpbTables *)(p + align_up(sizeof(MpbTables), 256));
         c->ws.ovf_count = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256));
+        c->ws.bad_len = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256) + 64);
         c->ws.pass_count = (unsigned long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 256);
+        c->ws.ovf_total = (long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 320);
         c->ws.lut = c->d_lut;
     }
     if (n <= c->ws_cap) return MPB_OK;
@@ -464,10 +535,18 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     if (counts) {
         mpb_launch_count(d_pass, n, c->ws, s);
         unsigned long long np = 0;
-        int32_t novf = 0;
+        int32_t novf = 0, bad = 0;
         HIPCHK(hipMemcpyAsync(&np, c->ws.pass_count, sizeof(np), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(&novf, c->ws.ovf_count, sizeof(novf), hipMemcpyDeviceToHost, s));
+        if (d_len) HIPCHK(hipMemcpyAsync(&bad, c->ws.bad_len, sizeof(bad), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (bad) {
+            // a length in d_len was negative or above max_len: the kernels clamped it to stay inside the row, so
+            // those reads' results are not the reference's -- the call fails (sticky until a call reports it)
+            HIPCHK(hipMemsetAsync(c->ws.bad_len, 0, sizeof(int32_t), s));
+            return fail(MPB_E_INVALID, "%d read length(s) in d_len outside 0..%d (row_stride %lld; reads longer than %d bases "
+                        "are not supported)", bad, max_len, (long long)row_stride, MPB_MAX_LEN);
+        }
         counts->n_pass = (int64_t)np;
         counts->n_fail = n - (int64_t)np;
         counts->n_overflow = novf;
@@ -504,6 +583,11 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
 // the size, which is all a per-read caller (bernoulli.calculate_errors_PB) would ever see.
 #ifndef MPB_SMALL_N
 #define MPB_SMALL_N 4096
+#endif
+// qualities per chunk of the host pipeline: large enough that a chunk's launch sequence (~0.2 ms fixed) is
+// noise beside its 2 ms of PCIe time, small enough that three slots stay below half a GiB
+#ifndef MPB_HOST_CHUNK_BYTES
+#define MPB_HOST_CHUNK_BYTES (128ll << 20)
 #endif
 
 static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
@@ -554,6 +638,164 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
     return MPB_OK;
 }
 
+// ---- host pipeline (SURVEY a-9: chunked batch, async H2D / compute / D2H) ------------------------
+//
+// Three streams, MPB_HOST_SLOTS chunk slots.  Chunk k (slot k % 3):
+//   copy_stream : H2D of its qualities (+ lengths)            -> h2d_done
+//   stream      : waits h2d_done, the five kernels of the pass -> k_done
+//   out_stream  : waits k_done, D2H of ee / Ns / pass          -> d2h_done
+// so that the H2D of chunk k+1 and the D2H of chunk k-1 run beside the kernels of chunk k.  A slot is
+// reused only after its previous chunk's d2h_done (which implies its kernels and its H2D are done).
+// Inputs in pinned host memory (mpb_host_alloc, or registered by the caller) are DMA-ed where they lie;
+// pageable inputs are first copied into the slot's pinned staging block by `copy_threads` threads, which
+// happens while the GPU is busy with the chunks before.  Outputs always land in the slot's pinned block and
+// are copied out when the slot is retired (13 bytes per read).
+
+static bool is_pinned_host(const void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return false;
+    hipPointerAttribute_t a;
+    const void *ends[2] = {p, (const char *)p + bytes - 1};
+    for (const void *e : ends) {
+        memset(&a, 0, sizeof(a));
+        if (hipPointerGetAttributes(&a, e) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+static int grow_block(void **p, int64_t *cap, int64_t bytes, bool pinned)
+{
+    if (bytes <= *cap) return MPB_OK;
+    if (*p) { HIPCHK(pinned ? hipHostFree(*p) : hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIPCHK(pinned ? hipHostMalloc(p, (size_t)bytes, hipHostMallocDefault) : hipMalloc(p, (size_t)bytes));
+    *cap = bytes;
+    return MPB_OK;
+}
+
+struct ChunkLayout { int64_t q, len, ee, ns, pass, in_bytes, out_bytes; };
+
+static ChunkLayout chunk_layout(int64_t m, int64_t row_stride)
+{
+    ChunkLayout L;
+    L.q = align_up(m * row_stride, 256); L.len = align_up(m * 4, 256);
+    L.ee = align_up(m * 8, 256); L.ns = align_up(m * 4, 256); L.pass = align_up(m, 256);
+    L.in_bytes = L.q + L.len; L.out_bytes = L.ee + L.ns + L.pass;
+    return L;
+}
+
+static void drain_pipeline(mpb_ctx *c)
+{
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->out_stream);
+    for (auto &sl : c->slot) sl.off = -1;
+}
+
+// wait for the chunk parked in `sl` and hand its results to the caller's arrays
+static int retire_slot(mpb_ctx *c, HostSlot &sl, int64_t cap_reads, int64_t row_stride, double *ee, int32_t *ns,
+                       uint8_t *pass, int64_t *n_pass)
+{
+    if (sl.off < 0) return MPB_OK;
+    HIPCHK(hipEventSynchronize(sl.d2h_done));
+    const ChunkLayout L = chunk_layout(cap_reads, row_stride);
+    const char *h = (const char *)sl.pin_out;
+    memcpy(ee + sl.off, h, (size_t)(sl.m * 8));
+    memcpy(ns + sl.off, h + L.ee, (size_t)(sl.m * 4));
+    const uint8_t *hp = (const uint8_t *)(h + L.ee + L.ns);
+    memcpy(pass + sl.off, hp, (size_t)sl.m);
+    int64_t np = 0;
+    for (int64_t i = 0; i < sl.m; i++) np += hp[i];
+    *n_pass += np;
+    sl.off = -1;
+    return MPB_OK;
+}
+
+static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
+                                int32_t fixed_len, const mpb_filter_params *params, double *ee, int32_t *ns,
+                                uint8_t *pass, mpb_filter_counts *counts)
+{
+    // chunk: at most MPB_HOST_CHUNK_BYTES of qualities, and at least four chunks per batch where the batch
+    // is large enough for a chunk to be worth a launch sequence (overlap needs more than one chunk)
+    int64_t chunk = (int64_t)MPB_HOST_CHUNK_BYTES / row_stride;
+    if (chunk > (n + 3) / 4) chunk = (n + 3) / 4;
+    if (chunk < 16384) chunk = 16384;
+    if (chunk > n) chunk = n;
+    const ChunkLayout L = chunk_layout(chunk, row_stride);
+    const bool q_pinned = is_pinned_host(q, (size_t)(n * row_stride));
+    const bool len_pinned = len && is_pinned_host(len, (size_t)(n * 4));
+    const int64_t nchunks = (n + chunk - 1) / chunk;
+    const int nslots = (int)(nchunks < MPB_HOST_SLOTS ? nchunks : MPB_HOST_SLOTS);
+    int rc = ensure_workspace(c, chunk);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < nslots; k++) {
+        HostSlot &sl = c->slot[k];
+        sl.off = -1;
+        if ((rc = grow_block(&sl.dev, &sl.dev_cap, L.in_bytes + L.out_bytes, false))) return rc;
+        if ((rc = grow_block(&sl.pin_out, &sl.pin_out_cap, L.out_bytes, true))) return rc;
+        if (!(q_pinned && (!len || len_pinned)))
+            if ((rc = grow_block(&sl.pin_in, &sl.pin_in_cap, L.in_bytes, true))) return rc;
+    }
+    HIPCHK(hipMemsetAsync(c->ws.ovf_total, 0, sizeof(long long), c->stream));
+    int64_t n_pass = 0;
+    int64_t k = 0;
+    for (int64_t off = 0; off < n; off += chunk, k++) {
+        const int64_t m = (n - off < chunk) ? n - off : chunk;
+        HostSlot &sl = c->slot[k % MPB_HOST_SLOTS];
+        if ((rc = retire_slot(c, sl, chunk, row_stride, ee, ns, pass, &n_pass))) { drain_pipeline(c); return rc; }
+        char *d = (char *)sl.dev;
+        uint8_t *d_q = (uint8_t *)d;
+        int32_t *d_len = (int32_t *)(d + L.q);
+        double *d_ee = (double *)(d + L.in_bytes);
+        int32_t *d_ns = (int32_t *)(d + L.in_bytes + L.ee);
+        uint8_t *d_pass = (uint8_t *)(d + L.in_bytes + L.ee + L.ns);
+        // ---- H2D ----
+        const uint8_t *src_q = q + off * row_stride;
+        if (!q_pinned) {
+            parallel_copy(sl.pin_in, src_q, (size_t)(m * row_stride), c->copy_threads);
+            src_q = (const uint8_t *)sl.pin_in;
+        }
+        hipError_t e = hipMemcpyAsync(d_q, src_q, (size_t)(m * row_stride), hipMemcpyHostToDevice, c->copy_stream);
+        if (e == hipSuccess && len) {
+            const int32_t *src_len = len + off;
+            if (!len_pinned) {
+                memcpy((char *)sl.pin_in + L.q, src_len, (size_t)(m * 4));
+                src_len = (const int32_t *)((char *)sl.pin_in + L.q);
+            }
+            e = hipMemcpyAsync(d_len, src_len, (size_t)(m * 4), hipMemcpyHostToDevice, c->copy_stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(sl.h2d_done, c->copy_stream);
+        // ---- kernels ----
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, sl.h2d_done, 0);
+        if (e != hipSuccess) { drain_pipeline(c); return fail(MPB_E_HIP, "host pipeline (H2D): %s", hipGetErrorString(e)); }
+        rc = mpb_filter_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, params, d_ee, d_ns, d_pass, nullptr);
+        if (rc) { drain_pipeline(c); return rc; }
+        e = hipEventRecord(sl.k_done, c->stream);
+        // ---- D2H ----
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->out_stream, sl.k_done, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(sl.pin_out, d + L.in_bytes, (size_t)(L.ee + L.ns + align_up(m, 256)),
+                                                hipMemcpyDeviceToHost, c->out_stream);
+        if (e == hipSuccess) e = hipEventRecord(sl.d2h_done, c->out_stream);
+        if (e != hipSuccess) { drain_pipeline(c); return fail(MPB_E_HIP, "host pipeline (D2H): %s", hipGetErrorString(e)); }
+        sl.off = off; sl.m = m;
+    }
+    // retire what is still in flight, oldest first
+    for (int64_t j = k; j < k + MPB_HOST_SLOTS; j++)
+        if ((rc = retire_slot(c, c->slot[j % MPB_HOST_SLOTS], chunk, row_stride, ee, ns, pass, &n_pass))) { drain_pipeline(c); return rc; }
+    long long ovf = 0;
+    int32_t bad = 0;
+    HIPCHK(hipMemcpyAsync(&ovf, c->ws.ovf_total, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&bad, c->ws.bad_len, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (bad) {
+        HIPCHK(hipMemsetAsync(c->ws.bad_len, 0, sizeof(int32_t), c->stream));
+        return fail(MPB_E_INVALID, "%d read length(s) outside 0..%d", bad, MPB_MAX_LEN);
+    }
+    if (counts) { counts->n_reads = n; counts->n_pass = n_pass; counts->n_fail = n - n_pass; counts->n_overflow = ovf; }
+    return MPB_OK;
+}
+
 int mpb_filter_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
                     int32_t fixed_len, const mpb_filter_params *params, double *ee, int32_t *ns,
                     uint8_t *pass, mpb_filter_counts *counts)
@@ -563,43 +805,43 @@ int mpb_filter_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride,
     if (rc) return rc;
     if (n < 0) return fail(MPB_E_INVALID, "n < 0");
     if (row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "row_stride must be a positive multiple of 16");
+    if (row_stride > MPB_MAX_LEN + 1) return fail(MPB_E_INVALID, "row_stride %lld exceeds %d (reads longer than %d bases are not supported)", (long long)row_stride, MPB_MAX_LEN + 1, MPB_MAX_LEN);
     if (n > 0 && (!q || !ee || !ns || !pass)) return fail(MPB_E_INVALID, "NULL host buffer");
-    if (n > 0 && n <= MPB_SMALL_N && !(params->flags & MPB_FLAG_BATCHED_ONLY) && row_stride <= MPB_MAX_LEN + 1 &&
-        (len || (fixed_len >= 0 && fixed_len <= row_stride && fixed_len <= MPB_MAX_LEN))) {
+    if (!len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len %d does not fit row_stride %lld", fixed_len, (long long)row_stride);
+    if (!len && fixed_len > MPB_MAX_LEN) return fail(MPB_E_INVALID, "reads longer than %d bases are not supported", MPB_MAX_LEN);
+    if (len) {
+        // a length is never clamped silently: the reference scores every base it is given
+        const int64_t lim = row_stride < MPB_MAX_LEN ? row_stride : MPB_MAX_LEN;
+        for (int64_t i = 0; i < n; i++)
+            if (len[i] < 0 || len[i] > lim)
+                return fail(MPB_E_INVALID, len[i] > row_stride || len[i] < 0 ? "read %lld: length %d does not fit the %lld-byte row"
+                                                                             : "read %lld: %d bases; reads longer than 1023 bases are not supported (row of %lld bytes)",
+                            (long long)i, len[i], (long long)row_stride);
+    }
+    if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
+    if (n == 0) return MPB_OK;
+    if (n <= MPB_SMALL_N && !(params->flags & MPB_FLAG_BATCHED_ONLY)) {
         bool done = false;
         rc = filter_host_small(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts, &done);
         if (rc || done) return rc;
     }
-    mpb_filter_counts total = {n, 0, 0, 0};
-    // chunk so that the staging area stays bounded (<= ~1 GiB of qualities per chunk)
-    int64_t chunk = (int64_t)(1ll << 30) / row_stride;
-    if (chunk < 1024) chunk = 1024;
-    if (chunk > n) chunk = n;
-    if (n > 0) {
-        const int64_t per_read = row_stride + 4 + 8 + 4 + 1;
-        rc = ensure_stage(c, align_up(chunk * per_read + 8 * 256, 256));
-        if (rc) return rc;
-    }
-    for (int64_t off = 0; off < n; off += chunk) {
-        const int64_t m = (n - off < chunk) ? n - off : chunk;
-        char *p = (char *)c->stage_dev;
-        uint8_t *d_q = (uint8_t *)p;   p += align_up(m * row_stride, 256);
-        double *d_ee = (double *)p;    p += align_up(m * 8, 256);
-        int32_t *d_len = (int32_t *)p; p += align_up(m * 4, 256);
-        int32_t *d_ns = (int32_t *)p;  p += align_up(m * 4, 256);
-        uint8_t *d_pass = (uint8_t *)p;
-        HIPCHK(hipMemcpyAsync(d_q, q + off * row_stride, (size_t)(m * row_stride), hipMemcpyHostToDevice, c->stream));
-        if (len) HIPCHK(hipMemcpyAsync(d_len, len + off, (size_t)(m * 4), hipMemcpyHostToDevice, c->stream));
-        mpb_filter_counts cc;
-        rc = mpb_filter_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, params, d_ee, d_ns, d_pass, &cc);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(ee + off, d_ee, (size_t)(m * 8), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(ns + off, d_ns, (size_t)(m * 4), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(pass + off, d_pass, (size_t)m, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        total.n_pass += cc.n_pass; total.n_fail += cc.n_fail; total.n_overflow += cc.n_overflow;
-    }
-    if (counts) *counts = total;
+    return filter_host_pipeline(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts);
+}
+
+int mpb_host_alloc(mpb_ctx *c, int64_t bytes, void **hptr_out)
+{
+    CTXCHK(c);
+    if (!hptr_out || bytes < 0) return fail(MPB_E_INVALID, "mpb_host_alloc: bad arguments");
+    *hptr_out = nullptr;
+    HIPCHK(hipHostMalloc(hptr_out, bytes > 0 ? (size_t)bytes : 16, hipHostMallocDefault));
+    return MPB_OK;
+}
+
+int mpb_host_free(mpb_ctx *c, void *hptr)
+{
+    CTXCHK(c);
+    drain_pipeline(c);
+    if (hptr) HIPCHK(hipHostFree(hptr));
     return MPB_OK;
 }
 
@@ -665,11 +907,10 @@ int mpb_poisson_lambda_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t
 
 // float(math.factorial(j)) for j = 0..170: exact up to 22!, correctly rounded above (built from
 // the exact integer with round-half-even on first use).
-static const double *factorial_table()
-{
-    static double tab[171];
-    static bool init = false;
-    if (!init) {
+struct FactorialTable {
+    double tab[171];
+    FactorialTable()
+    {
         // exact big-integer product in base 2^32, then correctly rounded conversion
         std::vector<uint32_t> big(1, 1u);
         tab[0] = 1.0;
@@ -696,9 +937,15 @@ static const double *factorial_table()
             tab[j] = ldexp((double)mant, nbits > 53 ? (int)(nbits - 53) : 0);
             if (nbits <= 53) tab[j] = (double)mant / ldexp(1.0, (int)(53 - nbits));
         }
-        init = true;
     }
-    return tab;
+};
+
+static const double *factorial_table()
+{
+    // function-local static object: initialised once, thread-safe (C++11 magic static) -- contexts on different
+    // threads may reach the Poisson path for the first time concurrently
+    static const FactorialTable t;
+    return t.tab;
 }
 
 // ref: moira/moira.py:1666-1679 -- one read

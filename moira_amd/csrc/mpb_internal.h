@@ -51,7 +51,6 @@ struct MpbTables {
     int32_t perm_base[MPB_NCLS + 1];  // first slot of the class in perm[]
     int32_t tile_start[MPB_NCLS + 1]; // first tile of the class (tiles ordered widest class first)
     int32_t total_tiles;
-    int32_t next_chunk;               // reserved
     int32_t kcount[MPB_SKEYS];        // reads per sort key (class * bins + bin)
     int32_t key_base[MPB_SKEYS];      // first slot of the key in perm[]
 };
@@ -83,6 +82,8 @@ struct MpbWorkspace {
     MpbTables *tables2;    // overflow pass
     int32_t  *ovf_list;    // [n]
     int32_t  *ovf_count;   // [1]
+    int32_t  *bad_len;     // [1] lengths in d_len outside 0..max_len seen by the prepass (sticky; the host reports and clears it)
+    long long *ovf_total;  // [1] overflow re-runs summed over the chunks of one host-pipeline call
     unsigned long long *pass_count;  // [1]
     const double2 *lut;    // [256] {1-p, p'} on device
 };

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                                                  int32_t *__restrict__ blockhist,
                                                  int32_t *__restrict__ ns_out,
                                                  double *__restrict__ ee_out,
-                                                 uint8_t *__restrict__ pass_out)
+                                                 uint8_t *__restrict__ pass_out,
+                                                 int32_t *__restrict__ bad_len)
 {
     __shared__ float2 s_tab[256];
     __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts}
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             const float4 e = s_row[w][lane];
             const float mu = e.x, var = e.y, k3 = e.z;
             const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
+            if (RAGGED && li != len[i]) atomicAdd(bad_len, 1);            // never clamped silently: the host fails the call
             const int ambi = (int)e.w;                                    // exact: integer-valued float < 2^24
             const int nzero = ambi & 1023, n255 = ambi >> 10;
             // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
@@ -313,17 +315,17 @@ __global__ void k_tables(MpbTables *__restrict__ tb, int nb, int32_t *__restrict
     }
     tb->tile_start[MPB_NCLS] = t;
     tb->total_tiles = t;
-    tb->next_chunk = 0;
     *ovf_count = 0;
     *pass_count = 0ull;
 }
 
 // overflow pass: every listed read goes to one class `wc`
 __global__ void k_tables_overflow(MpbTables *__restrict__ tb, const int32_t *__restrict__ ovf_count,
-                                  int wc)
+                                  int wc, long long *__restrict__ ovf_total)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int cnt = *ovf_count;
+    *ovf_total += cnt;
     const int rpt = 64 / c_classes[wc].G;
     // class c owns tiles [tile_start[c], tile_start[c] + tiles(count[c])); only wc is non-empty
     for (int c = 0; c <= MPB_NCLS; c++) {
@@ -332,7 +334,6 @@ __global__ void k_tables_overflow(MpbTables *__restrict__ tb, const int32_t *__r
         tb->tile_start[c] = 0;
     }
     tb->total_tiles = (cnt + rpt - 1) / rpt;
-    tb->next_chunk = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -921,10 +922,10 @@ void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32
 {
     if (len)
         hipLaunchKernelGGL((k_prepass<true>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm,
-                           ws.cls, ws.blockhist, ns_out, ee_out, pass_out);
+                           ws.cls, ws.blockhist, ns_out, ee_out, pass_out, ws.bad_len);
     else
         hipLaunchKernelGGL((k_prepass<false>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm,
-                           ws.cls, ws.blockhist, ns_out, ee_out, pass_out);
+                           ws.cls, ws.blockhist, ns_out, ee_out, pass_out, ws.bad_len);
 }
 
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s)
@@ -967,8 +968,13 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
     // (64 reads per tile) plus one partial tile per class.  Classes with G > 1 have more tiles
     // per read; the kernel's tile loop is grid-strided, so they are still covered.
     const int64_t tiles = (n + 63) / 64 + MPB_NCLS;
-    static const int chunk_tiles = getenv("MPB_DP_CHUNK") ? atoi(getenv("MPB_DP_CHUNK")) : MPB_DP_CHUNK;   // tuning knobs
+#ifdef MPB_TUNING_KNOBS          // experiment builds only (tools/): never in the shipped library
+    static const int chunk_tiles = getenv("MPB_DP_CHUNK") ? atoi(getenv("MPB_DP_CHUNK")) : MPB_DP_CHUNK;
     static const int grid_cap = getenv("MPB_DP_GRID") ? atoi(getenv("MPB_DP_GRID")) : MPB_DP_GRID;
+#else
+    constexpr int chunk_tiles = MPB_DP_CHUNK;
+    constexpr int grid_cap = MPB_DP_GRID;
+#endif
     int64_t want = (tiles + 4 * chunk_tiles - 1) / (4 * chunk_tiles);   // blocks if every wave took one chunk
     const int blocks = (int)(want < grid_cap ? (want > 0 ? want : 1) : grid_cap);
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 0);
@@ -987,7 +993,7 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
     int wc = MPB_NCLS - 1;
     for (int c = MPB_NCLS - 1; c >= 0; c--)
         if (classes[c].cap >= prm.max_len + 1) wc = c;
-    hipLaunchKernelGGL(k_tables_overflow, dim3(1), dim3(64), 0, s, ws.tables2, ws.ovf_count, wc);
+    hipLaunchKernelGGL(k_tables_overflow, dim3(1), dim3(64), 0, s, ws.tables2, ws.ovf_count, wc, ws.ovf_total);
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 1);
     const int blocks = 256;
     // always the three-rounding arithmetic: with MPB_FLAG_FAST_FMA this pass also settles the reads whose fma

@@ -68,9 +68,13 @@ class Engine:
         L.check(self.lib.mpb_create(int(device), C.byref(ctx)))
         self.ctx = ctx
         self.device = int(device)
+        self._pinned = {}
 
     def close(self):
         if getattr(self, "ctx", None):
+            for p in list(getattr(self, "_pinned", {}).values()):
+                self.lib.mpb_host_free(self.ctx, p)
+            self._pinned = {}
             self.lib.mpb_destroy(self.ctx)
             self.ctx = None
 
@@ -103,6 +107,24 @@ class Engine:
     # ---- memory -----------------------------------------------------------------------------
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def host_alloc(self, shape, dtype=np.uint8):
+        """A numpy array over PINNED host memory (mpb_host_alloc): `filter()` DMA-s such a batch from where it
+        lies instead of staging it.  Release it with host_free() (or with the engine)."""
+        shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        L.check(self.lib.mpb_host_alloc(self.ctx, nbytes, C.byref(p)))
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data, None)
+        if p is not None and self.ctx:
+            L.check(self.lib.mpb_host_free(self.ctx, p))
 
     def synchronize(self):
         L.check(self.lib.mpb_synchronize(self.ctx))
@@ -185,6 +207,8 @@ class Engine:
                 raise ValueError("lens must have one entry per read")
             if n and (lens.min() < 0 or lens.max() > stride):
                 raise ValueError("a length does not fit the row stride")
+            if n and lens.max() > L.MAX_LEN:
+                raise ValueError("reads longer than %d bases are not supported (longest: %d)" % (L.MAX_LEN, int(lens.max())))
         elif fixed_len is None:
             raise ValueError("give lens or fixed_len")
         ee = np.empty(n, np.float64)

@@ -1,17 +1,26 @@
 """Host-side split / gather of a read batch across the GPUs of one node.
 
-The path shards with no exchange step: reads are independent, so rank r of W takes
-the contiguous index range [r*n/W, (r+1)*n/W), filters it on its own MI355X, and results are
-concatenated in read order.  No collective is on the data path.  The only (optional)
-collective is a 3 x int64 all-reduce of the pass / fail / overflow totals, which is what
-moira prints at the end of a run (moira/moira.py:508-519) -- 24 bytes over RCCL/xGMI.
+The path shards with no exchange step: reads are independent, so rank r of W owns the
+contiguous index range [r*n/W, (r+1)*n/W), filters it on its own MI355X, and results are either kept /
+written per rank or concatenated in read order.  No collective is on the data path.  The only collectives
+are optional and small: a 3 x int64 all-reduce of the pass / fail / overflow totals, which is what moira
+prints at the end of a run (moira/moira.py:508-519) -- 24 bytes over RCCL/xGMI -- and, when a caller wants
+every rank to see all results, three `all_gather_into_tensor` calls on fixed-width padded buffers
+(13 bytes per read; nothing is pickled).
 
 This replaces moira's `Pool(processors)` + per-read `apply_async` + `.get()` barrier
 (moira/moira.py:398-399,431-454): one process per GPU instead of one task per read.
 
-The functions take a `filter_fn(q, lens) -> (ee, ns, passed)` so the same split/gather logic
-is exercised on CPU ranks under gloo in the tests (with the oracle as filter_fn) and on GPU
-ranks under RCCL in production (Engine.filter).
+Ownership: a rank only ever materialises ITS range.  `filter_sharded_owned` takes a
+`load_fn(lo, hi) -> (q, lens)` (read the slice of a file, generate it, ...) and calls it exactly once
+with the rank's bounds; `filter_synth_shard` is the device-resident form used for BASELINE config 4
+(1 B reads over 8 GPUs: each rank generates its 125 M reads in its own HBM).  `filter_sharded` keeps the
+replicated-input signature for callers that already hold the whole batch (it slices views, it does not
+copy) -- at config-4 scale use the owned forms.
+
+The functions take a `filter_fn(q, lens) -> (ee, ns, passed)` so the same split/gather logic is
+exercised on CPU ranks under gloo in the tests (with the oracle as filter_fn) and on GPU ranks under
+RCCL in production (Engine.filter).
 """
 import numpy as np
 
@@ -33,36 +42,100 @@ def engine_filter_fn(engine, **params):
     return fn
 
 
-def filter_sharded(q, lens, filter_fn, dist=None, gather=True):
-    """Filter the whole batch (every rank holds the same q/lens, as every rank of a job can
-    read the same input file), each rank computing only its shard.
+def _coll_device(dist):
+    import torch
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
-    Returns (ee, ns, passed, totals).  With gather=True every rank gets the full-length arrays
-    (all_gather of the variable-size shards, order preserved); with gather=False the arrays
-    cover only this rank's shard.  totals = (n_pass, n_fail) over ALL ranks."""
-    n = len(lens)
+
+def reduce_totals(totals, dist=None):
+    """Sum a tuple of per-rank integer totals over all ranks (the one optional 24-byte collective)."""
+    if dist is None or dist.get_world_size() == 1:
+        return tuple(int(x) for x in totals)
+    import torch
+    t = torch.tensor([int(x) for x in totals], dtype=torch.int64, device=_coll_device(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return tuple(int(x) for x in t.tolist())
+
+
+def gather_results(ee, ns, passed, n_total, dist):
+    """Every rank gets the full-length (ee, ns, passed) in read order.  Shards differ by at most one read, so
+    each rank pads its three arrays to ceil(n_total / W) and three all_gather_into_tensor calls move
+    13 bytes per read; the padding is cut out with the known bounds.  No pickling, no per-rank Python lists."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    width = -(-n_total // world) if n_total else 0
+    dev = _coll_device(dist)
+    out = []
+    for arr, tdt in ((np.ascontiguousarray(ee, np.float64), torch.float64),
+                     (np.ascontiguousarray(ns, np.int32), torch.int32),
+                     (np.ascontiguousarray(passed, bool).view(np.uint8), torch.uint8)):
+        mine = torch.zeros(max(width, 1), dtype=tdt)
+        mine[:len(arr)] = torch.from_numpy(arr)
+        mine = mine.to(dev)
+        full = torch.empty(max(width, 1) * world, dtype=tdt, device=dev)
+        dist.all_gather_into_tensor(full, mine)
+        full = full.cpu().numpy().reshape(world, max(width, 1))
+        parts = []
+        for r in range(world):
+            lo, hi = shard_bounds(n_total, world, r)
+            parts.append(full[r, :hi - lo])
+        out.append(np.concatenate(parts) if parts else full[:0])
+    del rank
+    return out[0], out[1], out[2].astype(bool)
+
+
+def filter_sharded_owned(n_total, load_fn, filter_fn, dist=None, gather=False):
+    """Each rank loads and filters ONLY its own range: `load_fn(lo, hi) -> (q, lens)` is called once, with
+    this rank's bounds.  Returns (ee, ns, passed, totals, (lo, hi)); the arrays cover the rank's range
+    (gather=False: a rank then writes its own part of the output, as moira's writers do per file) or the whole
+    batch on every rank (gather=True).  totals = (n_pass, n_fail) over ALL ranks."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    lo, hi = shard_bounds(n, world, rank)
-    ee, ns, passed = filter_fn(q[lo:hi], lens[lo:hi])
+    lo, hi = shard_bounds(n_total, world, rank)
+    q, lens = load_fn(lo, hi)
+    if len(lens) != hi - lo:
+        raise ValueError("load_fn returned %d reads for the range [%d, %d)" % (len(lens), lo, hi))
+    ee, ns, passed = filter_fn(q, lens)
     ee = np.ascontiguousarray(ee, np.float64)
     ns = np.ascontiguousarray(ns, np.int32)
     passed = np.ascontiguousarray(passed, bool)
     n_pass = int(passed.sum())
-    totals = (n_pass, (hi - lo) - n_pass)
-    if dist is None or world == 1:
-        return ee, ns, passed, totals
-    import torch
-    t = torch.tensor(totals, dtype=torch.int64)
-    dev = None
-    if dist.get_backend() == "nccl":
-        dev = torch.device("cuda", torch.cuda.current_device())
-        t = t.to(dev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    totals = tuple(int(x) for x in t.tolist())
-    if not gather:
-        return ee, ns, passed, totals
-    parts = [None] * world
-    dist.all_gather_object(parts, (ee, ns, passed))      # results only: 13 bytes per read
-    return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
-            np.concatenate([p[2] for p in parts]), totals)
+    totals = reduce_totals((n_pass, (hi - lo) - n_pass), dist)
+    if gather and world > 1:
+        ee, ns, passed = gather_results(ee, ns, passed, n_total, dist)
+    return ee, ns, passed, totals, (lo, hi)
+
+
+def filter_sharded(q, lens, filter_fn, dist=None, gather=True):
+    """Replicated-input form (every rank can see the same q/lens, e.g. a memory-mapped file): each rank
+    computes only its slice (a view, not a copy).  Returns (ee, ns, passed, totals); see filter_sharded_owned."""
+    n = len(lens)
+    ee, ns, passed, totals, _ = filter_sharded_owned(n, lambda lo, hi: (q[lo:hi], lens[lo:hi]), filter_fn,
+                                                     dist=dist, gather=gather)
+    return ee, ns, passed, totals
+
+
+def filter_synth_shard(engine, n_total, world, rank, length, stride, seed, download=True, **params):
+    """BASELINE config 4 on one rank: generate this rank's range of the synthetic batch IN ITS OWN HBM (read
+    ids lo..hi-1 of the counter-based generator; no host copy of the inputs exists anywhere) and filter it
+    there.  Returns (ee, ns, passed, (n_pass, n_fail, n_overflow)) for the range, or only the totals when
+    download=False (13 bytes per read stay on the device)."""
+    lo, hi = shard_bounds(n_total, world, rank)
+    m = hi - lo
+    if m == 0:
+        return np.empty(0), np.empty(0, np.int32), np.empty(0, bool), (0, 0, 0)
+    d_q, d_ee, d_ns, d_pass = engine.alloc(m * stride), engine.alloc(m * 8), engine.alloc(m * 4), engine.alloc(m)
+    try:
+        engine.synth_fill(d_q, m, stride, fixed_len=length, seed=seed, first_read=lo)
+        c = engine.filter_device(d_q, m, stride, fixed_len=length, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass,
+                                 params=engine.params(**params))
+        totals = (c.n_pass, c.n_fail, c.n_overflow)
+        if not download:
+            return None, None, None, totals
+        return (d_ee.download(np.float64, m), d_ns.download(np.int32, m),
+                d_pass.download(np.uint8, m).astype(bool), totals)
+    finally:
+        for b in (d_q, d_ee, d_ns, d_pass):
+            b.free()

@@ -1,0 +1,69 @@
+"""BASELINE configs[3]: "1 B synthetic 300 bp reads sharded host-side across 8 x MI355X" -- what ONE GPU of
+that job does: a 125 M-read shard (40 GB resident, generated on the device from the counter-based
+generator, read ids first_read..).  The oracle cannot run 125 M reads in a test, so the full-size checks are
+the size-independent properties (determinism, pass count == sum of flags == threshold test on ee, no NaN)
+plus 300 random 64-read windows regenerated on the host and compared bit for bit; and the host-side split
+itself (a shard == the same slice of the unsplit batch) is checked at a size the oracle covers."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from moira_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def test_config4_one_shard_of_125M(eng, oracle):
+    n, stride, L, seed = 125_000_000, 320, 300, 2
+    rank = 5                                              # any of the 8 shards: read ids 625 M .. 750 M
+    first = rank * n
+    d_q, d_ee, d_ns, d_pass = eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
+    try:
+        eng.synth_fill(d_q, n, stride, fixed_len=L, seed=seed, first_read=first)
+        c1 = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+        ee1 = d_ee.download(np.float64, n)
+        ps1 = d_pass.download(np.uint8, n)
+        ns1 = d_ns.download(np.int32, n)
+        c2 = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+        assert same(d_ee.download(np.float64, n), ee1)                      # deterministic
+        assert np.array_equal(d_pass.download(np.uint8, n), ps1)
+        assert (c1.n_reads, c1.n_pass, c1.n_overflow) == (n, c2.n_pass, c2.n_overflow)
+        assert c1.n_pass == int(ps1.sum(dtype=np.int64)) and c1.n_fail == n - c1.n_pass
+        assert not np.isnan(ee1).any()
+        assert np.array_equal(ps1.astype(bool), ee1 <= L * 0.01)            # the predicate, recomputed
+        rng = np.random.default_rng(4)
+        starts = rng.integers(0, n - 64, 300)
+        starts[:2] = (0, n - 64)
+        for start in starts:
+            hq, _ = oracle.synth_fill(64, stride, fixed_len=L, seed=seed, first_read=first + int(start))
+            ee, ns, ps, _ = oracle.filter_batch(hq, fixed_len=L)
+            sl = slice(int(start), int(start) + 64)
+            assert same(ee1[sl], ee) and np.array_equal(ns1[sl], ns) and np.array_equal(ps1[sl], ps)
+    finally:
+        for b in (d_q, d_ee, d_ns, d_pass):
+            b.free()
+
+
+def test_shards_equal_slices_of_the_unsplit_batch(eng, oracle):
+    """The host-side split of config 4 at a size the oracle covers: W ranks, each generating and filtering ONLY
+    its own range on the device (moira_amd.shard.filter_synth_shard), concatenated == the unsplit batch."""
+    from moira_amd.shard import filter_synth_shard, shard_bounds
+    n, stride, L, seed = 300_001, 320, 300, 2
+    hq, _ = oracle.synth_fill(n, stride, fixed_len=L, seed=seed)
+    ee, ns, ps, _ = oracle.filter_batch(hq, fixed_len=L, threads=oracle.lib().pbo_max_threads())
+    for world in (1, 3, 8):
+        parts = [filter_synth_shard(eng, n, world, r, L, stride, seed) for r in range(world)]
+        assert [len(p[0]) for p in parts] == [hi - lo for lo, hi in (shard_bounds(n, world, r) for r in range(world))]
+        assert same(np.concatenate([p[0] for p in parts]), ee)
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), ns)
+        assert np.array_equal(np.concatenate([p[2] for p in parts]), ps.astype(bool))
+        assert sum(p[3][0] for p in parts) == int(ps.sum())

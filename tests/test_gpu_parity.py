@@ -314,18 +314,68 @@ def test_on_device_ascii_decode(eng, oracle):
 
 
 def test_host_entry_chunks_large_batches(eng, oracle):
-    """mpb_filter_host splits at 1 GiB of qualities: 1.2 M rows of stride 1024 take two chunks."""
+    """mpb_filter_host cuts a batch into chunks of <= 128 MiB of qualities that travel through three
+    pinned/device slots (H2D of chunk k+1 | kernels of chunk k | D2H of chunk k-1): 1.2 M rows of stride
+    1024 are ten chunks, with ragged lengths, from pageable and from pinned memory; every read is compared."""
     n, stride = 1_200_000, 1024
-    q = np.zeros((n, stride), np.uint8)
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 61, n).astype(np.int32)
     base, _ = oracle.synth_fill(n, 64, fixed_len=60, seed=21)
-    q[:, :64] = base
-    lens = np.full(n, 60, np.int32)
+    base[np.arange(64)[None, :] >= lens[:, None]] = 0
+    ee, ns, ps, _ = oracle.filter_batch(base, lens=lens, threads=oracle.lib().pbo_max_threads())
+    pin = eng.host_alloc((n, stride), np.uint8)
+    for kind in ("pageable", "pinned"):
+        q = np.zeros((n, stride), np.uint8) if kind == "pageable" else pin
+        q[:, 64:] = 0
+        q[:, :64] = base
+        r = eng.filter(q, lens=lens)
+        assert same(r.ee, ee) and np.array_equal(r.ns, ns) and np.array_equal(r.passed, ps.astype(bool)), kind
+        assert r.n_pass == int(ps.sum())
+        del q
+    eng.host_free(pin)
+
+
+def test_host_entry_overlapped_pipeline_ragged_config5(eng, oracle):
+    """The same pipeline on BASELINE config 5's shape (ragged 50-600 bp, stride 608): 1 M reads = five
+    chunks, last chunk shorter than the others; overflow totals are summed over the chunks."""
+    n = 1_000_003
+    q, lens = oracle.synth_fill(n, 608, min_len=50, max_len=600, seed=5)
+    ee, ns, ps, _ = oracle.filter_batch(q, lens=lens, threads=oracle.lib().pbo_max_threads())
     r = eng.filter(q, lens=lens)
-    idx = np.random.default_rng(2).integers(0, n, 5000)
-    idx[:4] = (0, 1, n - 2, n - 1)
-    ee, ns, ps, _ = oracle.filter_batch(np.ascontiguousarray(base[idx]), lens=lens[idx], threads=8)
-    assert same(r.ee[idx], ee) and np.array_equal(r.ns[idx], ns) and np.array_equal(r.passed[idx], ps.astype(bool))
-    assert r.n_pass == int(r.passed.sum())
+    assert same(r.ee, ee) and np.array_equal(r.ns, ns) and np.array_equal(r.passed, ps.astype(bool))
+    assert r.n_pass == int(ps.sum())
+    r2 = eng.filter(q, lens=lens, test_underpredict=True)          # forces the second pass in every chunk
+    assert same(r2.ee, ee) and r2.n_overflow > 10000
+
+
+def test_lengths_are_validated_never_clamped(eng):
+    """a read of exactly 1024 bases in a stride-1024 ragged batch used to be truncated to 1023
+    silently.  The reference scores every base it is given, so the call must fail instead."""
+    import ctypes as C
+    from moira_amd import _lib as L
+    q = np.full((3, 1024), 30, np.uint8)
+    for bad in (1024, -1):
+        lens = np.array([100, bad, 1023], np.int32)
+        with pytest.raises(ValueError):
+            eng.filter(q, lens=lens)
+        ee, ns, ps = np.empty(3), np.empty(3, np.int32), np.empty(3, np.uint8)
+        prm = eng.params()
+        rc = eng.lib.mpb_filter_host(eng.ctx, q.ctypes.data, 3, 1024, lens.ctypes.data, 0, C.byref(prm),
+                                     ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, None)
+        assert rc == L.E_INVALID
+        # device-resident lengths: the prepass counts what it had to clamp and the call reports it
+        d_q, d_len = eng.alloc(q.nbytes).upload(q), eng.alloc(12).upload(lens)
+        d_ee, d_ns, d_pass = eng.alloc(24), eng.alloc(12), eng.alloc(3)
+        with pytest.raises(ValueError, match="outside"):
+            eng.filter_device(d_q, 3, 1024, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+        ok = np.array([100, 1023, 1023], np.int32)
+        d_len.upload(ok)
+        c = eng.filter_device(d_q, 3, 1024, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)   # the error does not stick
+        assert c.n_reads == 3
+        for b in (d_q, d_len, d_ee, d_ns, d_pass):
+            b.free()
+    with pytest.raises(ValueError):
+        eng.filter(q, fixed_len=1024)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(alpha=0.05, uncert=0.02), dict(alpha=0.3), dict(maxerrors=6.0, ambigs="ignore"),

@@ -40,7 +40,7 @@ def _worker(rank, world, port, n, out_dir):
             sys.path.insert(0, p)
     import torch.distributed as dist
     import pb_oracle as O
-    from moira_amd.shard import filter_sharded
+    from moira_amd.shard import filter_sharded, filter_sharded_owned
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     q, lens = O.synth_fill(n, 320, fixed_len=300, seed=7)
@@ -51,8 +51,19 @@ def _worker(rank, world, port, n, out_dir):
 
     ee, ns, passed, totals = filter_sharded(q, lens, fn, dist=dist, gather=True)
     ee_l, _, _, totals_l = filter_sharded(q, lens, fn, dist=dist, gather=False)
+    # owned form: this rank generates ONLY its own range (no rank ever holds the whole batch)
+    asked = []
+
+    def load(lo, hi):
+        asked.append((lo, hi))
+        return O.synth_fill(hi - lo, 320, fixed_len=300, seed=7, first_read=lo)
+
+    ee_o, ns_o, ps_o, totals_o, (lo, hi) = filter_sharded_owned(n, load, fn, dist=dist, gather=False)
+    ee_g, ns_g, ps_g, totals_g, _ = filter_sharded_owned(n, load, fn, dist=dist, gather=True)
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), ee=ee, ns=ns, passed=passed,
-             totals=np.array(totals), local_n=len(ee_l), totals_l=np.array(totals_l))
+             totals=np.array(totals), local_n=len(ee_l), totals_l=np.array(totals_l),
+             asked=np.array(asked), lo=lo, hi=hi, ee_o=ee_o, ns_o=ns_o, ps_o=ps_o, totals_o=np.array(totals_o),
+             ee_g=ee_g, ns_g=ns_g, ps_g=ps_g, totals_g=np.array(totals_g))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,11 +74,32 @@ def test_sharded_filter_matches_single_process(tmp_path, oracle, world):
     mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
     q, lens = oracle.synth_fill(n, 320, fixed_len=300, seed=7)
     ee, ns, ps, _ = oracle.filter_batch(q, lens=lens)
+    want_totals = (int(ps.sum()), n - int(ps.sum()))
     local = 0
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
         assert np.array_equal(z["ee"], ee) and np.array_equal(z["ns"], ns)
         assert np.array_equal(z["passed"], ps.astype(bool))
-        assert tuple(z["totals"]) == (int(ps.sum()), n - int(ps.sum())) == tuple(z["totals_l"])
+        assert tuple(z["totals"]) == want_totals == tuple(z["totals_l"])
         local += int(z["local_n"])
+        # owned form: the rank asked its loader for exactly its own range, both times, and nothing else
+        lo, hi = shard_bounds(n, world, r)
+        assert (int(z["lo"]), int(z["hi"])) == (lo, hi)
+        assert [tuple(a) for a in z["asked"]] == [(lo, hi), (lo, hi)]
+        assert np.array_equal(z["ee_o"], ee[lo:hi]) and np.array_equal(z["ns_o"], ns[lo:hi])
+        assert np.array_equal(z["ps_o"], ps[lo:hi].astype(bool))
+        assert tuple(z["totals_o"]) == want_totals == tuple(z["totals_g"])
+        # padded fixed-width gather: full arrays in read order on every rank
+        assert np.array_equal(z["ee_g"], ee) and np.array_equal(z["ns_g"], ns)
+        assert np.array_equal(z["ps_g"], ps.astype(bool))
     assert local == n
+
+
+def test_no_object_collectives_in_the_shard_module():
+    """Results travel as fixed-width tensors (13 bytes per read), never as pickled Python objects."""
+    import inspect
+    import moira_amd.shard as S
+    src = inspect.getsource(S)
+    code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
+    assert "all_gather_object" not in code.split('"""', 2)[2] and "gather_object" not in code.split('"""', 2)[2]
+    assert "all_gather_into_tensor" in code
