@@ -13,6 +13,13 @@ What runs here
     used, and deleted.  It supplies `ee_py` for the cases where the C reference
     has undefined behaviour (first CDF row already above 1-alpha,
     moira/bernoullimodule.c:254) and for a cross-check subset.
+  * moira/nw_align.pyx (the reference's Cython Needleman-Wunsch): cythonized (`cython -2`) and
+    compiled with gcc INTO A TEMP DIR outside the repo, imported, used on >= 2,000 read pairs
+    (overlapping, low-complexity / tie-heavy, unrelated, contained, unequal lengths, five
+    match/mismatch/gap settings) and deleted -> nw_pairs.npz (inputs + aligned strings + score),
+    plus moira.py's make_contig on those alignments in its three consensus modes -> nw_contigs.npz.
+  * moira.py's calculate_errors_poisson on >= 2,000 reads incl. the region where it raises
+    OverflowError -> poisson.npz.
 Only data (inputs + the reference's outputs) is written into the repo.
 
 The inputs are stored in the packed-qscore encoding of include/moira_pb.h
@@ -46,6 +53,169 @@ def load_python_reference():
     sys.path.insert(0, tmp)
     import moira_ref_py3 as M
     return M, tmp
+
+
+def load_cython_nw(tmp):
+    """moira/nw_align.pyx -> nw_align.c -> nw_align.so, all inside `tmp` (outside the repo)."""
+    import sysconfig
+    c_file = os.path.join(tmp, "nw_align.c")
+    subprocess.check_call([sys.executable, "-m", "cython", "-2", os.path.join(REF, "nw_align.pyx"), "-o", c_file],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    so = os.path.join(tmp, "nw_align" + sysconfig.get_config_var("EXT_SUFFIX"))
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-w", "-I", sysconfig.get_paths()["include"],
+                           c_file, "-o", so])
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nw_align", so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cat_strings(strs):
+    """list[str] -> (uint8 buffer, int64 offsets[n+1])"""
+    off = np.zeros(len(strs) + 1, np.int64)
+    off[1:] = np.cumsum([len(x) for x in strs])
+    return np.frombuffer("".join(strs).encode("ascii"), np.uint8).copy(), off
+
+
+NW_PARAMS = [(1, -1, -2), (2, -3, -1), (1, 0, 0), (5, -4, -10), (1, -2, -1)]
+
+
+def nw_pairs(rng):
+    """(seq_1, seq_2) pairs: what nw_align sees in moira (forward read, reverse-complemented mate) and the
+    shapes where a restatement goes wrong (ties, no overlap, containment, 1-base reads)."""
+    def rnd(n, alphabet="ACGT"):
+        return "".join(rng.choice(list(alphabet), n)) if n else ""
+
+    def mutate(s, rate, alphabet="ACGTN"):
+        s = list(s)
+        for k in range(len(s)):
+            if rng.random() < rate:
+                s[k] = rng.choice(list(alphabet))
+        for _ in range(int(rng.integers(0, 3))):
+            if len(s) > 2 and rng.random() < 0.5:
+                del s[int(rng.integers(0, len(s)))]
+            elif rng.random() < 0.3:
+                s.insert(int(rng.integers(0, len(s) + 1)), rng.choice(list("ACGT")))
+        return "".join(s)
+
+    pairs = [("A", "A"), ("A", "C"), ("ACGT", "ACGT"), ("AAAAAAAA", "AAAA"), ("ACGTACGTAC", "TTTT"),
+             ("A", "ACGTACGT"), ("ACGTACGT", "T"), ("AC" * 20, "CA" * 20), ("A" * 50, "A" * 50), ("A" * 30, "A" * 47)]
+    for _ in range(900):                      # overlapping pairs, as real paired reads are
+        n1, n2 = int(rng.integers(20, 260)), int(rng.integers(20, 260))
+        k = int(rng.integers(1, min(n1, n2) + 1))
+        a = rnd(n1)
+        b = a[n1 - k:] + rnd(n2 - k)
+        pairs.append((mutate(a, 0.01), mutate(b, rng.choice([0.0, 0.02, 0.1]))))
+    for _ in range(500):                      # low complexity: two-letter alphabets, homopolymer runs, tandem repeats
+        kind = rng.integers(0, 3)
+        n1, n2 = int(rng.integers(5, 200)), int(rng.integers(5, 200))
+        if kind == 0:
+            a, b = rnd(n1, "AC"), rnd(n2, "AC")
+            if rng.random() < 0.5:
+                k = int(rng.integers(1, min(n1, n2) + 1))
+                b = a[n1 - k:] + rnd(n2 - k, "AC")
+        elif kind == 1:
+            unit = rnd(int(rng.integers(1, 5)))
+            a, b = (unit * 200)[:n1], (unit * 200)[int(rng.integers(0, 4)):][:n2]
+            a, b = mutate(a, 0.03, "ACGT"), mutate(b, 0.03, "ACGT")
+        else:
+            a = "".join(c * int(rng.integers(1, 9)) for c in rnd(40))[:n1]
+            b = "".join(c * int(rng.integers(1, 9)) for c in rnd(40))[:n2]
+        pairs.append((a, b))
+    for _ in range(350):                      # unrelated reads (no overlap at all)
+        pairs.append((rnd(int(rng.integers(1, 300))), rnd(int(rng.integers(1, 300)))))
+    for _ in range(300):                      # one read contained in the other / very unequal lengths
+        n1 = int(rng.integers(60, 330))
+        a = rnd(n1)
+        k = int(rng.integers(1, 40))
+        s = int(rng.integers(0, n1 - k + 1))
+        b = mutate(a[s:s + k], 0.03)
+        pairs.append((a, b) if rng.random() < 0.5 else (b, a))
+    return [(a, b) for a, b in pairs if a and b]
+
+
+def make_nw_fixtures(pyref, tmp):
+    nw = load_cython_nw(tmp)
+    # the reference's own KAT first (moira/test/test_moira.py:53-55)
+    rng = np.random.default_rng(20161004)
+    pairs = nw_pairs(rng)
+    s1, s2, a1, a2, sc, prm = [], [], [], [], [], []
+    for k, (x, y) in enumerate(pairs):
+        for pi in ([0] if k % 3 else range(len(NW_PARAMS))):      # every third pair under all five settings
+            m, mm, g = NW_PARAMS[pi]
+            r1, r2, score = nw.nw_align(x, y, m, mm, g)
+            s1.append(x); s2.append(y); a1.append(r1); a2.append(r2); sc.append(score); prm.append(pi)
+    b1, o1 = cat_strings(s1); b2, o2 = cat_strings(s2); c1, p1 = cat_strings(a1); c2, p2 = cat_strings(a2)
+    out = os.path.join(HERE, "nw_pairs.npz")
+    np.savez_compressed(out, seq1=b1, off1=o1, seq2=b2, off2=o2, aln1=c1, aoff1=p1, aln2=c2, aoff2=p2,
+                        score=np.array(sc, np.int64), param=np.array(prm, np.int8),
+                        params=np.array(NW_PARAMS, np.int32))
+    print("nw_pairs       n=%5d alignments of %d pairs (moira/nw_align.pyx, cythonized in a temp dir) -> %s"
+          % (len(sc), len(pairs), os.path.relpath(out, ROOT)))
+    # make_contig (moira/moira.py:1376-1558) on the reference's alignment of the default-parameter cases
+    modes = [("best", 40, False), ("sum", 0, False), ("posterior", 40, False), ("best", 40, True), ("sum", 60, True)]
+    rows = []
+    for k in range(0, len(sc), 4):
+        if prm[k] != 0 or len(s1[k]) < 2:
+            continue
+        q1 = [int(v) for v in rng.integers(2, 42, len(s1[k]))]
+        q2 = [int(v) for v in rng.integers(2, 42, len(s2[k]))]
+        for mi, (mode, cap, trim) in enumerate(modes):
+            try:
+                cs, cq, ov, gaps, mism = pyref.make_contig(a1[k], list(q1), a2[k], list(q2), 20, 6, mode, cap, trim)
+            except Exception:                                       # the reference raises on some degenerate alignments
+                continue
+            rows.append((k, mi, q1, q2, cs, [int(v) for v in cq], int(ov), int(gaps), int(mism)))
+    cs_b, cs_o = cat_strings([r[4] for r in rows])
+    flat = lambda idx: (np.concatenate([np.asarray(r[idx], np.int16) for r in rows]),
+                        np.concatenate([[0], np.cumsum([len(r[idx]) for r in rows])]).astype(np.int64))
+    q1b, q1o = flat(2); q2b, q2o = flat(3); cqb, cqo = flat(5)
+    out = os.path.join(HERE, "nw_contigs.npz")
+    np.savez_compressed(out, pair=np.array([r[0] for r in rows], np.int32), mode=np.array([r[1] for r in rows], np.int8),
+                        q1=q1b, q1off=q1o, q2=q2b, q2off=q2o, contig=cs_b, coff=cs_o, cq=cqb, cqoff=cqo,
+                        stats=np.array([r[6:9] for r in rows], np.int32),
+                        modes=np.array([m[0] for m in modes]), caps=np.array([m[1] for m in modes], np.int32),
+                        trims=np.array([m[2] for m in modes], np.bool_), insert=np.int32(20), deltaq=np.int32(6))
+    print("nw_contigs     n=%5d contigs (moira.py make_contig, %d modes) -> %s" % (len(rows), len(modes), os.path.relpath(out, ROOT)))
+
+
+def make_poisson_fixture(pyref):
+    """moira/moira.py:1637-1679 on packed reads (0 = 'N'; the Python reference scores 'n' as a base, so no 255)."""
+    rng = np.random.default_rng(20161005)
+    q, lens = rand_mixed(rng, 1800, 352)
+    q[q == 255] = 17
+    # long low-quality reads: Lambda up to several hundred -> factorial(171) / float pow overflow region
+    ql = np.zeros((500, 608), np.uint8)
+    ll = rng.integers(100, 600, 500).astype(np.int32)
+    for i in range(500):
+        hi = int(rng.integers(2, 9))
+        ql[i, :ll[i]] = rng.integers(1, hi + 1, ll[i])
+        if rng.random() < 0.2:
+            ql[i, rng.integers(0, ll[i], 5)] = 0
+    alphas = (0.005, 0.05, 1e-4)
+    sets = []
+    for mat, ln in ((q, lens), (ql, ll)):
+        n = mat.shape[0]
+        ee = np.full((len(alphas), n), np.nan)
+        ns = np.zeros(n, np.int32)
+        ovf = np.zeros((len(alphas), n), np.uint8)
+        for i in range(n):
+            seq, quals = unpack(mat[i], int(ln[i]))
+            for ai, a in enumerate(alphas):
+                try:
+                    e, s = pyref.calculate_errors_poisson(seq, quals, a)
+                    ee[ai, i] = e
+                    ns[i] = s
+                except OverflowError:
+                    ovf[ai, i] = 1
+                    ns[i] = seq.count("N")
+        sets.append((mat, ln, ee, ns, ovf))
+    out = os.path.join(HERE, "poisson.npz")
+    np.savez_compressed(out, alphas=np.array(alphas), q_a=sets[0][0], lens_a=sets[0][1], ee_a=sets[0][2], ns_a=sets[0][3],
+                        ovf_a=sets[0][4], q_b=sets[1][0], lens_b=sets[1][1], ee_b=sets[1][2], ns_b=sets[1][3], ovf_b=sets[1][4])
+    print("poisson        n=%5d reads x %d alphas (overflow cases: %d) -> %s"
+          % (len(lens) + len(ll), len(alphas), int(sets[0][4].sum() + sets[1][4].sum()), os.path.relpath(out, ROOT)))
 
 
 def unpack(row, n):
@@ -141,6 +311,13 @@ def main():
     ref = O.reference_module()
     assert ref is not None, "oracle/_ref/bernoulli.so missing: make -C oracle ref"
     pyref, tmp = load_python_reference()
+    if "--only-new" in sys.argv:          # nw_*.npz and poisson.npz only (the PB sets are already committed)
+        try:
+            make_nw_fixtures(pyref, tmp)
+            make_poisson_fixture(pyref)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
     try:
         # ---- known-answer tests of the reference's own test-suite (moira/test/test_moira.py) ----
         ns = {}
@@ -195,6 +372,8 @@ def main():
         run_set("synth250", q, lens, 0.005, ref, pyref, py_every=50)
         q, lens = O.synth_fill(2048, 608, min_len=50, max_len=600, seed=5)
         run_set("synth_ragged", q, lens, 0.005, ref, pyref, py_every=64)
+        make_nw_fixtures(pyref, tmp)
+        make_poisson_fixture(pyref)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -127,3 +127,47 @@ def test_simd_walk_equals_scalar_loop():
             assert CT.nw_align(a, b, m, mm, g) == CT.nw_align(a, b, m, mm, g, scalar=True), (a, b, m, mm, g)
     a, b = cases[20]
     assert CT.nw_align(a, b, 500, -700, -900) == CT.nw_align(a, b, 500, -700, -900, scalar=True)   # 32-bit path
+
+
+def _strings(buf, off):
+    b = buf.tobytes().decode("ascii")
+    return [b[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+def test_nw_align_against_reference_fixture():
+    """tests/golden/nw_pairs.npz: 4,808 alignments produced by the REFERENCE's Cython aligner
+    (moira/nw_align.pyx, cythonized and run by tests/golden/make_golden.py in the build container) on
+    overlapping, low-complexity / tie-heavy, unrelated, contained and unequal-length pairs under five
+    match/mismatch/gap settings.  Both walks of the library (anti-diagonal SIMD and row-by-row scalar) must
+    reproduce the aligned strings and the score: this pins the tie-break order (nw_align.pyx:96-113) and the
+    3' overlap fix (:155-201) to the reference, not to ourselves."""
+    z = G.load_set("nw_pairs")
+    s1, s2 = _strings(z["seq1"], z["off1"]), _strings(z["seq2"], z["off2"])
+    a1, a2 = _strings(z["aln1"], z["aoff1"]), _strings(z["aln2"], z["aoff2"])
+    assert len(s1) >= 2000 * 2 and len(set(zip(s1, s2))) >= 2000
+    bad = []
+    for k in range(len(s1)):
+        m, mm, g = (int(v) for v in z["params"][z["param"][k]])
+        want = (a1[k], a2[k], int(z["score"][k]))
+        if CT.nw_align(s1[k], s2[k], m, mm, g) != want:
+            bad.append(("simd", k))
+        if k % 2 == 0 and CT.nw_align(s1[k], s2[k], m, mm, g, scalar=True) != want:
+            bad.append(("scalar", k))
+    assert not bad, bad[:10]
+
+
+def test_make_contig_against_reference_fixture():
+    """tests/golden/nw_contigs.npz: moira.py's make_contig (moira/moira.py:1376-1558) on the reference's
+    own alignments, five consensus/cap/trim settings, random qualities."""
+    z, c = G.load_set("nw_pairs"), G.load_set("nw_contigs")
+    a1, a2 = _strings(z["aln1"], z["aoff1"]), _strings(z["aln2"], z["aoff2"])
+    contigs = _strings(c["contig"], c["coff"])
+    assert len(contigs) >= 2000
+    for r in range(len(contigs)):
+        k, mi = int(c["pair"][r]), int(c["mode"][r])
+        q1 = [int(v) for v in c["q1"][c["q1off"][r]:c["q1off"][r + 1]]]
+        q2 = [int(v) for v in c["q2"][c["q2off"][r]:c["q2off"][r + 1]]]
+        got = CT.make_contig(a1[k], q1, a2[k], q2, int(c["insert"]), int(c["deltaq"]), str(c["modes"][mi]),
+                             int(c["caps"][mi]), bool(c["trims"][mi]))
+        want = (contigs[r], [int(v) for v in c["cq"][c["cqoff"][r]:c["cqoff"][r + 1]]]) + tuple(int(v) for v in c["stats"][r])
+        assert got == want, (r, k, mi)

@@ -77,3 +77,44 @@ def test_poisson_gpu_matches_python_reference_function():
         e, ns = calculate_errors_poisson(seq, quals, 0.005)
         assert r.ee[i] == e + ns and r.ns[i] == ns
         assert bool(r.passed[i]) == (e + ns <= lens[i] * 0.01)
+
+
+def _fixture_sets():
+    z = G.load_set("poisson")
+    return z["alphas"], [(z["q_" + t], z["lens_" + t], z["ee_" + t], z["ns_" + t], z["ovf_" + t]) for t in ("a", "b")]
+
+
+def test_poisson_host_tail_against_reference_fixture():
+    """tests/golden/poisson.npz: moira.py's own calculate_errors_poisson (moira/moira.py:1637-1679, imported by
+    tests/golden/make_golden.py) on 2,300 reads x 3 alphas, incl. the long low-quality reads where it raises
+    OverflowError (the library reports NaN there).  lambda is summed here exactly as the reference sums it."""
+    alphas, sets = _fixture_sets()
+    n_cases = n_ovf = 0
+    for q, lens, ee_ref, ns_ref, ovf in sets:
+        lams = np.array([py_lambda(["N" if v == 0 else "A" for v in q[i, :lens[i]]], [int(v) for v in q[i, :lens[i]]])
+                         for i in range(len(lens))])
+        for ai, alpha in enumerate(alphas):
+            ee, _ = finish(lams, ns_ref, lens, alpha=float(alpha), ambigs="ignore")
+            o = ovf[ai].astype(bool)
+            assert np.all(np.isnan(ee[o])) and not np.isnan(ee[~o]).any()
+            assert np.array_equal(ee[~o], ee_ref[ai][~o])
+            n_cases += len(lens)
+            n_ovf += int(o.sum())
+    assert n_cases >= 6000 and n_ovf >= 100
+
+
+@pytest.mark.gpu
+def test_poisson_gpu_against_reference_fixture():
+    """The GPU lambda reduction (k_lambda, sequential per read) + host tail against the same reference set."""
+    from moira_amd.engine import Engine
+    alphas, sets = _fixture_sets()
+    with Engine(0) as eng:
+        for q, lens, ee_ref, ns_ref, ovf in sets:
+            for ai, alpha in enumerate(alphas):
+                r = eng.filter_poisson(q, lens=lens, alpha=float(alpha), ambigs="ignore")
+                o = ovf[ai].astype(bool)
+                assert np.array_equal(r.ns, ns_ref)
+                assert np.all(np.isnan(r.ee[o])) and np.array_equal(r.ee[~o], ee_ref[ai][~o])
+                r2 = eng.filter_poisson(q, lens=lens, alpha=float(alpha), ambigs="treat_as_errors")
+                assert np.array_equal(r2.ee[~o], ee_ref[ai][~o] + ns_ref[~o])
+                assert np.array_equal(r2.passed[~o], (ee_ref[ai] + ns_ref)[~o] <= lens[~o] * 0.01)
