@@ -299,7 +299,7 @@ def main():
         hist_do = eng.class_histogram()
         extras = {"decision_only_mode": {
             "note": "opt-in MPB_FLAG_DECISION_ONLY on the same resident batch of rank 0: reads proven to fail "
-                    "(Chernoff bound) skip their DP and report ee=NaN; identical pass/fail flags; NOT the headline",
+                    "(Chernoff bound) skip their DP and report ee=+inf; identical pass/fail flags; NOT the headline",
             "reads_per_s_this_rank": n / dt_do, "ms_per_step": dt_do * 1e3,
             "pass": counts_do.n_pass, "reads_run_through_dp": int(sum(hist_do.values()))}}
         if not args.fast_fma:

@@ -83,6 +83,14 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    override = os.environ.get("MOIRA_PB_LIB")
+    if override:
+        # experiment builds (tools/variants.sh) live OUTSIDE the tree and are selected here; the in-tree library
+        # and its stamp are never touched by an experiment
+        if not os.path.exists(override):
+            raise MoiraPBError("MOIRA_PB_LIB=%s does not exist" % override)
+        LIB_PATH, build_if_missing = override, False
     if build_if_missing:
         from . import build as _build
         if _build.stale():

@@ -43,6 +43,22 @@ CHUNK_READS = 262144
 # ---------------------------------------------------------------------------------------------
 # exceptions (names and messages of moira/moira.py:973-1055)
 # ---------------------------------------------------------------------------------------------
+class ReadTooLongError(Exception):
+    """Not a reference exception: the Poisson-binomial kernels cover reads of up to 1023 bases (the reference's
+    own C path overruns its stack near 1000).  Raised BEFORE the chunk is filtered; main() removes
+    the partial output files and explains the alternatives."""
+    def __init__(self, header, length):
+        self.header, self.length = header, length
+
+    def __str__(self):
+        return ("Sequence %s has %d bases after contig construction / truncation; the poisson_binomial error "
+                "calculation of this build supports at most %d. Use --error_calc poisson (recommended by moira "
+                "for reads > 500 nt) or --truncate." % (self.header, self.length, MAX_PB_LEN))
+
+
+MAX_PB_LEN = 1023        # MPB_MAX_LEN of the HIP library
+
+
 class ReturnedNaNError(Exception):
     def __init__(self, header):
         self.header = header
@@ -401,7 +417,7 @@ def make_gpu_backend(device=None):
             uncert, maxerrors = fast_discard
             ee, ns, _ = filter_bucketed(eng, seqs, quals, alpha=alpha, ambigs=ambigs, round_=round_,
                                         uncert=uncert, maxerrors=maxerrors, decision_only=True)
-            return np.where(np.isnan(ee), np.inf, ee)     # "certainly above the threshold"
+            return ee      # reads settled by the bound carry ee = +inf ("certainly above the threshold"); NaN stays an error
         if method == "poisson":
             # the Python reference scores a lower-case n as a normal base (moira.py:1660)
             seqs = [s.replace("n", "A") if "n" in s else s for s in seqs]
@@ -414,7 +430,7 @@ def make_gpu_backend(device=None):
             uncert, maxerrors = fast_discard
             r = eng.filter(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, uncert=uncert,
                            maxerrors=maxerrors, decision_only=True)
-            return np.where(np.isnan(r.ee), np.inf, r.ee)
+            return r.ee    # settled reads: +inf from the kernel; a NaN is a genuine failure and raises ReturnedNaNError
         run = eng.filter_poisson if method == "poisson" else eng.filter
         return run(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, uncert=1.0).ee
     backend.engine = eng
@@ -449,6 +465,9 @@ def process_chunk(records, args, backend):
                  (np.maximum(ql, 1) if isinstance(ql, np.ndarray) else [q if q > 0 else 1 for q in ql])
                  for ql in quals]                                                       # QualStr clamps in ints()
         if args.error_calc in ("poisson_binomial", "poisson_binomial_py"):
+            for i, sq in enumerate(seqs):
+                if len(sq) > MAX_PB_LEN:
+                    raise ReadTooLongError(records[i][0], len(sq))
             if getattr(args, "fast_discard", False) and not args.collapse and args.pipeline == "mothur" \
                     and "poisson" in getattr(backend, "methods", ()):
                 ee = backend(seqs, quals, args.alpha, args.ambigs, args.round,
@@ -844,6 +863,9 @@ def _run_fast_fastq(args, backend, o, say, t0):
         for buf, idx, aux in _prefetched(_fast_chunks(args)):
             n = len(idx)
             lens = np.minimum(idx[:, F.SEQ_LEN], T) if T else idx[:, F.SEQ_LEN].copy()
+            if not only and method == "poisson_binomial" and n and int(lens.max()) > MAX_PB_LEN:
+                k = int(np.argmax(lens))
+                raise ReadTooLongError(F.header_of(buf, idx[k]), int(lens[k]))
             strides = bucket_of(lens, 64)
             ee = np.zeros(n, np.float64)                 # --only_contig: process_data returns 0 (moira.py:809-810)
             has_n = np.zeros(n, bool)
@@ -1042,6 +1064,16 @@ def main(args, backend=None, out=None, _no_fastio=False):
             for p in o.files:
                 say(p)
             say()
+    except ReadTooLongError as e:
+        _close(o)
+        for p in o.files:                       # nothing half-written is left behind
+            try:
+                os.remove(p)
+            except OSError:
+                pass
+        say(str(e))
+        say()
+        return 1
     finally:
         _close(o)
     return 0

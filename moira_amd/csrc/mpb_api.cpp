@@ -480,6 +480,8 @@ static int check_params(const mpb_filter_params *p)
     if (!(p->alpha > 0 && p->alpha < 1))                       // ref: bernoullimodule.c:79-83
         return fail(MPB_E_INVALID, "Alpha must be between 0 and 1");
     if (p->ambig_mode < 0 || p->ambig_mode > 2) return fail(MPB_E_INVALID, "unknown ambig_mode %d", p->ambig_mode);
+    if ((p->flags & MPB_FLAG_FAST_FMA) && p->alpha < 1e-5)      // the fma error grows like 1/alpha (include/moira_pb.h)
+        return fail(MPB_E_INVALID, "MPB_FLAG_FAST_FMA needs alpha >= 1e-5 (its error bound does not hold below)");
     const bool has_me = p->maxerrors == p->maxerrors;
     if (has_me && !(p->maxerrors > 0)) return fail(MPB_E_INVALID, "maxerrors must be > 0");           // moira.py:732
     if (!has_me && !(p->uncert > 0 && p->uncert <= 1)) return fail(MPB_E_INVALID, "uncert must be in (0,1]");  // moira.py:728

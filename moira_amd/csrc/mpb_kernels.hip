@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             }
             if (settled) {
                 cls[i] = (uint8_t)(MPB_CLS_SETTLED | (nzero > 0 ? 0x80 : 0));
-                ee_out[i] = __builtin_nan("");
+                ee_out[i] = __builtin_inf();              // "certainly above the threshold"; NaN stays a failure
                 pass_out[i] = 0;
             } else {
                 cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
         ns_out[i] = nzero + n_lower;
         cls_out[i] = (uint8_t)((settled ? MPB_CLS_SETTLED : c) | (nzero > 0 ? 0x80 : 0));
         ident[i] = (int32_t)i;
-        if (settled) { args.ee[i] = __builtin_nan(""); args.pass[i] = 0; }
+        if (settled) { args.ee[i] = __builtin_inf(); args.pass[i] = 0; }
     }
     if (settled) return;
     __threadfence();                                      // the class body reads ns / cls / ident back

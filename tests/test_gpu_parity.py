@@ -174,6 +174,8 @@ def test_fast_fma_mode_within_tolerance(eng, oracle):
     rel = np.abs(r.ee - ee) / np.maximum(np.abs(ee), 1e-300)
     assert rel.max() <= REL_TOL, rel.max()
     assert np.array_equal(r.passed, ps.astype(bool))
+    with pytest.raises(ValueError, match="alpha >= 1e-5"):         # the fma error grows like 1/alpha: refused below
+        eng.filter(q[:100], fixed_len=300, fast_fma=True, alpha=1e-6)
 
 
 def test_fast_fma_mode_keeps_decisions_exact_at_the_threshold(eng, oracle):
@@ -381,20 +383,21 @@ def test_lengths_are_validated_never_clamped(eng):
 @pytest.mark.parametrize("kw", [dict(), dict(alpha=0.05, uncert=0.02), dict(alpha=0.3), dict(maxerrors=6.0, ambigs="ignore"),
                                 dict(round_=True), dict(ambigs="disallow")])
 def test_decision_only_mode_never_changes_a_decision(eng, oracle, kw):
-    """MPB_FLAG_DECISION_ONLY: reads proven to fail are reported (pass=0, ee=NaN) without their DP;
+    """MPB_FLAG_DECISION_ONLY: reads proven to fail are reported (pass=0, ee=+inf) without their DP;
     every flag must equal the full computation's, every computed ee must stay bit-exact."""
     q, lens = oracle.synth_fill(60000, 320, fixed_len=300, seed=6)
     ee, ns, ps, _ = oracle.filter_batch(q, fixed_len=300, threads=8, **kw)
     r = eng.filter(q, fixed_len=300, decision_only=True, **kw)
     assert np.array_equal(r.passed, ps.astype(bool)) and np.array_equal(r.ns, ns)
-    skipped = np.isnan(r.ee)
+    skipped = np.isinf(r.ee)
+    assert not np.isnan(r.ee).any()
     assert skipped.sum() > 1000                       # the shortcut really fires on this workload
     assert not ps[skipped].any()                      # only failing reads are ever skipped
     assert same(r.ee[~skipped], ee[~skipped])
     s = G.load_set("rand_mixed")
     r2 = eng.filter(s["q"], lens=s["lens"], decision_only=True, **kw)
     e2, n2, p2, _ = oracle.filter_batch(s["q"], lens=s["lens"], threads=8, **kw)
-    sk = np.isnan(r2.ee)
+    sk = np.isinf(r2.ee)
     assert np.array_equal(r2.passed, p2.astype(bool)) and same(r2.ee[~sk], e2[~sk]) and not p2[sk].any()
 
 
