@@ -277,6 +277,10 @@ int mpb_kernel_time(mpb_ctx *ctx, int kernel_id, double *total_ms, int64_t *laun
  * caps[i] = rows (J_cap) of class i, counts[i] = reads in it.  Returns the
  * number of classes written (<= max_classes).  Synchronises. */
 int mpb_last_class_histogram(mpb_ctx *ctx, int32_t *caps, int64_t *counts, int32_t max_classes);
+/* Row budget (J_cap) the prepass assigned to each of the first n reads of the last mpb_filter_device call
+ * (0 for a read MPB_FLAG_DECISION_ONLY settled without a DP); host array of n int32.  Diagnostic: what
+ * tools/class_efficiency.py uses to build single-class batches.  Synchronises. */
+int mpb_last_read_budgets(mpb_ctx *ctx, int32_t *caps_out, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "mpb_timing_reset": (C.c_int, [_VP]),
     "mpb_kernel_time": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mpb_last_class_histogram": (C.c_int, [_VP, _VP, _VP, C.c_int32]),
+    "mpb_last_read_budgets": (C.c_int, [_VP, _VP, C.c_int64]),
 }
 
 _lib = None

@@ -570,6 +570,22 @@ int mpb_last_class_histogram(mpb_ctx *c, int32_t *caps, int64_t *cnts, int32_t m
     return k;
 }
 
+int mpb_last_read_budgets(mpb_ctx *c, int32_t *caps_out, int64_t n)
+{
+    CTXCHK(c);
+    if (!caps_out || n < 0) return fail(MPB_E_INVALID, "bad arguments");
+    if (n > c->ws_cap || !c->ws.cls) return fail(MPB_E_INVALID, "no filter call of at least %lld reads precedes", (long long)n);
+    static const MpbClass classes[MPB_NCLS] = MPB_CLASS_TABLE;
+    std::vector<uint8_t> cls((size_t)n);
+    HIPCHK(hipMemcpyAsync(cls.data(), c->ws.cls, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < n; i++) {
+        const int k = cls[(size_t)i] & 0x7f;
+        caps_out[i] = k < MPB_NCLS ? classes[k].cap : 0;
+    }
+    return MPB_OK;
+}
+
 static int ensure_stage(mpb_ctx *c, int64_t bytes)
 {
     if (bytes <= c->stage_cap) return MPB_OK;

@@ -57,6 +57,28 @@ __constant__ ClassOfRows c_class_of_rows{};
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Loads / stores through pointers that reach a class body inside a struct (DpArgs, parked in LDS) have an
+// unknown address space, so the compiler emits FLAT instructions -- which complete out of order with respect
+// to LDS traffic, and therefore force `s_waitcnt vmcnt(0) lgkmcnt(0)` before the first use of ANY of them:
+// a prefetch issued one super-chunk ahead would be waited for at once.  These helpers state the address
+// space (global), which gives global_load / global_store and counted waits (vmcnt(N)).
+template <typename T>
+__device__ __forceinline__ T gload(const T *p)
+{
+    return *(const __attribute__((address_space(1))) T *)(p);
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 gload16(const uint8_t *p)      // 16 aligned bytes
+{
+    const u32x4 x = *(const __attribute__((address_space(1))) u32x4 *)(p);
+    return make_uint4(x.x, x.y, x.z, x.w);
+}
+template <typename T>
+__device__ __forceinline__ void gstore(T *p, T v)
+{
+    *(__attribute__((address_space(1))) T *)(p) = v;
+}
+
 // Orders this wave's LDS writes before its later LDS reads (LDS operations of one wave execute in
 // order; the fence stops the compiler from moving them and drains the counter).  Enough when the
 // LDS region is touched by one wave only.
@@ -445,6 +467,21 @@ __device__ __forceinline__ void dp_chunk_compact(double (&v)[R], const uint4 x, 
     }
 }
 
+// up to 16 bases of a tail chunk: `ndw` (wave-uniform, 1..4) dwords, 8 bases per trip while two dwords remain
+template <int R, int G, bool FMA>
+__device__ __forceinline__ void dp_chunk_tail(double (&v)[R], const uint4 x, int keep, int ndw)
+{
+    uint32_t w0 = x.x, w1 = x.y, w2 = x.z, w3 = x.w;
+    int d = 0;
+#pragma unroll 1
+    for (; d + 2 <= ndw; d += 2) {
+        dp_dword<R, G, FMA>(v, w0, keep);
+        dp_dword<R, G, FMA>(v, w1, keep);
+        w0 = w2; w1 = w3;
+    }
+    if (d < ndw) dp_dword<R, G, FMA>(v, w0, keep);
+}
+
 template <int R, int G, bool FMA>
 __device__ __forceinline__ void dp_chunk(double (&v)[R], const uint4 x, int keep)
 {
@@ -498,21 +535,22 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
     for (int local_tile = first_tile; local_tile < first_tile + n_tiles; local_tile++) {
     const int slot = local_tile * RPT + lane / G;
     const bool valid = slot < count;
-    const int idx = perm_cls[valid ? slot : count - 1];
-    const int li = A.len ? clamp_len(A.len[idx], A.prm.max_len) : A.prm.fixed_len;
+    const int idx = gload(perm_cls + (valid ? slot : count - 1));
+    const int li = A.len ? clamp_len(gload(A.len + idx), A.prm.max_len) : A.prm.fixed_len;
     const uint8_t *row = A.q + (int64_t)idx * A.stride;
 
-    int nch = (li + 15) >> 4;             // 16-byte chunks to walk: the longest read of the tile
+    int limax = li;                       // the longest read of the tile
     int nfull = li >> 4;                  // chunks that are complete in EVERY lane: no masking needed
     if (A.len) {                          // (fixed-length batches: every lane has the same li)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            nch = max(nch, __shfl_xor(nch, off));
+            limax = max(limax, __shfl_xor(limax, off));
             nfull = min(nfull, __shfl_xor(nfull, off));
         }
     }
-    nch = __builtin_amdgcn_readfirstlane(nch);      // wave-uniform trip counts
+    limax = __builtin_amdgcn_readfirstlane(limax);  // wave-uniform trip counts
     nfull = __builtin_amdgcn_readfirstlane(nfull);
+    const int nch = (limax + 15) >> 4;    // 16-byte chunks to walk
 
     double v[R];
 #pragma unroll
@@ -522,6 +560,64 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
     // Each lane pulls its row 64 bytes at a time (4 x dwordx4, issued together, one 64-byte
     // segment of one line) and one super-chunk ahead of the arithmetic, so a cache line is
     // consumed while it is still resident instead of being re-fetched 16 bytes at a time.
+    // A load is guarded by a WAVE-UNIFORM test only (the chunk lies inside the row: rows are `stride`
+    // bytes whatever the read's length, and bytes past a read's end are masked below), so the
+    // prefetch costs one 64-bit pointer bump per 64 bases instead of a compare / exec-mask / zero-fill
+    // sequence per 16.
+#ifndef MPB_DP_LEGACY_PREFETCH
+    const int row_chunks = __builtin_amdgcn_readfirstlane((int)(A.stride >> 4));
+    const int nsc = (nch + 3) >> 2;                // wave-uniform 64-byte super-chunks
+    const int nsc_fast = nfull >> 2;               // ... of which this many hold 64 valid bases in EVERY lane (all inside the row)
+    uint4 cur[4], nxt[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) cur[p] = nxt[p] = make_uint4(0, 0, 0, 0);
+    if (nsc_fast > 0) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) cur[p] = gload16(row + p * 16);
+        // Exactly four loads per trip, whatever the trip: the compiler can then wait for `cur` with
+        // vmcnt(4) and leave the prefetch in flight behind the arithmetic.  The last trip has nothing
+        // new to fetch when the row ends here; it re-reads its own (cache-resident) 64 bytes instead of
+        // branching, because a path-dependent load count degrades every wait to vmcnt(0).
+        for (int sc = 0; sc < nsc_fast; sc++) {
+            const int nxt_sc = (sc * 4 + 8 <= row_chunks) ? sc + 1 : sc;     // scalar select
+            const uint8_t *pf = row + (nxt_sc << 6);
+#pragma unroll
+            for (int p = 0; p < 4; p++) nxt[p] = gload16(pf + p * 16);
+            // the machine scheduler otherwise sinks these loads to the end of the trip (their registers are
+            // free there) and the next trip opens with vmcnt(0): the whole memory latency exposed
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 4; p++) dp_chunk<R, G, FMA>(v, cur[p], keep);
+#pragma unroll
+            for (int p = 0; p < 4; p++) cur[p] = nxt[p];
+        }
+    }
+    // tail: the super-chunks that are ragged in some lane (a 300-base read: bases 256..299)
+    for (int sc = nsc_fast; sc < nsc; sc++) {
+        if (!(sc > 0 && sc == nsc_fast && sc * 4 + 4 <= row_chunks)) {      // not already fetched by the loop above
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                cur[p] = make_uint4(0, 0, 0, 0);
+                if (sc * 4 + p < row_chunks) cur[p] = gload16(row + (sc * 4 + p) * 16);   // wave-uniform guard
+            }
+        }
+        const int pmax = min(4, nch - sc * 4);     // wave-uniform
+#pragma unroll 1
+        for (int p = 0; p < pmax; p++) {
+            uint4 x = cur[0];
+            cur[0] = cur[1]; cur[1] = cur[2]; cur[2] = cur[3];   // rotate: keeps every index static
+            const int c = sc * 4 + p;
+            int ndw = 4;                                 // dwords of this chunk to walk: wave-uniform
+            if (c >= nfull) {                            // wave-uniform: only ragged tail chunks are masked
+                const int nv = li - c * 16;              // may be <= 0 for reads shorter than the tile's longest
+                x.x = mask_dword(x.x, nv); x.y = mask_dword(x.y, nv - 4);
+                x.z = mask_dword(x.z, nv - 8); x.w = mask_dword(x.w, nv - 12);
+                ndw = min(4, (limax - c * 16 + 3) >> 2); // a 300-base read ends 12 bases into its last chunk: 3 dwords, not 4
+            }
+            dp_chunk_tail<R, G, FMA>(v, x, keep, ndw);
+        }
+    }
+#else
     const int my_nch = (li + 15) >> 4;             // this lane's own 16-byte chunks
     const int nsc = (nch + 3) >> 2;                // wave-uniform 64-byte super-chunks
     uint4 cur[4], nxt[4];
@@ -558,6 +654,7 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
 #pragma unroll
         for (int p = 0; p < 4; p++) cur[p] = nxt[p];
     }
+#endif
 
     // ---- epilogue: sequential CDF (ref: bernoullimodule.c:233-251), first row above thr ----
     const double thr = A.prm.thr;
@@ -636,7 +733,7 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
                 e = (double)(js - 1) + ((thr - lo) / (hi - lo));
                 if (e < 0) e = 0;
             }
-            const int nsv = A.perm_ns ? (int)A.perm_ns[(perm_cls - A.perm) + slot] : A.ns[idx];
+            const int nsv = A.perm_ns ? (int)gload(A.perm_ns + (perm_cls - A.perm) + slot) : gload(A.ns + idx);
             if (A.prm.ambig_mode == 0) e = e + (double)nsv;              // moira.py:827-828
             const double limit = (A.prm.maxerrors == A.prm.maxerrors) ? A.prm.maxerrors          // moira.py:925-926
                                                                       : (double)li * A.prm.uncert; // moira.py:949-950
@@ -655,10 +752,10 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
             }
             if (A.prm.flags & 1u) e = floor(e);                          // moira.py:830-831
             bool keep_read;
-            if (A.prm.ambig_mode == 2 && (A.cls[idx] & 0x80)) keep_read = false;           // moira.py:911
+            if (A.prm.ambig_mode == 2 && (gload(A.cls + idx) & 0x80)) keep_read = false;    // moira.py:911
             else keep_read = e <= limit;
-            A.ee[idx] = e;
-            A.pass[idx] = keep_read ? 1 : 0;
+            gstore(A.ee + idx, e);
+            gstore(A.pass + idx, (uint8_t)(keep_read ? 1 : 0));
         }
     }
     }   // tiles of this run

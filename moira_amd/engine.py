@@ -285,6 +285,12 @@ class Engine:
             out[name] = (ms.value, cnt.value)
         return out
 
+    def read_budgets(self, n):
+        """Row budget (class cap) of each of the first n reads of the last filter_device call."""
+        out = np.empty(n, np.int32)
+        L.check(self.lib.mpb_last_read_budgets(self.ctx, out.ctypes.data, n))
+        return out
+
     def class_histogram(self):
         caps = np.zeros(64, np.int32)
         cnts = np.zeros(64, np.int64)
