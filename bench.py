@@ -432,10 +432,11 @@ def host_fed_rate(eng, L, stride, seed, n=3_000_000):
                 q = np.empty((n, stride), np.uint8)
             q.reshape(-1)[:] = d.download(np.uint8, n * stride)
             eng.filter(q[:200000], fixed_len=L)
+            res = (np.zeros(n), np.zeros(n, np.int32), np.zeros(n, np.uint8))     # reused result arrays
             best = None
             for _ in range(3):
                 t = time.perf_counter()
-                eng.filter(q, fixed_len=L)
+                eng.filter(q, fixed_len=L, out=res)
                 dt = time.perf_counter() - t
                 best = dt if best is None else min(best, dt)
             out[kind + "_source"] = {"reads_per_s": n / best, "qscore_GBps": n * stride / best / 1e9}

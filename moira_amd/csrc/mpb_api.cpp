@@ -44,7 +44,7 @@ struct TimedSpan { int kid; hipEvent_t a, b; };
 // One of the MPB_HOST_SLOTS chunk buffers of the host pipeline (mpb_filter_host): a device block
 // (q | len | ee | ns | pass), a pinned staging block for inputs that arrive in pageable memory, a pinned
 // block the outputs land in, and the three events that hand the chunk from stream to stream.
-#define MPB_HOST_SLOTS 3
+#define MPB_HOST_SLOTS 4
 struct HostSlot {
     void *dev = nullptr;      int64_t dev_cap = 0;
     void *pin_in = nullptr;   int64_t pin_in_cap = 0;
@@ -658,12 +658,14 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
 
 // ---- host pipeline (SURVEY a-9: chunked batch, async H2D / compute / D2H) ------------------------
 //
-// Three streams, MPB_HOST_SLOTS chunk slots.  Chunk k (slot k % 3):
+// Three streams, MPB_HOST_SLOTS (4) chunk slots.  Chunk k (slot k % 4):
 //   copy_stream : H2D of its qualities (+ lengths)            -> h2d_done
 //   stream      : waits h2d_done, the five kernels of the pass -> k_done
 //   out_stream  : waits k_done, D2H of ee / Ns / pass          -> d2h_done
 // so that the H2D of chunk k+1 and the D2H of chunk k-1 run beside the kernels of chunk k.  A slot is
-// reused only after its previous chunk's d2h_done (which implies its kernels and its H2D are done).
+// reused only after its previous chunk's d2h_done (which implies its kernels and its H2D are done); a chunk is
+// retired three trips after it was queued, AFTER the current trip's work has been queued, so the copy stream
+// never runs dry while the host thread copies results out.
 // Inputs in pinned host memory (mpb_host_alloc, or registered by the caller) are DMA-ed where they lie;
 // pageable inputs are first copied into the slot's pinned staging block by `copy_threads` threads, which
 // happens while the GPU is busy with the chunks before.  Outputs always land in the slot's pinned block and
@@ -760,8 +762,7 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
     int64_t k = 0;
     for (int64_t off = 0; off < n; off += chunk, k++) {
         const int64_t m = (n - off < chunk) ? n - off : chunk;
-        HostSlot &sl = c->slot[k % MPB_HOST_SLOTS];
-        if ((rc = retire_slot(c, sl, chunk, row_stride, ee, ns, pass, &n_pass))) { drain_pipeline(c); return rc; }
+        HostSlot &sl = c->slot[k % MPB_HOST_SLOTS];          // free: its previous chunk (k - 4) was retired in trip k - 1
         char *d = (char *)sl.dev;
         uint8_t *d_q = (uint8_t *)d;
         int32_t *d_len = (int32_t *)(d + L.q);
@@ -797,6 +798,17 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
         if (e == hipSuccess) e = hipEventRecord(sl.d2h_done, c->out_stream);
         if (e != hipSuccess) { drain_pipeline(c); return fail(MPB_E_HIP, "host pipeline (D2H): %s", hipGetErrorString(e)); }
         sl.off = off; sl.m = m;
+        // With this chunk queued behind the two before it, hand chunk k - 3 to the caller: the host-side copy
+        // of its results (and, next trip, the staging copy of chunk k + 1) runs while the copy engines are busy
+        // with queued work, and frees the slot the next trip fills.
+        if ((rc = retire_slot(c, c->slot[(k + 1) % MPB_HOST_SLOTS], chunk, row_stride, ee, ns, pass, &n_pass))) { drain_pipeline(c); return rc; }
+        // ... and any younger chunk whose results have already landed (in order), so that little is left for the end
+        for (int64_t j = k + 2; j <= k + MPB_HOST_SLOTS - 1; j++) {
+            HostSlot &o = c->slot[j % MPB_HOST_SLOTS];
+            if (o.off < 0) continue;
+            if (hipEventQuery(o.d2h_done) != hipSuccess) { (void)hipGetLastError(); break; }
+            if ((rc = retire_slot(c, o, chunk, row_stride, ee, ns, pass, &n_pass))) { drain_pipeline(c); return rc; }
+        }
     }
     // retire what is still in flight, oldest first
     for (int64_t j = k; j < k + MPB_HOST_SLOTS; j++)

@@ -4,7 +4,7 @@
 # never combined with sys/hip/hsa tracing).  Output under gpurun_out/prof_$1/ ; summarise with
 # tools/summarize_profiles.py $1 and commit the summaries under profiles/.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 D=$PWD/gpurun_out/prof_$TAG
 mkdir -p $D

@@ -23,11 +23,30 @@ with Engine(0) as eng:
     pin = eng.host_alloc((n, stride), np.uint8)
     pin[:] = host
     eng.filter(host[:200000], fixed_len=L)
+    out = (np.zeros(n), np.zeros(n, np.int32), np.zeros(n, np.uint8))     # reused result arrays, pages already present
     for name, q in (("pageable", host), ("pinned", pin)):
         for rep in range(4):
             t = time.perf_counter()
-            r = eng.filter(q, fixed_len=L)
+            r = eng.filter(q, fixed_len=L, out=out)
             dt = time.perf_counter() - t
             print("host path (%s source): %d reads in %.1f ms = %.3e reads/s (%.2f GB/s of qscores over PCIe), pass=%d"
                   % (name, n, dt * 1e3, n / dt, n * stride / dt / 1e9, r.n_pass), flush=True)
     eng.host_free(pin)
+
+# where the time goes: the C call alone with outputs that already have their pages (no first-touch faults), from pinned memory
+import ctypes as C  # noqa: E402
+from moira_amd import _lib as L  # noqa: E402
+with Engine(0) as eng:
+    pin = eng.host_alloc((n, stride), np.uint8)
+    pin[:] = host
+    ee, ns, ps = np.zeros(n), np.zeros(n, np.int32), np.zeros(n, np.uint8)
+    pee, pns, pps = eng.host_alloc(n, np.float64), eng.host_alloc(n, np.int32), eng.host_alloc(n, np.uint8)
+    prm = eng.params()
+    cnt = L.FilterCounts()
+    for name, (a, b, c) in (("touched pageable outputs", (ee, ns, ps)), ("pinned outputs", (pee, pns, pps))):
+        for rep in range(3):
+            t = time.perf_counter()
+            L.check(eng.lib.mpb_filter_host(eng.ctx, pin.ctypes.data, n, stride, None, L_ := 300, C.byref(prm),
+                                            a.ctypes.data, b.ctypes.data, c.ctypes.data, C.byref(cnt)))
+            dt = time.perf_counter() - t
+            print("C call only, pinned source, %s: %.1f ms = %.2f GB/s, pass=%d" % (name, dt * 1e3, n * stride / dt / 1e9, cnt.n_pass), flush=True)
