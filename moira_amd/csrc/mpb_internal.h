@@ -11,12 +11,12 @@
 // cap >= J.  cap = G * R: G lanes cooperate on one read, each keeps R consecutive rows of the
 // running probability vector in registers.  G == 1 is one read per lane.  R <= 16 everywhere so
 // the whole kernel fits a small VGPR budget (many waves per SIMD hide the LUT-read latency).
-#define MPB_NCLS 32
 #define MPB_MAX_LEN 1023          // cap of the widest class is 1024 = max_len + 1 rows
 
 struct MpbClass { int cap, G, R; };
 
 // X(id, R, G): the single list the class table AND the kernel's dispatch switch are generated from
+#define MPB_NCLS 32
 #define MPB_CLASSES(X)                                                                       \
     X(0, 2, 1) X(1, 3, 1) X(2, 4, 1) X(3, 5, 1) X(4, 6, 1) X(5, 7, 1) X(6, 8, 1) X(7, 9, 1)  \
     X(8, 10, 1) X(9, 12, 1) X(10, 14, 1) X(11, 16, 1)                                        \

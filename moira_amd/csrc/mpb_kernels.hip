@@ -564,7 +564,6 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
     // bytes whatever the read's length, and bytes past a read's end are masked below), so the
     // prefetch costs one 64-bit pointer bump per 64 bases instead of a compare / exec-mask / zero-fill
     // sequence per 16.
-#ifndef MPB_DP_LEGACY_PREFETCH
     const int row_chunks = __builtin_amdgcn_readfirstlane((int)(A.stride >> 4));
     const int nsc = (nch + 3) >> 2;                // wave-uniform 64-byte super-chunks
     const int nsc_fast = nfull >> 2;               // ... of which this many hold 64 valid bases in EVERY lane (all inside the row)
@@ -574,10 +573,13 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
     if (nsc_fast > 0) {
 #pragma unroll
         for (int p = 0; p < 4; p++) cur[p] = gload16(row + p * 16);
-        // Exactly four loads per trip, whatever the trip: the compiler can then wait for `cur` with
-        // vmcnt(4) and leave the prefetch in flight behind the arithmetic.  The last trip has nothing
-        // new to fetch when the row ends here; it re-reads its own (cache-resident) 64 bytes instead of
-        // branching, because a path-dependent load count degrades every wait to vmcnt(0).
+        // Exactly four loads per trip, whatever the trip, issued BEFORE the trip's arithmetic and first
+        // waited for at the top of the next trip: a whole super-chunk of FP64 work (1.5-6 us) covers the
+        // memory latency.  The last trip has nothing new to fetch when the row ends here; it re-reads its
+        // own (cache-resident) 64 bytes instead of branching, because a path-dependent load count makes
+        // the compiler's wait-count bookkeeping fall back to "wait for everything" at once.
+        // (Tried and rejected, bit-exact both: re-loading two chunks at a time into the registers just
+        // consumed -- no second register set, no copies, but half the prefetch distance: k_dp +2 %.)
         for (int sc = 0; sc < nsc_fast; sc++) {
             const int nxt_sc = (sc * 4 + 8 <= row_chunks) ? sc + 1 : sc;     // scalar select
             const uint8_t *pf = row + (nxt_sc << 6);
@@ -617,44 +619,6 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
             dp_chunk_tail<R, G, FMA>(v, x, keep, ndw);
         }
     }
-#else
-    const int my_nch = (li + 15) >> 4;             // this lane's own 16-byte chunks
-    const int nsc = (nch + 3) >> 2;                // wave-uniform 64-byte super-chunks
-    uint4 cur[4], nxt[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        cur[p] = make_uint4(0, 0, 0, 0);
-        if (p < my_nch) cur[p] = *reinterpret_cast<const uint4 *>(row + p * 16);
-    }
-    for (int sc = 0; sc < nsc; sc++) {
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int c = (sc + 1) * 4 + p;
-            nxt[p] = make_uint4(0, 0, 0, 0);
-            if (c < my_nch) nxt[p] = *reinterpret_cast<const uint4 *>(row + c * 16);
-        }
-        if (sc * 4 + 4 <= nfull) {
-            // fast path: 64 valid bases in every lane
-#pragma unroll
-            for (int p = 0; p < 4; p++) dp_chunk<R, G, FMA>(v, cur[p], keep);
-        } else {
-            const int pmax = min(4, nch - sc * 4); // wave-uniform
-#pragma unroll 1
-            for (int p = 0; p < pmax; p++) {
-                uint4 x = cur[0];
-                cur[0] = cur[1]; cur[1] = cur[2]; cur[2] = cur[3];   // rotate: keeps every index static
-                if (sc * 4 + p >= nfull) {               // wave-uniform: only ragged tail chunks are masked
-                    const int nv = li - (sc * 4 + p) * 16;   // may be <= 0 for reads shorter than the tile's longest
-                    x.x = mask_dword(x.x, nv); x.y = mask_dword(x.y, nv - 4);
-                    x.z = mask_dword(x.z, nv - 8); x.w = mask_dword(x.w, nv - 12);
-                }
-                dp_chunk_compact<R, G, FMA>(v, x, keep);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 4; p++) cur[p] = nxt[p];
-    }
-#endif
 
     // ---- epilogue: sequential CDF (ref: bernoullimodule.c:233-251), first row above thr ----
     const double thr = A.prm.thr;
