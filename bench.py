@@ -19,7 +19,8 @@ Workload (config.workload):
 A "step" = one pass of the whole hot path over the resident batch: prepass -> scan -> scatter ->
 DP -> overflow pass, producing ee / Ns / pass for every read.  The wall-clock region carries no
 per-kernel events; the per-kernel HIP-event timing behind `roofline` is taken in a separate pass
-right after it.  Without --steps the timed region is sized to last >= 1 s.
+right after it.  Without --steps the timed region is sized to last >= 1 s (1.25 s of steps at the
+warm-up rate).
 
 One JSON line on rank 0.  Extra objects:
   roofline     dominant kernel (k_dp): algorithmic bytes (L + 13 per read) per launch
@@ -257,7 +258,7 @@ def main():
     steps = args.steps
     if steps <= 0:                                        # >= 1 s of timed work, the same count on every rank
         t1 = time.perf_counter(); step(); eng.synchronize(); t_one = time.perf_counter() - t1
-        steps = int(allmax(max(10.0, min(2000.0, 1.0 / max(min(t_one, t_warm), 1e-5) + 1))))
+        steps = int(allmax(max(10.0, min(4000.0, 1.25 / max(min(t_one, t_warm), 1e-5) + 1))))
     # ---- the timed region: no events, no host round trips ----
     barrier()
     t0 = time.perf_counter()
@@ -416,7 +417,7 @@ def main():
     eng.close()
 
 
-def host_fed_rate(eng, L, stride, seed, n=3_000_000):
+def host_fed_rate(eng, L, stride, seed, n=8_000_000):
     """PCIe-inclusive rate of the host-buffer entry (mpb_filter_host), never `value`: packed reads in host
     memory in, ee / Ns / pass in host memory out, through the pinned double-buffered pipeline."""
     import numpy as np

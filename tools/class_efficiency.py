@@ -10,14 +10,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from moira_amd.engine import Engine  # noqa: E402
+from moira_amd import _lib as L_  # noqa: E402
 
 PEAK = 39.3e12
 n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 6_000_000
-target = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
+target = int(sys.argv[2]) if len(sys.argv) > 2 else 16_000_000      # reads per single-class batch for G = 1 (divided by G)
+UNIQ = 1_000_000                                                      # distinct rows uploaded per class, replicated on the device
 stride, L = 320, 300
 with Engine(0) as eng:
     d_q = eng.alloc(n0 * stride)
-    d_ee, d_ns, d_pass = eng.alloc(n0 * 8), eng.alloc(n0 * 4), eng.alloc(n0)
+    nmax = max(n0, target)
+    d_ee, d_ns, d_pass = eng.alloc(nmax * 8), eng.alloc(nmax * 4), eng.alloc(nmax)
     eng.synth_fill(d_q, n0, stride, fixed_len=L, seed=2)
     eng.filter_device(d_q, n0, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
     caps = eng.read_budgets(n0)
@@ -29,15 +32,19 @@ with Engine(0) as eng:
         idx = np.nonzero(caps == cap)[0]
         if len(idx) < 200:
             continue
-        reps = max(1, target // len(idx))
-        sel = np.tile(idx, reps)[:target]
-        m = len(sel)
-        d_b.upload(host[sel])
+        G = 1 if cap <= 16 else 2 if cap <= 32 else 4 if cap <= 64 else 8 if cap <= 128 else 16
+        uniq = np.ascontiguousarray(host[idx[:UNIQ]])
+        m = 0
+        while m + len(uniq) <= target // G:          # replicate the class's rows until the batch fills the chip many times over
+            L_.check(eng.lib.mpb_memcpy_h2d(eng.ctx, d_b.ptr + m * stride, uniq.ctypes.data, uniq.nbytes))
+            m += len(uniq)
+        if m == 0:
+            continue
         eng.filter_device(d_b, m, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
         hist = eng.class_histogram()
         assert hist.get(cap, 0) == m, (cap, hist)
         eng.timing(True); eng.timing_reset()
-        for _ in range(5):
+        for _ in range(4):
             eng.filter_device(d_b, m, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, want_counts=False)
         t = eng.kernel_times()["dp"]
         eng.timing(False)
