@@ -983,11 +983,12 @@ static double poisson_tail(double lam, double alpha, const double *fact)
 {
     double acc_prev = 0, acc = 0;
     int j = 0;
+    const double em = exp(-lam);                                  // the reference re-evaluates it per term: same value
     for (;;) {
         if (j > 170) return NAN;                                  // Python: int too large to convert to float
         const double pw = pow(lam, (double)j);
         if (std::isinf(pw)) return NAN;                           // Python: OverflowError from float pow
-        const double prob = (exp(-lam) * pw) / fact[j];
+        const double prob = (em * pw) / fact[j];
         acc_prev = acc;
         acc = acc_prev + prob;
         if (acc > (1 - alpha)) break;
@@ -1006,18 +1007,33 @@ int mpb_poisson_finish_host(const double *lambda, const int32_t *ns, const int32
     if (n < 0 || (n > 0 && (!lambda || !ns || !ee || !pass))) return fail(MPB_E_INVALID, "bad arguments");
     const double *fact = factorial_table();
     const bool has_me = p->maxerrors == p->maxerrors;
-    for (int64_t i = 0; i < n; i++) {
-        double e = poisson_tail(lambda[i], p->alpha, fact);
-        if (p->ambig_mode == MPB_AMBIG_TREAT_AS_ERRORS) e = e + ns[i];          // moira.py:827-828
-        if (p->flags & MPB_FLAG_ROUND) e = floor(e);                              // moira.py:830-831
-        const int li = len ? len[i] : fixed_len;
-        bool keep;
-        if (p->ambig_mode == MPB_AMBIG_DISALLOW && ns[i] > 0) keep = false;       // moira.py:911
-        else if (has_me) keep = e <= p->maxerrors;
-        else keep = e <= li * p->uncert;
-        ee[i] = e;
-        pass[i] = keep ? 1 : 0;
+    auto run = [=](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            double e = poisson_tail(lambda[i], p->alpha, fact);
+            if (p->ambig_mode == MPB_AMBIG_TREAT_AS_ERRORS) e = e + ns[i];          // moira.py:827-828
+            if (p->flags & MPB_FLAG_ROUND) e = floor(e);                              // moira.py:830-831
+            const int li = len ? len[i] : fixed_len;
+            bool keep;
+            if (p->ambig_mode == MPB_AMBIG_DISALLOW && ns[i] > 0) keep = false;       // moira.py:911
+            else if (has_me) keep = e <= p->maxerrors;
+            else keep = e <= li * p->uncert;
+            ee[i] = e;
+            pass[i] = keep ? 1 : 0;
+        }
+    };
+    // the scalar tail (one libm pow per CDF term) is what a GPU-fed Poisson run waits for: reads are independent,
+    // so large batches are split over the CPUs this process is granted (each read's arithmetic is unchanged)
+    const int threads = n >= 16384 ? 2 * staging_threads() : 1;
+    if (threads <= 1) { run(0, n); return MPB_OK; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + threads - 1) / threads;
+    for (int t = 1; t < threads; t++) {
+        const int64_t lo = per * t, hi = lo + per < n ? lo + per : n;
+        if (lo >= n) break;
+        th.emplace_back(run, lo, hi);
     }
+    run(0, per < n ? per : n);
+    for (auto &t : th) t.join();
     return MPB_OK;
 }
 

@@ -118,3 +118,15 @@ def test_poisson_gpu_against_reference_fixture():
                 r2 = eng.filter_poisson(q, lens=lens, alpha=float(alpha), ambigs="treat_as_errors")
                 assert np.array_equal(r2.ee[~o], ee_ref[ai][~o] + ns_ref[~o])
                 assert np.array_equal(r2.passed[~o], (ee_ref[ai] + ns_ref)[~o] <= lens[~o] * 0.01)
+
+
+def test_poisson_host_tail_threads_do_not_change_results():
+    """Batches of >= 16384 reads are split over threads inside mpb_poisson_finish_host: same values as read by read."""
+    rng = np.random.default_rng(9)
+    lams = np.concatenate([rng.uniform(0, 6, 30000), rng.uniform(6, 200, 10000)])
+    ns = rng.integers(0, 3, len(lams)).astype(np.int32)
+    lens = np.full(len(lams), 300, np.int32)
+    big, pbig = finish(lams, ns, lens, alpha=0.005)
+    for lo in range(0, len(lams), 7919):
+        small, psmall = finish(lams[lo:lo + 100], ns[lo:lo + 100], lens[lo:lo + 100], alpha=0.005)
+        assert np.array_equal(big[lo:lo + 100], small, equal_nan=True) and np.array_equal(pbig[lo:lo + 100], psmall)
