@@ -67,3 +67,25 @@ def test_shards_equal_slices_of_the_unsplit_batch(eng, oracle):
         assert np.array_equal(np.concatenate([p[1] for p in parts]), ns)
         assert np.array_equal(np.concatenate([p[2] for p in parts]), ps.astype(bool))
         assert sum(p[3][0] for p in parts) == int(ps.sum())
+
+
+def test_bench_starts_its_own_ranks_from_the_plain_command():
+    """`python bench.py --gpus 2` without torchrun (the driver's command shape): the script starts its two ranks as a
+    child job before touching the GPU and hands on their JSON line and exit code.  Rehearsal mode: both ranks share
+    this box's one GPU and the 24-byte collectives go over gloo; small shards so that it takes seconds."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu",
+                        "--reads", "300000", "--steps", "3", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["reads_per_gpu"] == 300000 and "configs[3]" in line["config"]["workload"]
+    assert len(line["reads_per_s_per_rank"]) == 2 and all(v > 0 for v in line["reads_per_s_per_rank"])
+    assert line["outcome"]["pass"] + line["outcome"]["fail"] == 600000
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
