@@ -379,14 +379,28 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
     const int32_t *__restrict__ len = RAGGED ? len_arg : nullptr;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     for (int k = tid; k < nkeys; k += 256) s_base[k] = tb->key_base[k] + blockhist[(int64_t)k * gridDim.x + blockIdx.x];
+    // everything this thread needs from global memory for all its rounds, requested up front: the rounds
+    // themselves are then LDS / ballot work only (they used to pay two dependent HBM round trips each)
+    int kk_r[MPB_PRE_ROUNDS], ns_r[MPB_PRE_ROUNDS], c_r[MPB_PRE_ROUNDS], len_r[MPB_PRE_ROUNDS];
+#pragma unroll
+    for (int round = 0; round < MPB_PRE_ROUNDS; round++) {      // independent loads: all in flight together
+        const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + tid;
+        c_r[round] = i < n ? (int)cls[i] : 0xff;
+        ns_r[round] = i < n ? ns[i] : 0;
+        len_r[round] = (len && i < n) ? len[i] : 0;
+    }
+#pragma unroll
+    for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
+        int c = c_r[round] == 0xff ? -1 : (c_r[round] & 0x7f);
+        if (c == MPB_CLS_SETTLED) c = -1;         // settled by the prepass: not part of any tile
+        kk_r[round] = c < 0 ? -1 : c * nb + (len ? min(MPB_LEN_BINS - 1, clamp_len(len_r[round], max_len) >> MPB_LEN_SHIFT) : 0);
+    }
+#pragma unroll
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
         for (int k = tid; k < 4 * nkeys; k += 256) (&s_wcnt[0][0])[k] = 0;
         __syncthreads();
         const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + tid;
-        int c = i < n ? (cls[i] & 0x7f) : -1;
-        if (c == MPB_CLS_SETTLED) c = -1;         // settled by the prepass: not part of any tile
-        int kk = -1;
-        if (c >= 0) kk = c * nb + (len ? min(MPB_LEN_BINS - 1, clamp_len(len[i], max_len) >> MPB_LEN_SHIFT) : 0);
+        const int kk = kk_r[round];
         int rank = 0;
         unsigned long long remaining = __ballot(kk >= 0);
         while (remaining) {
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
             int off = s_base[kk];
             for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][kk];
             perm[off + rank] = (int32_t)i;
-            perm_ns[off + rank] = (uint16_t)ns[i];
+            perm_ns[off + rank] = (uint16_t)ns_r[round];
         }
         __syncthreads();
         for (int k = tid; k < nkeys; k += 256)

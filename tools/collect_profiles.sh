@@ -8,7 +8,7 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 D=$PWD/gpurun_out/prof_$TAG
 mkdir -p $D
-rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $D/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras > $D/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $D/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $D/write.log 2>&1
 # exact memory-side byte counts: read requests by size (32/64/128 B) and write requests (64 B vs 32 B)

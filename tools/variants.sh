@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: interleaved in-session comparison of compile-time variants of the library.
-#   tools/variants.sh [-n rounds] [-t] [-p "COUNTERS"] name1:"-DX=1 -DY=2" name2:"" ...
+#   tools/variants.sh [-n rounds] [-t] [-p "COUNTERS"] name1:"-DX=1 -DY=2" name2:"" name3:""@path/to/other_kernels.hip ...
 #     -t            also run the GPU parity tests against every variant first
 #     -p "C1 C2"    also one rocprofv3 --pmc pass per variant (k_dp / k_prepass rows)
 #   VARIANT_CMD="python tools/config5_rate.py 5000000" VARIANT_TAIL=2 tools/variants.sh ...   (another workload)
@@ -14,8 +14,8 @@ FL="-O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -fno-fa
 mkdir -p /tmp/var
 names=()
 for spec in "$@"; do
-  name=${spec%%:*}; defs=${spec#*:}; names+=($name)
-  SRC=${VARIANT_SRC:-moira_amd/csrc/mpb_kernels.hip}
+  name=${spec%%:*}; rest=${spec#*:}; defs=${rest%%@*}; names+=($name)
+  SRC=moira_amd/csrc/mpb_kernels.hip; if [ "$rest" != "$defs" ]; then SRC=${rest#*@}; fi     # name:"-Dflags"@other_kernels.hip
   /opt/rocm/bin/hipcc $FL $defs $SRC moira_amd/csrc/mpb_api.cpp -o /tmp/var/$name.so 2>/tmp/var/$name.err || { echo "build of $name failed"; tail -5 /tmp/var/$name.err; exit 1; }
 done
 if [ $TESTS = 1 ]; then for v in "${names[@]}"; do
