@@ -31,7 +31,9 @@ struct MpbClass { int cap, G, R; };
 
 // reads handled by one prepass / scatter block: MPB_PRE_ROUNDS rounds of 256 (one thread per read in
 // the ranking step).  More reads per block = shorter histograms to scan.
+#ifndef MPB_PRE_ROUNDS
 #define MPB_PRE_ROUNDS 4
+#endif
 #define MPB_PRE_READS (256 * MPB_PRE_ROUNDS)
 // class byte of a read the prepass already settled (MPB_FLAG_DECISION_ONLY): never scattered, never run
 #define MPB_CLS_SETTLED 0x7f
