@@ -89,3 +89,26 @@ def test_bench_starts_its_own_ranks_from_the_plain_command():
     assert len(line["reads_per_s_per_rank"]) == 2 and all(v > 0 for v in line["reads_per_s_per_rank"])
     assert line["outcome"]["pass"] + line["outcome"]["fail"] == 600000
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_config2_size_order_invariance(eng):
+    """A size-independent property at BASELINE config 2's full size, with no oracle in the loop: a read's result
+    does not depend on where it sits in the batch.  Batch B holds the same 10 M reads as batch A rotated by 3.7 M
+    positions (two device fills), so its sort / tiling differs everywhere; results must be A's, rotated -- bit for bit."""
+    n, stride, L, seed, rot = 10_000_000, 320, 300, 2, 3_700_001
+    d_q, d_ee, d_ns, d_pass = eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
+    try:
+        eng.synth_fill(d_q, n, stride, fixed_len=L, seed=seed)
+        ca = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+        ee_a, ns_a, ps_a = d_ee.download(np.float64, n), d_ns.download(np.int32, n), d_pass.download(np.uint8, n)
+        # B = reads rot..n-1 followed by 0..rot-1
+        eng.synth_fill(d_q.ptr, n - rot, stride, fixed_len=L, seed=seed, first_read=rot)
+        eng.synth_fill(d_q.ptr + (n - rot) * stride, rot, stride, fixed_len=L, seed=seed, first_read=0)
+        cb = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+        ee_b, ns_b, ps_b = d_ee.download(np.float64, n), d_ns.download(np.int32, n), d_pass.download(np.uint8, n)
+        assert same(ee_b, np.roll(ee_a, -rot)) and np.array_equal(ns_b, np.roll(ns_a, -rot))
+        assert np.array_equal(ps_b, np.roll(ps_a, -rot))
+        assert (ca.n_pass, ca.n_overflow) == (cb.n_pass, cb.n_overflow)
+    finally:
+        for b in (d_q, d_ee, d_ns, d_pass):
+            b.free()
