@@ -326,6 +326,7 @@ def main():
         r_len.free()
         if world == 1:
             extras["host_fed"] = host_fed_rate(eng, L, stride, args.seed)
+        extras["poisson_error_calc"] = poisson_rate(eng, d_q, n, stride, L, d_ee, d_ns)
 
     per_rank = [n * steps / dt_local]
     if world > 1:
@@ -415,6 +416,40 @@ def main():
     for b in (d_q, d_ee, d_ns, d_pass):
         b.free()
     eng.close()
+
+
+def poisson_rate(eng, d_q, n, stride, L, d_lam, d_ns):
+    """--error_calc poisson on the same resident batch: the device part is a pure streaming
+    reduction (per-read in-order sum of error probabilities, k_lambda) -- the one kernel of the path that IS
+    HBM-bound; the scalar CDF tail stays on the host (same libm exp / pow as the reference).  NOT the headline."""
+    import ctypes as C
+    import numpy as np
+    from moira_amd import _lib as ML
+    out = {"note": "device part of --error_calc poisson on the resident batch of rank 0 (k_lambda, HIP events) and the host "
+                   "tail on the CPUs this box grants; NOT the headline"}
+    try:
+        for _ in range(2):
+            ML.check(eng.lib.mpb_poisson_lambda_device(eng.ctx, d_q.ptr, n, stride, None, L, d_lam.ptr, d_ns.ptr))
+        eng.timing(True)
+        eng.timing_reset()
+        for _ in range(5):
+            ML.check(eng.lib.mpb_poisson_lambda_device(eng.ctx, d_q.ptr, n, stride, None, L, d_lam.ptr, d_ns.ptr))
+        ms, cnt = eng.kernel_times()["lambda"]
+        eng.timing(False)
+        ms /= max(cnt, 1)
+        out["k_lambda"] = {"ms_per_launch": ms, "reads_per_s": n / ms * 1e3,
+                           "algorithmic_GBps": n * (L + 12) / ms / 1e6, "frac_of_hbm_peak": n * (L + 12) / (ms * 1e-3) / 8e12}
+        m = min(n, 4_000_000)
+        lam, ns = d_lam.download(np.float64, m), d_ns.download(np.int32, m)
+        ee, ps = np.empty(m), np.empty(m, np.uint8)
+        prm = eng.params()
+        t = time.perf_counter()
+        ML.check(eng.lib.mpb_poisson_finish_host(lam.ctypes.data, ns.ctypes.data, None, L, m, C.byref(prm), ee.ctypes.data, ps.ctypes.data))
+        dt = time.perf_counter() - t
+        out["host_tail"] = {"reads_per_s": m / dt, "reads": m, "pass": int(ps.sum())}
+    except Exception as e:                                  # an extra must never cost the headline line
+        out["error"] = repr(e)
+    return out
 
 
 def host_fed_rate(eng, L, stride, seed, n=8_000_000):

@@ -880,43 +880,107 @@ __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict__ pass,
 }
 
 // ------------------------------------------------------------------------------------------
-// k_lambda (--error_calc poisson): one lane per read walks its row in base order, so the sum has
-// the reference's association (moira/moira.py:1663  Lambda += 10**(qscore / -10.0)).
+// k_lambda (--error_calc poisson): lambda = sum of the error probabilities of a read's non-'N' bases IN BASE
+// ORDER, so that the sum has the reference's association (moira/moira.py:1663  Lambda += 10**(qscore / -10.0))
+// and is bit-identical to it.  The order pins one accumulator to one read, i.e. one lane per row -- which, read
+// straight from HBM, is 64 rows per load instruction and a cache line re-visited eight times.  So a wave moves
+// its 64 rows through LDS in panels of 128 columns: coalesced loads shaped like the prepass' (16 rows x 64 B per
+// instruction, the next panel in flight while the current one is summed), a padded row pitch (144 B: the 16
+// lanes an LDS b128 access groups together land in 16 different bank quads), then every lane walks ITS row.
+// 'N' (byte 0) looks up 0.0 (x + 0.0 == x: the reference skips the base), lower-case 'n' (byte 255) looks up a NaN
+// that poisons the sum and is reported; Ns are counted eight bytes at a time with integer arithmetic.
 // ------------------------------------------------------------------------------------------
+#define MPB_LAM_W 128
+#define MPB_LAM_PITCH 144
+
+__device__ __forceinline__ int count_zero_bytes(uint32_t w)
+{
+    uint32_t t = (w & 0x7f7f7f7fu) + 0x7f7f7f7fu;       // bit 7 of a byte is set iff its low 7 bits are non-zero
+    t = ~(t | w | 0x7f7f7f7fu);                         // 0x80 where the whole byte is zero
+    return __popc(t);
+}
+
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void k_lambda(const uint8_t *__restrict__ q, int64_t n, int64_t stride,
-                                                const int32_t *__restrict__ len, int32_t fixed_len,
+                                                const int32_t *__restrict__ len_arg, int32_t fixed_len,
                                                 const double2 *__restrict__ lut_ap,
                                                 double *__restrict__ lambda, int32_t *__restrict__ ns,
                                                 int32_t *__restrict__ bad)
 {
     __shared__ double s_p[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[4][64 * MPB_LAM_PITCH];
+    const int32_t *__restrict__ len = RAGGED ? len_arg : nullptr;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     // the DP LUT holds {1-p, p'}; p' == p bit for bit (tests/test_oracle_golden.py::test_lut_pins)
-    s_p[threadIdx.x] = lut_ap[threadIdx.x].y;
+    s_p[tid] = tid == 0 ? 0.0 : (tid == 255 ? __builtin_nan("") : lut_ap[tid].y);
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int li = len ? clamp_len(len[i], (int)stride) : fixed_len;
-    const uint8_t *row = q + i * stride;
-    double lam = 0.0;
-    int nzero = 0, n255 = 0;
-    for (int c = 0; c * 16 < li; c++) {
-        const uint4 x = *reinterpret_cast<const uint4 *>(row + c * 16);
-        const int nv = li - c * 16;
-        const uint32_t ww[4] = {x.x, x.y, x.z, x.w};
+    uint8_t *tile = s_tile[w];
+    const int r16 = lane & 15, cl = lane >> 4;
+    const int row_bytes = (int)stride;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * 64; row0 < n; row0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = row0 + lane;
+        const bool live = i < n;
+        const int li = live ? (len ? clamp_len(len[i], row_bytes) : fixed_len) : 0;
+        int lmax = li;
+        if (RAGGED || row0 + 64 > n) {
 #pragma unroll
-        for (int d = 0; d < 4; d++)
+            for (int off = 32; off >= 1; off >>= 1) lmax = max(lmax, __shfl_xor(lmax, off));
+        }
+        lmax = __builtin_amdgcn_readfirstlane(lmax);
+        const int npanel = (lmax + MPB_LAM_W - 1) / MPB_LAM_W;
+        double lam = 0.0;
+        int nzero = 0;
+        uint4 pre[8];
+        auto load_panel = [&](int p) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                if (d * 4 + t < nv) {
-                    const uint32_t b = (ww[d] >> (8 * t)) & 0xffu;
-                    if (b == 0u) nzero++;
-                    else { lam = lam + s_p[b]; n255 += b == 255u ? 1 : 0; }
+            for (int rg = 0; rg < 4; rg++)
+#pragma unroll
+                for (int cq = 0; cq < 2; cq++) {
+                    const int64_t r = row0 + rg * 16 + r16;
+                    const int col = p * MPB_LAM_W + cq * 64 + cl * 16;
+                    pre[rg * 2 + cq] = make_uint4(0, 0, 0, 0);
+                    if (p * MPB_LAM_W + cq * 64 < lmax && r < n && col < row_bytes)       // first test wave-uniform
+                        pre[rg * 2 + cq] = *reinterpret_cast<const uint4 *>(q + r * stride + col);
                 }
+        };
+        if (npanel > 0) load_panel(0);
+        for (int p = 0; p < npanel; p++) {
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++)
+#pragma unroll
+                for (int cq = 0; cq < 2; cq++)
+                    *reinterpret_cast<uint4 *>(tile + (rg * 16 + r16) * MPB_LAM_PITCH + cq * 64 + cl * 16) = pre[rg * 2 + cq];
+            wave_lds_fence();
+            if (p + 1 < npanel) load_panel(p + 1);        // in flight while this panel is summed
+            __builtin_amdgcn_sched_barrier(0);
+            const int base = p * MPB_LAM_W;
+            const int nch = (min(MPB_LAM_W, lmax - base) + 15) >> 4;          // wave-uniform
+            const uint8_t *mine = tile + lane * MPB_LAM_PITCH;
+            for (int c = 0; c < nch; c++) {
+                uint4 x = *reinterpret_cast<const uint4 *>(mine + c * 16);
+                const int nv = li - base - c * 16;           // this lane's valid bytes in the chunk (may be <= 0)
+                uint32_t cw[4] = {x.x, x.y, x.z, x.w};       // what is counted: bytes past the end must not look like 'N'
+                if (nv < 16) {
+                    x.x = mask_dword(x.x, nv); x.y = mask_dword(x.y, nv - 4);
+                    x.z = mask_dword(x.z, nv - 8); x.w = mask_dword(x.w, nv - 12);
+                    cw[0] = fill_dword(cw[0], nv); cw[1] = fill_dword(cw[1], nv - 4);
+                    cw[2] = fill_dword(cw[2], nv - 8); cw[3] = fill_dword(cw[3], nv - 12);
+                }
+                nzero += count_zero_bytes(cw[0]) + count_zero_bytes(cw[1]) + count_zero_bytes(cw[2]) + count_zero_bytes(cw[3]);
+                const uint32_t ww[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) lam = lam + s_p[(ww[d] >> (8 * t)) & 0xffu];    // in base order
             }
+            wave_lds_fence();                             // the tile is overwritten by the next panel
+        }
+        if (live) {
+            lambda[i] = lam;
+            ns[i] = nzero;
+            if (lam != lam) atomicAdd(bad, 1);            // only a byte 255 can do that
+        }
     }
-    lambda[i] = lam;
-    ns[i] = nzero;
-    if (n255) atomicAdd(bad, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1079,8 +1143,14 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
 void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, int32_t fixed_len,
                        const double2 *lut_ap, double *lambda, int32_t *ns, int32_t *bad, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lambda, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q, n, stride, len,
-                       fixed_len, lut_ap, lambda, ns, bad);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (1 << 20)) blocks = 1 << 20;            // the tile loop is grid-strided
+    if (len)
+        hipLaunchKernelGGL((k_lambda<true>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, len,
+                           fixed_len, lut_ap, lambda, ns, bad);
+    else
+        hipLaunchKernelGGL((k_lambda<false>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, len,
+                           fixed_len, lut_ap, lambda, ns, bad);
 }
 
 void mpb_launch_decode(const uint8_t *seq, const uint8_t *qual, int64_t n, int64_t stride, const int32_t *len,

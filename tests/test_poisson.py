@@ -130,3 +130,53 @@ def test_poisson_host_tail_threads_do_not_change_results():
     for lo in range(0, len(lams), 7919):
         small, psmall = finish(lams[lo:lo + 100], ns[lo:lo + 100], lens[lo:lo + 100], alpha=0.005)
         assert np.array_equal(big[lo:lo + 100], small, equal_nan=True) and np.array_equal(pbig[lo:lo + 100], psmall)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stride", [16, 48, 128, 144, 320, 608, 1024, 2048])
+def test_lambda_kernel_is_the_sequential_sum(stride):
+    """k_lambda moves rows through LDS in 128-column panels and lets one lane walk each row: lambda must be the
+    reference's left-to-right sum bit for bit (moira/moira.py:1663) for any stride / length / panel boundary,
+    Ns the count of byte 0 inside the read, garbage past a read's end must not matter, a byte 255 must be reported."""
+    from moira_amd.engine import Engine
+    rng = np.random.default_rng(stride)
+    n = 1000 if stride <= 1024 else 300
+    lens = rng.integers(0, stride + 1, n).astype(np.int32)
+    lens[:6] = (0, 1, min(stride, 127), min(stride, 128), min(stride, 129), stride)
+    q = rng.integers(1, 60, (n, stride)).astype(np.uint8)
+    q[rng.random((n, stride)) < 0.03] = 0
+    pad = np.arange(stride)[None, :] >= lens[:, None]
+    q[pad] = rng.integers(0, 256, int(pad.sum()), dtype=np.uint8)          # garbage (incl. 0 and 255) in the padding
+    p = [0.0] + [10 ** (v / -10.0) for v in range(1, 256)]
+    want = np.empty(n)
+    want_ns = np.zeros(n, np.int32)
+    for i in range(n):
+        lam = 0
+        for v in q[i, :lens[i]]:
+            if v == 0:
+                want_ns[i] += 1
+            else:
+                lam += p[int(v)]
+        want[i] = float(lam)
+    with Engine(0) as eng:
+        def run(mat, d_len_ptr, fixed_len):
+            d_q, d_lam, d_ns = eng.alloc(mat.nbytes).upload(mat), eng.alloc(n * 8), eng.alloc(n * 4)
+            L.check(eng.lib.mpb_poisson_lambda_device(eng.ctx, d_q.ptr, n, stride, d_len_ptr, fixed_len, d_lam.ptr, d_ns.ptr))
+            out = d_lam.download(np.float64, n), d_ns.download(np.int32, n)
+            for b in (d_q, d_lam, d_ns):
+                b.free()
+            return out
+        d_len = eng.alloc(n * 4).upload(lens)
+        lam, ns = run(q, d_len.ptr, 0)                                   # ragged
+        assert np.array_equal(lam, want) and np.array_equal(ns, want_ns)
+        full = q.copy()
+        full[full == 255] = 17                                           # every row read in full: the padding is data now
+        lam, ns = run(full, None, stride)                                # fixed length = the whole row
+        w2 = np.array([float(sum(p[int(v)] for v in row)) for row in full])     # built-in sum: left to right from int 0
+        assert np.array_equal(lam, w2) and np.array_equal(ns, (full == 0).sum(1))
+        bad = q.copy()
+        bad[3, 0] = 255
+        l2 = lens.copy(); l2[3] = max(1, l2[3])
+        d_q, d_lam, d_ns = eng.alloc(bad.nbytes).upload(bad), eng.alloc(n * 8), eng.alloc(n * 4)
+        d_len.upload(l2)
+        assert eng.lib.mpb_poisson_lambda_device(eng.ctx, d_q.ptr, n, stride, d_len.ptr, 0, d_lam.ptr, d_ns.ptr) == L.E_INVALID
