@@ -349,6 +349,9 @@ def main():
         achieved = alg_bytes / dp_avg_s / 1e9 if dp_n else None
         cells = sum(cap * cnt for cap, cnt in hist.items()) * L        # DP cells one launch evaluates
         opc = 2 if args.fast_fma else 3
+        # FP64 lane-operations actually issued: row 0 of a one-lane-per-read class (budget <= 16) is a single
+        # multiply (there is no row -1), every other cell costs `opc`
+        issued = sum((opc * cap - (opc - 1 if cap <= 16 else 0)) * cnt for cap, cnt in hist.items()) * L
         # HBM bytes of one k_dp launch from the PMC counters (collected by tools/collect_profiles.sh in
         # separate rocprofv3 passes, corrected as MI355X_MICROARCH.md prescribes); only valid for the
         # workload it was measured on
@@ -400,7 +403,9 @@ def main():
                           "peak_ops_per_s": FP64_VALU_PEAK,
                           "frac": cells * opc / dp_avg_s / FP64_VALU_PEAK if dp_n else None,
                           "floor_ms_per_launch": fp64_floor_ms,
-                          "note": "the binding roof: a scalar FP64 recurrence (SURVEY §8d)"},
+                          "issued_ops_per_launch": issued,
+                          "frac_issued": issued / dp_avg_s / FP64_VALU_PEAK if dp_n else None,
+                          "note": "the binding roof: a scalar FP64 recurrence (SURVEY §8d); `frac` counts 3 ops for every cell, `frac_issued` the FP64 instructions actually issued (row 0 of a one-lane class is one multiply)"},
             "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in times.items()},
             "kernel_event_pass": {"steps": ev_steps, "note": "HIP events on the library's stream, separate from the wall-clock region"},
             "outcome": {"pass": n_pass, "fail": n_fail, "overflow_reruns": n_ovf},

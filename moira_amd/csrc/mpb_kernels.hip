@@ -890,8 +890,10 @@ __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict__ pass,
 // 'N' (byte 0) looks up 0.0 (x + 0.0 == x: the reference skips the base), lower-case 'n' (byte 255) looks up a NaN
 // that poisons the sum and is reported; Ns are counted eight bytes at a time with integer arithmetic.
 // ------------------------------------------------------------------------------------------
-#define MPB_LAM_W 128
-#define MPB_LAM_PITCH 144
+#ifndef MPB_LAM_W
+#define MPB_LAM_W 128                       // 64, 128, 192, 256: measured 128 best
+#endif
+#define MPB_LAM_PITCH (MPB_LAM_W + 16)      // (pitch / 16) odd for every W above
 
 __device__ __forceinline__ int count_zero_bytes(uint32_t w)
 {
@@ -930,17 +932,17 @@ __global__ __launch_bounds__(256) void k_lambda(const uint8_t *__restrict__ q, i
         const int npanel = (lmax + MPB_LAM_W - 1) / MPB_LAM_W;
         double lam = 0.0;
         int nzero = 0;
-        uint4 pre[8];
+        uint4 pre[MPB_LAM_W / 16];
         auto load_panel = [&](int p) {
 #pragma unroll
             for (int rg = 0; rg < 4; rg++)
 #pragma unroll
-                for (int cq = 0; cq < 2; cq++) {
+                for (int cq = 0; cq < MPB_LAM_W / 64; cq++) {
                     const int64_t r = row0 + rg * 16 + r16;
                     const int col = p * MPB_LAM_W + cq * 64 + cl * 16;
-                    pre[rg * 2 + cq] = make_uint4(0, 0, 0, 0);
+                    pre[rg * (MPB_LAM_W / 64) + cq] = make_uint4(0, 0, 0, 0);
                     if (p * MPB_LAM_W + cq * 64 < lmax && r < n && col < row_bytes)       // first test wave-uniform
-                        pre[rg * 2 + cq] = *reinterpret_cast<const uint4 *>(q + r * stride + col);
+                        pre[rg * (MPB_LAM_W / 64) + cq] = *reinterpret_cast<const uint4 *>(q + r * stride + col);
                 }
         };
         if (npanel > 0) load_panel(0);
@@ -948,8 +950,8 @@ __global__ __launch_bounds__(256) void k_lambda(const uint8_t *__restrict__ q, i
 #pragma unroll
             for (int rg = 0; rg < 4; rg++)
 #pragma unroll
-                for (int cq = 0; cq < 2; cq++)
-                    *reinterpret_cast<uint4 *>(tile + (rg * 16 + r16) * MPB_LAM_PITCH + cq * 64 + cl * 16) = pre[rg * 2 + cq];
+                for (int cq = 0; cq < MPB_LAM_W / 64; cq++)
+                    *reinterpret_cast<uint4 *>(tile + (rg * 16 + r16) * MPB_LAM_PITCH + cq * 64 + cl * 16) = pre[rg * (MPB_LAM_W / 64) + cq];
             wave_lds_fence();
             if (p + 1 < npanel) load_panel(p + 1);        // in flight while this panel is summed
             __builtin_amdgcn_sched_barrier(0);
