@@ -251,7 +251,8 @@ int mpb_poisson_lambda_device(mpb_ctx *ctx, const uint8_t *d_q, int64_t n, int64
 int mpb_poisson_finish_host(const double *lambda, const int32_t *ns, const int32_t *len,
                             int32_t fixed_len, int64_t n, const mpb_filter_params *params,
                             double *ee, uint8_t *pass);
-/* Both steps for a batch in host memory. */
+/* Both steps for a batch in host memory, through the same chunked, overlapped pipeline as mpb_filter_host (the host tail
+ * of a chunk runs while the GPU works on the next chunks).  Lengths may be as long as the row (no 1023-base limit here). */
 int mpb_filter_poisson_host(mpb_ctx *ctx, const uint8_t *q, int64_t n, int64_t row_stride,
                             const int32_t *len, int32_t fixed_len, const mpb_filter_params *params,
                             double *ee, int32_t *ns, uint8_t *pass, mpb_filter_counts *counts);

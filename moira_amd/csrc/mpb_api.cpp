@@ -712,18 +712,36 @@ static void drain_pipeline(mpb_ctx *c)
     for (auto &sl : c->slot) sl.off = -1;
 }
 
+// what a pipeline run computes: the Poisson-binomial pass, or the Poisson approximation (lambda on the device, the
+// scalar tail on the host when a chunk is retired -- i.e. beside the GPU work of the chunks after it)
+struct PipeJob {
+    int poisson;
+    const mpb_filter_params *params;
+    const int32_t *len;
+    int32_t fixed_len;
+    double *ee; int32_t *ns; uint8_t *pass;
+};
+
 // wait for the chunk parked in `sl` and hand its results to the caller's arrays
-static int retire_slot(mpb_ctx *c, HostSlot &sl, int64_t cap_reads, int64_t row_stride, double *ee, int32_t *ns,
-                       uint8_t *pass, int64_t *n_pass)
+static int retire_slot(mpb_ctx *c, HostSlot &sl, int64_t cap_reads, int64_t row_stride, const PipeJob &job, int64_t *n_pass)
 {
     if (sl.off < 0) return MPB_OK;
     HIPCHK(hipEventSynchronize(sl.d2h_done));
     const ChunkLayout L = chunk_layout(cap_reads, row_stride);
     const char *h = (const char *)sl.pin_out;
-    memcpy(ee + sl.off, h, (size_t)(sl.m * 8));
-    memcpy(ns + sl.off, h + L.ee, (size_t)(sl.m * 4));
-    const uint8_t *hp = (const uint8_t *)(h + L.ee + L.ns);
-    memcpy(pass + sl.off, hp, (size_t)sl.m);
+    memcpy(job.ns + sl.off, h + L.ee, (size_t)(sl.m * 4));
+    const uint8_t *hp;
+    if (job.poisson) {
+        // the block's first array holds lambda; ee / pass come from the reference's scalar loop (moira.py:1666-1679)
+        int rc = mpb_poisson_finish_host((const double *)h, job.ns + sl.off, job.len ? job.len + sl.off : nullptr, job.fixed_len,
+                                         sl.m, job.params, job.ee + sl.off, job.pass + sl.off);
+        if (rc) return rc;
+        hp = job.pass + sl.off;
+    } else {
+        memcpy(job.ee + sl.off, h, (size_t)(sl.m * 8));
+        hp = (const uint8_t *)(h + L.ee + L.ns);
+        memcpy(job.pass + sl.off, hp, (size_t)sl.m);
+    }
     int64_t np = 0;
     for (int64_t i = 0; i < sl.m; i++) np += hp[i];
     *n_pass += np;
@@ -733,8 +751,9 @@ static int retire_slot(mpb_ctx *c, HostSlot &sl, int64_t cap_reads, int64_t row_
 
 static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
                                 int32_t fixed_len, const mpb_filter_params *params, double *ee, int32_t *ns,
-                                uint8_t *pass, mpb_filter_counts *counts)
+                                uint8_t *pass, mpb_filter_counts *counts, int poisson)
 {
+    const PipeJob job = {poisson, params, len, fixed_len, ee, ns, pass};
     // chunk: at most MPB_HOST_CHUNK_BYTES of qualities, and at least four chunks per batch where the batch
     // is large enough for a chunk to be worth a launch sequence (overlap needs more than one chunk)
     int64_t chunk = (int64_t)MPB_HOST_CHUNK_BYTES / row_stride;
@@ -758,6 +777,7 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
             if ((rc = grow_block(&sl.pin_in, &sl.pin_in_cap, L.in_bytes, true))) return rc;
     }
     HIPCHK(hipMemsetAsync(c->ws.ovf_total, 0, sizeof(long long), c->stream));
+    if (poisson) HIPCHK(hipMemsetAsync(c->ws.ovf_count, 0, sizeof(int32_t), c->stream));     // reads with a byte 255, summed over the chunks
     int64_t n_pass = 0;
     int64_t k = 0;
     for (int64_t off = 0; off < n; off += chunk, k++) {
@@ -788,7 +808,13 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
         // ---- kernels ----
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, sl.h2d_done, 0);
         if (e != hipSuccess) { drain_pipeline(c); return fail(MPB_E_HIP, "host pipeline (H2D): %s", hipGetErrorString(e)); }
-        rc = mpb_filter_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, params, d_ee, d_ns, d_pass, nullptr);
+        if (poisson) {
+            Span t(c, MPB_K_LAMBDA);
+            mpb_launch_lambda(d_q, m, row_stride, len ? d_len : nullptr, fixed_len, c->d_lut, d_ee, d_ns, c->ws.ovf_count, c->stream);
+            rc = hipGetLastError() == hipSuccess ? MPB_OK : fail(MPB_E_HIP, "k_lambda launch failed");
+        } else {
+            rc = mpb_filter_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, params, d_ee, d_ns, d_pass, nullptr);
+        }
         if (rc) { drain_pipeline(c); return rc; }
         e = hipEventRecord(sl.k_done, c->stream);
         // ---- D2H ----
@@ -801,23 +827,27 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
         // With this chunk queued behind the two before it, hand chunk k - 3 to the caller: the host-side copy
         // of its results (and, next trip, the staging copy of chunk k + 1) runs while the copy engines are busy
         // with queued work, and frees the slot the next trip fills.
-        if ((rc = retire_slot(c, c->slot[(k + 1) % MPB_HOST_SLOTS], chunk, row_stride, ee, ns, pass, &n_pass))) { drain_pipeline(c); return rc; }
+        if ((rc = retire_slot(c, c->slot[(k + 1) % MPB_HOST_SLOTS], chunk, row_stride, job, &n_pass))) { drain_pipeline(c); return rc; }
         // ... and any younger chunk whose results have already landed (in order), so that little is left for the end
         for (int64_t j = k + 2; j <= k + MPB_HOST_SLOTS - 1; j++) {
             HostSlot &o = c->slot[j % MPB_HOST_SLOTS];
             if (o.off < 0) continue;
             if (hipEventQuery(o.d2h_done) != hipSuccess) { (void)hipGetLastError(); break; }
-            if ((rc = retire_slot(c, o, chunk, row_stride, ee, ns, pass, &n_pass))) { drain_pipeline(c); return rc; }
+            if ((rc = retire_slot(c, o, chunk, row_stride, job, &n_pass))) { drain_pipeline(c); return rc; }
         }
     }
     // retire what is still in flight, oldest first
     for (int64_t j = k; j < k + MPB_HOST_SLOTS; j++)
-        if ((rc = retire_slot(c, c->slot[j % MPB_HOST_SLOTS], chunk, row_stride, ee, ns, pass, &n_pass))) { drain_pipeline(c); return rc; }
+        if ((rc = retire_slot(c, c->slot[j % MPB_HOST_SLOTS], chunk, row_stride, job, &n_pass))) { drain_pipeline(c); return rc; }
     long long ovf = 0;
-    int32_t bad = 0;
+    int32_t bad = 0, bad255 = 0;
     HIPCHK(hipMemcpyAsync(&ovf, c->ws.ovf_total, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&bad, c->ws.bad_len, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    if (poisson) HIPCHK(hipMemcpyAsync(&bad255, c->ws.ovf_count, sizeof(bad255), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (bad255) return fail(MPB_E_INVALID, "%d read(s) contain byte 255 ('n'): the Poisson path follows the Python reference, "
+                            "which scores lower-case n as a normal base -- pack it as one", bad255);
+    if (poisson) ovf = 0;
     if (bad) {
         HIPCHK(hipMemsetAsync(c->ws.bad_len, 0, sizeof(int32_t), c->stream));
         return fail(MPB_E_INVALID, "%d read length(s) outside 0..%d", bad, MPB_MAX_LEN);
@@ -855,7 +885,7 @@ int mpb_filter_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride,
         rc = filter_host_small(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts, &done);
         if (rc || done) return rc;
     }
-    return filter_host_pipeline(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts);
+    return filter_host_pipeline(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts, 0);
 }
 
 int mpb_host_alloc(mpb_ctx *c, int64_t bytes, void **hptr_out)
@@ -1046,37 +1076,16 @@ int mpb_filter_poisson_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row
     if (rc) return rc;
     if (n < 0 || row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "bad matrix shape");
     if (n > 0 && (!q || !ee || !ns || !pass)) return fail(MPB_E_INVALID, "NULL host buffer");
-    mpb_filter_counts total = {n, 0, 0, 0};
-    int64_t chunk = (int64_t)(1ll << 30) / row_stride;
-    if (chunk < 1024) chunk = 1024;
-    if (chunk > n) chunk = n;
-    std::vector<double> lam((size_t)(chunk > 0 ? chunk : 1));
-    if (n > 0) {
-        rc = ensure_stage(c, align_up(chunk * (row_stride + 16) + 8 * 256, 256));
-        if (rc) return rc;
-    }
-    for (int64_t off = 0; off < n; off += chunk) {
-        const int64_t m = (n - off < chunk) ? n - off : chunk;
-        char *p = (char *)c->stage_dev;
-        uint8_t *d_q = (uint8_t *)p;   p += align_up(m * row_stride, 256);
-        double *d_lam = (double *)p;   p += align_up(m * 8, 256);
-        int32_t *d_len = (int32_t *)p; p += align_up(m * 4, 256);
-        int32_t *d_ns = (int32_t *)p;
-        HIPCHK(hipMemcpyAsync(d_q, q + off * row_stride, (size_t)(m * row_stride), hipMemcpyHostToDevice, c->stream));
-        if (len) HIPCHK(hipMemcpyAsync(d_len, len + off, (size_t)(m * 4), hipMemcpyHostToDevice, c->stream));
-        rc = mpb_poisson_lambda_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, d_lam, d_ns);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(lam.data(), d_lam, (size_t)(m * 8), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(ns + off, d_ns, (size_t)(m * 4), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        rc = mpb_poisson_finish_host(lam.data(), ns + off, len ? len + off : nullptr, fixed_len, m, params,
-                                     ee + off, pass + off);
-        if (rc) return rc;
-        for (int64_t i = 0; i < m; i++) total.n_pass += pass[off + i];
-    }
-    total.n_fail = n - total.n_pass;
-    if (counts) *counts = total;
-    return MPB_OK;
+    if (!len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len does not fit row_stride");
+    if (len)
+        for (int64_t i = 0; i < n; i++)
+            if (len[i] < 0 || len[i] > row_stride)
+                return fail(MPB_E_INVALID, "read %lld: length %d does not fit the %lld-byte row", (long long)i, len[i], (long long)row_stride);
+    if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
+    if (n == 0) return MPB_OK;
+    // the same four-slot pipeline as mpb_filter_host: H2D of chunk k+1 | k_lambda of chunk k | D2H of chunk k-1, and the
+    // scalar tail of a chunk runs on the host while the GPU is busy with the chunks after it
+    return filter_host_pipeline(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts, 1);
 }
 
 int mpb_synth_fill_device(mpb_ctx *c, uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,

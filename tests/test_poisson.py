@@ -180,3 +180,33 @@ def test_lambda_kernel_is_the_sequential_sum(stride):
         d_q, d_lam, d_ns = eng.alloc(bad.nbytes).upload(bad), eng.alloc(n * 8), eng.alloc(n * 4)
         d_len.upload(l2)
         assert eng.lib.mpb_poisson_lambda_device(eng.ctx, d_q.ptr, n, stride, d_len.ptr, 0, d_lam.ptr, d_ns.ptr) == L.E_INVALID
+
+
+@pytest.mark.gpu
+def test_poisson_host_entry_pipeline_multi_chunk(oracle):
+    """mpb_filter_poisson_host runs through the same four-slot pipeline as the Poisson-binomial host entry (H2D |
+    k_lambda | D2H overlapped, the scalar tail of a chunk on the host while the GPU works on the next ones): a ragged
+    300 k-read batch = four chunks; every result equals the one-chunk path's, a sample equals the reference formula."""
+    from moira_amd.engine import Engine
+    n = 300_017
+    q, lens = oracle.synth_fill(n, 608, min_len=50, max_len=600, seed=5)
+    with Engine(0) as eng:
+        r = eng.filter_poisson(q, lens=lens, alpha=0.005, ambigs="treat_as_errors")
+        assert r.n_pass == int(r.passed.sum()) and 0 < r.n_pass < n
+        for lo in range(0, n, 40_000):                      # slices small enough for a single chunk
+            hi = min(n, lo + 12_000)
+            s = eng.filter_poisson(q[lo:hi], lens=lens[lo:hi], alpha=0.005, ambigs="treat_as_errors")
+            assert np.array_equal(r.ee[lo:hi], s.ee, equal_nan=True) and np.array_equal(r.ns[lo:hi], s.ns)
+            assert np.array_equal(r.passed[lo:hi], s.passed)
+        bad = q.copy()
+        bad[n - 5, 3] = 255                                # a lower-case n in the LAST chunk still fails the call
+        with pytest.raises(ValueError, match="255"):
+            eng.filter_poisson(bad, lens=lens)
+    for i in np.random.default_rng(1).integers(0, n, 1500):
+        row = q[i, :lens[i]]
+        try:
+            e, k = calculate_errors_poisson("".join("N" if v == 0 else "A" for v in row), [20 if v == 0 else int(v) for v in row], 0.005)
+        except OverflowError:                               # the reference crashes on this read; the library reports NaN
+            assert np.isnan(r.ee[i]) and not r.passed[i]
+            continue
+        assert r.ee[i] == e + k and r.ns[i] == k and bool(r.passed[i]) == (e + k <= lens[i] * 0.01)
