@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np  # noqa: E402
 import pb_oracle as O  # noqa: E402
 from moira_amd.engine import Engine  # noqa: E402
+from poisson_ref import calculate_errors_poisson  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -65,6 +66,28 @@ with Engine(0) as eng:
             extra["decision_only"] = True
         elif rng.random() < 0.2:
             extra["fast_fma"] = True                                 # ee within 1e-9 relative, decisions exact
+        if rng.random() < 0.1:                                       # --error_calc poisson against the reference's formula
+            m = min(n, 300)
+            qp = q[:m].copy()
+            qp[qp == 255] = 17                                       # the Python reference scores 'n' as a normal base
+            r = eng.filter_poisson(qp, lens=lens[:m], alpha=kw["alpha"], ambigs=kw["ambigs"], round_=kw["round_"],
+                                   **({"maxerrors": kw["maxerrors"]} if "maxerrors" in kw else {"uncert": kw.get("uncert", 0.01)}))
+            okp = True
+            for i in range(m):
+                row = qp[i, :lens[i]]
+                try:
+                    e, k = calculate_errors_poisson("".join("N" if v == 0 else "A" for v in row), [20 if v == 0 else int(v) for v in row], kw["alpha"])
+                except OverflowError:
+                    okp = okp and np.isnan(r.ee[i])
+                    continue
+                if kw["ambigs"] == "treat_as_errors":
+                    e = e + k
+                if kw["round_"]:
+                    e = float(np.floor(e))
+                okp = okp and r.ee[i] == e and r.ns[i] == k
+            if not okp:
+                bad += 1
+                print("POISSON MISMATCH round %d: n=%d stride=%d kw=%s" % (it, m, stride, kw), flush=True)
         eng.batched_only = bool(rng.random() < 0.5)                  # small batches: pipeline or one-read-per-wave path
         ee, ns, ps, rows = O.filter_batch(q, lens=lens, threads=threads, **kw)
         r = eng.filter(q, lens=None if fixed else lens, fixed_len=int(lens[0]) if fixed else None, **kw, **extra)
