@@ -177,7 +177,9 @@ int mpb_decode_ascii_device(mpb_ctx *ctx, const uint8_t *d_seq, const uint8_t *d
 /* ---- the hot path --------------------------------------------------------- */
 /*
  * Filter a batch that is RESIDENT IN HBM.
- *   d_q         device, n rows of row_stride bytes (row_stride % 16 == 0, 16-B aligned)
+ *   d_q         device, n rows of row_stride bytes (row_stride % 16 == 0, 16-B aligned; a 64-B aligned
+ *               matrix with row_stride % 64 == 0 is the fast layout: every 64-byte lane group then reads one
+ *               sector -- a matrix offset by 16 bytes costs the prepass 7 %)
  *   d_len       device int32[n], or NULL when every read has `fixed_len` bases
  *   outputs     device: d_ee double[n], d_ns int32[n], d_pass uint8[n]
  *   counts      host, may be NULL (when non-NULL the call synchronises)
