@@ -335,6 +335,7 @@ def main():
         r_len.free()
         if world == 1:
             extras["host_fed"] = host_fed_rate(eng, L, stride, args.seed)
+            extras["config4_shard"] = config4_shard_rate(eng, L, stride, args.seed, params)
         extras["poisson_error_calc"] = poisson_rate(eng, d_q, n, stride, L, d_ee, d_ns)
 
     per_rank = [n * steps / dt_local]
@@ -430,6 +431,39 @@ def main():
     for b in (d_q, d_ee, d_ns, d_pass):
         b.free()
     eng.close()
+
+
+def config4_shard_rate(eng, L, stride, seed, params, n=CONFIG4_SHARD, rank=3):
+    """What ONE GPU of BASELINE configs[3] does, timed in the same (driver-run) process: a 125 M-read shard (40 GB
+    resident, read ids rank*n ..) -- the per-GPU workload of `bench.py --gpus 8`.  NOT the headline of an N = 1 run."""
+    out = {"note": "one 125 M-read shard of configs[3] (1 B reads over 8 GPUs) on this GPU: the per-rank workload of "
+                   "--gpus 8, >= 1 s of steps; NOT the headline", "reads": n}
+    bufs = []
+    try:
+        bufs = [eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)]
+        d_q, d_ee, d_ns, d_pass = bufs
+        eng.synth_fill(d_q, n, stride, fixed_len=L, seed=seed, first_read=rank * n)
+        run = lambda c=False: eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass,
+                                                params=params, want_counts=c)
+        for _ in range(3):
+            run()
+        eng.synchronize()
+        k = 22
+        t = time.perf_counter()
+        for _ in range(k):
+            run()
+        eng.synchronize()
+        dt = (time.perf_counter() - t) / k
+        c = run(True)
+        out.update({"ms_per_step": dt * 1e3, "reads_per_s": n / dt, "steps": k, "pass": c.n_pass, "overflow_reruns": c.n_overflow})
+    except Exception as e:                                  # an extra must never cost the headline line
+        out["error"] = repr(e)
+    for b in bufs:
+        try:
+            b.free()
+        except Exception:
+            pass
+    return out
 
 
 def poisson_rate(eng, d_q, n, stride, L, d_lam, d_ns):
