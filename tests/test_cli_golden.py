@@ -309,3 +309,30 @@ def test_over_long_read_fails_cleanly_before_filtering(tmp_path, oracle, monkeyp
     a = reference_args(paired=False, forward_fastq=str(fq), output_prefix=out, collapse=False, truncate=200)
     assert cli.main(a, backend=oracle_backend(oracle), out=open(os.devnull, "w"), _no_fastio=line_parser) == 0
     assert os.path.exists(out + ".qc.good.fasta")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("line_parser", [False, True])
+def test_long_reads_run_with_the_poisson_method_gpu(tmp_path, line_parser):
+    """moira's README recommends --error_calc poisson for reads > 500 nt; the Poisson path has no 1023-base limit
+    (only the Poisson-binomial kernels do), so a file with 1,100- and 2,500-base reads runs to completion with it."""
+    from poisson_ref import calculate_errors_poisson
+    fq = tmp_path / "long.fastq"
+    recs = []
+    rng = np.random.default_rng(4)
+    for k, n in enumerate((300, 1100, 2500, 700)):
+        q = "".join(chr(33 + int(v)) for v in rng.integers(25, 41, n))
+        s = "".join(rng.choice(list("ACGT"), n))
+        recs.append((s, q))
+    with open(fq, "w") as f:
+        for k, (s, q) in enumerate(recs):
+            f.write("@r%d\n%s\n+\n%s\n" % (k, s, q))
+    out = str(tmp_path / "o")
+    a = reference_args(paired=False, forward_fastq=str(fq), output_prefix=out, collapse=False, error_calc="poisson")
+    assert cli.main(a, out=open(os.devnull, "w"), _no_fastio=line_parser) == 0
+    good = open(out + ".qc.good.fasta").read() + open(out + ".qc.bad.fasta").read()
+    assert all(">r%d" % k in good for k in range(4))
+    for k, (s, q) in enumerate(recs):          # the decision the reference's function leads to
+        e, ns = calculate_errors_poisson(s, [ord(c) - 33 for c in q], 0.005)
+        where = "good" if e + ns <= len(s) * 0.01 else "bad"
+        assert ">r%d" % k in open("%s.qc.%s.fasta" % (out, where)).read()
