@@ -83,7 +83,8 @@ extern "C" {
 #define MPB_K_DP        3   /* the Poisson-binomial DP + epilogue (dominant)  */
 #define MPB_K_OVERFLOW  4   /* re-run of reads whose predicted row count was too small */
 #define MPB_K_LAMBDA    5   /* Poisson approximation: per-read sum of error probabilities */
-#define MPB_K_COUNT     6
+#define MPB_K_WIDE      6   /* reads that need more than 1024 DP rows: one workgroup per read */
+#define MPB_K_COUNT     7
 
 typedef struct mpb_ctx mpb_ctx;
 

@@ -10,12 +10,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmoira_pb.so")
 
-MAX_LEN = 1023      # MPB_MAX_LEN (csrc/mpb_internal.h): longest read the DP classes cover
+MAX_LEN = 16383     # MPB_MAX_LEN (csrc/mpb_internal.h): longest read (up to 1024 DP rows: one wave; more: k_wide, 16 waves)
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_RANGE = 0, -1, -2, -3, -4, -5
 AMBIG = {"treat_as_errors": 0, "ignore": 1, "disallow": 2}
 FLAG_ROUND, FLAG_FAST_FMA, FLAG_TEST_UNDERPREDICT, FLAG_DECISION_ONLY, FLAG_BATCHED_ONLY = 1, 2, 4, 8, 16
-K_PREPASS, K_SCAN, K_SCATTER, K_DP, K_OVERFLOW, K_LAMBDA = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = {K_PREPASS: "prepass", K_SCAN: "scan", K_SCATTER: "scatter", K_DP: "dp", K_OVERFLOW: "overflow", K_LAMBDA: "lambda"}
+K_PREPASS, K_SCAN, K_SCATTER, K_DP, K_OVERFLOW, K_LAMBDA, K_WIDE = 0, 1, 2, 3, 4, 5, 6
+KERNEL_NAMES = {K_PREPASS: "prepass", K_SCAN: "scan", K_SCATTER: "scatter", K_DP: "dp", K_OVERFLOW: "overflow", K_LAMBDA: "lambda",
+                K_WIDE: "wide"}
 
 
 class MoiraPBError(RuntimeError):

@@ -44,9 +44,10 @@ CHUNK_READS = 262144
 # exceptions (names and messages of moira/moira.py:973-1055)
 # ---------------------------------------------------------------------------------------------
 class ReadTooLongError(Exception):
-    """Not a reference exception: the Poisson-binomial kernels cover reads of up to 1023 bases (the reference's
-    own C path overruns its stack near 1000).  Raised BEFORE the chunk is filtered; main() removes
-    the partial output files and explains the alternatives."""
+    """Not a reference exception: the Poisson-binomial kernels cover reads of up to 16383 bases (the reference's
+    own C path overruns its stack near 1000; its Python twin has no limit but needs O(J^2 L) Python
+    steps).  Raised BEFORE the chunk is filtered; main() removes the partial output files and explains the
+    alternatives."""
     def __init__(self, header, length):
         self.header, self.length = header, length
 
@@ -56,7 +57,7 @@ class ReadTooLongError(Exception):
                 "for reads > 500 nt) or --truncate." % (self.header, self.length, MAX_PB_LEN))
 
 
-MAX_PB_LEN = 1023        # MPB_MAX_LEN of the HIP library
+MAX_PB_LEN = 16383       # MPB_MAX_LEN of the HIP library
 
 
 class ReturnedNaNError(Exception):

@@ -66,6 +66,8 @@ struct mpb_ctx {
     MpbWorkspace ws{};
     void *ws_block = nullptr;
     void *ws_small = nullptr;
+    void *ws_wide = nullptr;             // wide-read list + predicted rows, only for batches whose rows hold > 1023 bases
+    int64_t ws_wide_cap = 0;
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -203,6 +205,7 @@ int mpb_destroy(mpb_ctx *c)
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->ws_block) (void)hipFree(c->ws_block);
     if (c->ws_small) (void)hipFree(c->ws_small);
+    if (c->ws_wide) (void)hipFree(c->ws_wide);
     if (c->one_dev) (void)hipFree(c->one_dev);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     if (c->pin_host) (void)hipHostFree(c->pin_host);
@@ -363,6 +366,7 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
         c->ws.bad_len = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256) + 64);
         c->ws.pass_count = (unsigned long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 256);
         c->ws.ovf_total = (long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 320);
+        c->ws.wide_count = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256) + 384);
         c->ws.lut = c->d_lut;
     }
     if (n <= c->ws_cap) return MPB_OK;
@@ -383,6 +387,20 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
     c->ws.blockhist = (int32_t *)p; p += b_hist;
     c->ws.ovf_list = (int32_t *)p;
     c->ws_cap = cap;
+    return MPB_OK;
+}
+
+// the wide-read list of a batch whose rows can hold more than MPB_TILE_MAX_ROWS - 1 bases (8 bytes per read)
+static int ensure_wide_workspace(mpb_ctx *c, int64_t n)
+{
+    if (n <= c->ws_wide_cap) return MPB_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->ws_wide) { HIPCHK(hipFree(c->ws_wide)); c->ws_wide = nullptr; c->ws_wide_cap = 0; c->ws.wide_list = c->ws.wide_rows = nullptr; }
+    const int64_t cap = n + n / 8 + 1024;
+    HIPCHK(hipMalloc(&c->ws_wide, (size_t)(2 * align_up(cap * 4, 256))));
+    c->ws.wide_list = (int32_t *)c->ws_wide;
+    c->ws.wide_rows = (int32_t *)((char *)c->ws_wide + align_up(cap * 4, 256));
+    c->ws_wide_cap = cap;
     return MPB_OK;
 }
 
@@ -515,23 +533,31 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     if (n < 0) return fail(MPB_E_INVALID, "n < 0");
     if (n > 0x7fffffffll - 4096) return fail(MPB_E_INVALID, "batch of %lld reads exceeds 2^31; split it", (long long)n);
     if (row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "row_stride must be a positive multiple of 16");
-    if (row_stride > MPB_MAX_LEN + 1) return fail(MPB_E_INVALID, "row_stride %lld exceeds %d (reads longer than %d bases are not supported)", (long long)row_stride, MPB_MAX_LEN + 1, MPB_MAX_LEN);
+    if (row_stride > MPB_MAX_STRIDE) return fail(MPB_E_INVALID, "row_stride %lld exceeds %d (reads longer than %d bases are not supported)", (long long)row_stride, MPB_MAX_STRIDE, MPB_MAX_LEN);
     if (((uintptr_t)d_q & 15) != 0) return fail(MPB_E_INVALID, "quality matrix must be 16-byte aligned");
     if (!d_len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len %d does not fit row_stride %lld", fixed_len, (long long)row_stride);
     const int32_t max_len = d_len ? (int32_t)(row_stride < MPB_MAX_LEN ? row_stride : MPB_MAX_LEN) : fixed_len;
-    if (max_len > MPB_MAX_LEN || (d_len && row_stride > MPB_MAX_LEN + 1))
+    if (max_len > MPB_MAX_LEN)
         return fail(MPB_E_INVALID, "reads longer than %d bases are not supported", MPB_MAX_LEN);
     if (n > 0 && (!d_q || !d_ee || !d_ns || !d_pass)) return fail(MPB_E_INVALID, "NULL device buffer");
     if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
     if (n == 0) return MPB_OK;
     rc = ensure_workspace(c, n);
     if (rc) return rc;
-    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
+    // reads of more than 1023 bases may need more DP rows than one wave holds: such reads are listed by the prepass
+    // and run by the wide kernel (k_wide).  Batches whose rows cannot hold such a read never see any of it.
+    const bool wide_possible = max_len + 1 > MPB_TILE_MAX_ROWS;
     hipStream_t s = c->stream;
+    if (wide_possible) {
+        if ((rc = ensure_wide_workspace(c, n))) return rc;
+        HIPCHK(hipMemsetAsync(c->ws.wide_count, 0, sizeof(int32_t), s));
+    }
+    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
     { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     { Span t(c, MPB_K_SCAN);     mpb_launch_scan(n, d_len, c->ws, s); }
     { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, d_len, d_ns, prm, c->ws, s); }
     { Span t(c, MPB_K_DP);       mpb_launch_dp(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
+    if (wide_possible) { Span t(c, MPB_K_WIDE); mpb_launch_wide(d_q, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     { Span t(c, MPB_K_OVERFLOW); mpb_launch_overflow(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     HIPCHK(hipGetLastError());
     if (counts) {
@@ -543,11 +569,11 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
         if (d_len) HIPCHK(hipMemcpyAsync(&bad, c->ws.bad_len, sizeof(bad), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (bad) {
-            // a length in d_len was negative or above max_len: the kernels clamped it to stay inside the row, so
-            // those reads' results are not the reference's -- the call fails (sticky until a call reports it)
+            // a length in d_len was negative or above max_len: those reads were given ee = NaN, pass = 0 by the prepass
+            // (never a result computed on a clamped length), and the call that fetches the counts fails
             HIPCHK(hipMemsetAsync(c->ws.bad_len, 0, sizeof(int32_t), s));
             return fail(MPB_E_INVALID, "%d read length(s) in d_len outside 0..%d (row_stride %lld; reads longer than %d bases "
-                        "are not supported)", bad, max_len, (long long)row_stride, MPB_MAX_LEN);
+                        "are not supported); those reads were given ee = NaN, pass = 0", bad, max_len, (long long)row_stride, MPB_MAX_LEN);
         }
         counts->n_pass = (int64_t)np;
         counts->n_fail = n - (int64_t)np;
@@ -777,6 +803,9 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
             if ((rc = grow_block(&sl.pin_in, &sl.pin_in_cap, L.in_bytes, true))) return rc;
     }
     HIPCHK(hipMemsetAsync(c->ws.ovf_total, 0, sizeof(long long), c->stream));
+    // the host has validated every length: a count left behind by an earlier mpb_filter_device call that never
+    // fetched its counts must not fail this one
+    HIPCHK(hipMemsetAsync(c->ws.bad_len, 0, sizeof(int32_t), c->stream));
     if (poisson) HIPCHK(hipMemsetAsync(c->ws.ovf_count, 0, sizeof(int32_t), c->stream));     // reads with a byte 255, summed over the chunks
     int64_t n_pass = 0;
     int64_t k = 0;
@@ -842,7 +871,7 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
     long long ovf = 0;
     int32_t bad = 0, bad255 = 0;
     HIPCHK(hipMemcpyAsync(&ovf, c->ws.ovf_total, sizeof(ovf), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&bad, c->ws.bad_len, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    if (len && !poisson) HIPCHK(hipMemcpyAsync(&bad, c->ws.bad_len, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
     if (poisson) HIPCHK(hipMemcpyAsync(&bad255, c->ws.ovf_count, sizeof(bad255), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (bad255) return fail(MPB_E_INVALID, "%d read(s) contain byte 255 ('n'): the Poisson path follows the Python reference, "
@@ -865,7 +894,7 @@ int mpb_filter_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride,
     if (rc) return rc;
     if (n < 0) return fail(MPB_E_INVALID, "n < 0");
     if (row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "row_stride must be a positive multiple of 16");
-    if (row_stride > MPB_MAX_LEN + 1) return fail(MPB_E_INVALID, "row_stride %lld exceeds %d (reads longer than %d bases are not supported)", (long long)row_stride, MPB_MAX_LEN + 1, MPB_MAX_LEN);
+    if (row_stride > MPB_MAX_STRIDE) return fail(MPB_E_INVALID, "row_stride %lld exceeds %d (reads longer than %d bases are not supported)", (long long)row_stride, MPB_MAX_STRIDE, MPB_MAX_LEN);
     if (n > 0 && (!q || !ee || !ns || !pass)) return fail(MPB_E_INVALID, "NULL host buffer");
     if (!len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len %d does not fit row_stride %lld", fixed_len, (long long)row_stride);
     if (!len && fixed_len > MPB_MAX_LEN) return fail(MPB_E_INVALID, "reads longer than %d bases are not supported", MPB_MAX_LEN);
@@ -875,12 +904,12 @@ int mpb_filter_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride,
         for (int64_t i = 0; i < n; i++)
             if (len[i] < 0 || len[i] > lim)
                 return fail(MPB_E_INVALID, len[i] > row_stride || len[i] < 0 ? "read %lld: length %d does not fit the %lld-byte row"
-                                                                             : "read %lld: %d bases; reads longer than 1023 bases are not supported (row of %lld bytes)",
+                                                                             : "read %lld: %d bases; reads longer than 16383 bases are not supported (row of %lld bytes)",
                             (long long)i, len[i], (long long)row_stride);
     }
     if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
     if (n == 0) return MPB_OK;
-    if (n <= MPB_SMALL_N && !(params->flags & MPB_FLAG_BATCHED_ONLY)) {
+    if (n <= MPB_SMALL_N && n * row_stride <= (8ll << 20) && !(params->flags & MPB_FLAG_BATCHED_ONLY)) {
         bool done = false;
         rc = filter_host_small(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts, &done);
         if (rc || done) return rc;

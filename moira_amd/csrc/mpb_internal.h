@@ -11,7 +11,16 @@
 // cap >= J.  cap = G * R: G lanes cooperate on one read, each keeps R consecutive rows of the
 // running probability vector in registers.  G == 1 is one read per lane.  R <= 16 everywhere so
 // the whole kernel fits a small VGPR budget (many waves per SIMD hide the LUT-read latency).
-#define MPB_MAX_LEN 1023          // cap of the widest class is 1024 = max_len + 1 rows
+// Tile classes (below) cover up to MPB_TILE_MAX_ROWS rows of the DP table: one wave, 64 lanes x 16 registers.
+// A read predicted to need more rows is a WIDE read: one workgroup of up to MPB_WIDE_WAVES waves holds its running
+// vector (wave w keeps rows w*1024 .. w*1024+1023), the waves run one 64-base block apart and hand the row that
+// crosses a wave boundary on through an LDS stream (k_wide).  16 waves x 1024 rows = 16384 rows = a read of
+// MPB_MAX_LEN bases in which every base is an error.
+#define MPB_TILE_MAX_ROWS 1024
+#define MPB_WIDE_WAVES 16
+#define MPB_MAX_ROWS (MPB_TILE_MAX_ROWS * MPB_WIDE_WAVES)
+#define MPB_MAX_LEN (MPB_MAX_ROWS - 1)     // longest read: rows needed <= len + 1
+#define MPB_MAX_STRIDE MPB_MAX_ROWS       // widest quality-matrix row (bytes)
 
 struct MpbClass { int cap, G, R; };
 
@@ -37,6 +46,8 @@ struct MpbClass { int cap, G, R; };
 #define MPB_PRE_READS (256 * MPB_PRE_ROUNDS)
 // class byte of a read the prepass already settled (MPB_FLAG_DECISION_ONLY): never scattered, never run
 #define MPB_CLS_SETTLED 0x7f
+// class byte of a wide read (more than MPB_TILE_MAX_ROWS rows predicted): listed for k_wide, never scattered
+#define MPB_CLS_WIDE 0x7e
 
 // Sort key of a read = (class, length bin of 2^MPB_LEN_SHIFT bases): perm[] is grouped by class and, inside a class,
 // by length, because a DP tile runs as long as its longest read.  Batches with one fixed length use a
@@ -86,6 +97,9 @@ struct MpbWorkspace {
     int32_t  *ovf_count;   // [1]
     int32_t  *bad_len;     // [1] lengths in d_len outside 0..max_len seen by the prepass (sticky; the host reports and clears it)
     long long *ovf_total;  // [1] overflow re-runs summed over the chunks of one host-pipeline call
+    int32_t  *wide_list;   // [n] reads the prepass classed as wide (only allocated for batches whose rows can hold > 1023 bases)
+    int32_t  *wide_rows;   // [n] ... and the rows predicted for each
+    int32_t  *wide_count;  // [1]
     unsigned long long *pass_count;  // [1]
     const double2 *lut;    // [256] {1-p, p'} on device
 };
@@ -107,6 +121,9 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
 void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                          const MpbDevParams &prm, const MpbWorkspace &ws, const int32_t *ns,
                          double *ee, uint8_t *pass, hipStream_t s);
+// wide reads of the main pass (ws.wide_list); only launched when prm.max_len + 1 > MPB_TILE_MAX_ROWS
+void mpb_launch_wide(const uint8_t *q, int64_t stride, const int32_t *len, const MpbDevParams &prm,
+                     const MpbWorkspace &ws, const int32_t *ns, double *ee, uint8_t *pass, hipStream_t s);
 void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, int32_t fixed_len,
                        const double2 *lut_ap, double *lambda, int32_t *ns, int32_t *bad, hipStream_t s);
 void mpb_launch_decode(const uint8_t *seq, const uint8_t *qual, int64_t n, int64_t stride, const int32_t *len,

@@ -42,11 +42,11 @@ __constant__ MpbClass c_classes[MPB_NCLS] = MPB_CLASS_TABLE;
 
 // rows -> smallest class whose cap >= rows, built at compile time
 struct ClassOfRows {
-    uint8_t t[MPB_MAX_LEN + 2];
+    uint8_t t[MPB_TILE_MAX_ROWS + 1];          // indexed by rows 0 .. MPB_TILE_MAX_ROWS; more rows = a wide read
     constexpr ClassOfRows() : t{}
     {
         constexpr MpbClass cl[MPB_NCLS] = MPB_CLASS_TABLE;
-        for (int rows = 0; rows < MPB_MAX_LEN + 2; rows++) {
+        for (int rows = 0; rows < MPB_TILE_MAX_ROWS + 1; rows++) {
             int c = 0;
             for (int k = 0; k < MPB_NCLS - 1; k++) c += (rows > cl[k].cap) ? 1 : 0;
             t[rows] = (uint8_t)c;
@@ -102,10 +102,11 @@ __device__ __forceinline__ int clamp_len(int li, int max_len) { return min(max(l
 // ds_read_b64 from a 256-entry float2 LUT {p, p(1-p)}, one packed f32 add (mu, var) and one fma
 // (sum of p*p(1-p), from which the third cumulant is var - 2*that).  Ambiguous bytes carry a large
 // marker in the second component (128 per 'N', 65536 per 'n'; a lane sees at most 256 bytes, whose
-// p(1-p) sum to <= 64, so both counts come off the lane total exactly with two floors).  Chunks that
+// p(1-p) sum to <= 64, so both counts come off the lane total exactly with two floors -- which is why a
+// row longer than 960 bytes is walked in panels of 60 chunk columns, peeled one by one).  Chunks that
 // are complete in every lane of the wave take a path without any masking; the ragged tail fills the
 // bytes past the read's end with Q254 (p = 4e-26).  The four lanes of a read are then combined in a
-// fixed order (deterministic).  Requires stride <= 1024 (16 chunks per lane; the C ABI enforces it).
+// fixed order (deterministic).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t mask_dword(uint32_t w, int nvalid_bytes)
@@ -145,7 +146,9 @@ __device__ __forceinline__ void pre_chunk(const float2 *tab, const uint4 x, f32x
         }
 }
 
-template <bool RAGGED>     // RAGGED <=> len != nullptr; the fixed-length instance has one length bin and no len loads
+// RAGGED <=> len != nullptr; the fixed-length instance has one length bin and no len loads.
+// LONG <=> rows of more than 960 bytes: walked in panels (below); the short-row instances are one panel by construction.
+template <bool RAGGED, bool LONG>
 __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, int64_t n,
                                                  int64_t stride, const int32_t *__restrict__ len_arg,
                                                  MpbDevParams prm, uint8_t *__restrict__ cls,
@@ -153,10 +156,13 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                                                  int32_t *__restrict__ ns_out,
                                                  double *__restrict__ ee_out,
                                                  uint8_t *__restrict__ pass_out,
-                                                 int32_t *__restrict__ bad_len)
+                                                 int32_t *__restrict__ bad_len,
+                                                 int32_t *__restrict__ wide_list,
+                                                 int32_t *__restrict__ wide_rows,
+                                                 int32_t *__restrict__ wide_count)
 {
     __shared__ float2 s_tab[256];
-    __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts}
+    __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts (bits of an int: N | n << 16)}
     __shared__ int s_hist[RAGGED ? MPB_SKEYS : MPB_NCLS];
     const int32_t *__restrict__ len = RAGGED ? len_arg : nullptr;
     constexpr int nb = RAGGED ? MPB_LEN_BINS : 1;   // length bins of the sort key (one fixed length: one bin)
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         const bool live = i < n;
         const int li = live ? (len ? clamp_len(len[i], prm.max_len) : prm.fixed_len) : 0;
         int ncol = (li + 15) >> 4;                // chunk columns to walk: the longest read of the 16
-        int nfull = live ? (li >> 4) : 1024;      // columns complete in every live lane
+        int nfull = live ? (li >> 4) : (1 << 20); // columns complete in every live lane
         if (len || wave_row0 + 64 > n) {
 #pragma unroll
             for (int off = 8; off >= 1; off >>= 1) {
@@ -191,23 +197,28 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         ncol = __builtin_amdgcn_readfirstlane(ncol);
         nfull = __builtin_amdgcn_readfirstlane(nfull);
         const uint8_t *src = q + (live ? i : (int64_t)0) * stride + cl * 16;
+        float mu = 0.f, var = 0.f, k3 = 0.f;
+        int ambi = 0;                              // 'N' count | 'n' count << 16
+        // A panel = 3 * MPB_PRE_NB column quads = at most 240 bytes per lane, so that the ambiguity markers come off
+        // the panel's sum exactly.  Rows of up to 960 bytes are one panel (and one set of sums, as before).
+        auto panel = [&](const int pb, const int pend) {
         f32x2 a01 = {0.f, 0.f};
         float s3 = 0.f;
         // MPB_PRE_NB column quads at a time: all their loads are issued before the first byte is
         // looked at (a row of 300 bases is one such batch), so a wave keeps 5 KiB in flight
-        for (int cb = 0; cb < ncol; cb += 4 * MPB_PRE_NB) {
+        for (int cb = pb; cb < pend; cb += 4 * MPB_PRE_NB) {
             uint4 xs[MPB_PRE_NB];
 #pragma unroll
             for (int b = 0; b < MPB_PRE_NB; b++) {
                 const int c0 = cb + 4 * b;
                 xs[b] = make_uint4(0, 0, 0, 0);
-                if (c0 < ncol && li > (c0 + cl) * 16)
+                if (c0 < pend && li > (c0 + cl) * 16)
                     xs[b] = *reinterpret_cast<const uint4 *>(src + c0 * 16);
             }
 #pragma unroll
             for (int b = 0; b < MPB_PRE_NB; b++) {
                 const int c0 = cb + 4 * b;
-                if (c0 >= ncol) break;                     // wave-uniform
+                if (c0 >= pend) break;                     // wave-uniform
                 uint4 y = xs[b];
                 if (c0 + 4 > nfull) {                      // wave-uniform: ragged tail, fill past the end
                     const int nv = li - (c0 + cl) * 16;
@@ -221,18 +232,23 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         const float n255 = floorf(a01.y * (1.0f / MPB_MARK_LOWER));
         const float rem = a01.y - MPB_MARK_LOWER * n255;
         const float nzero = floorf(rem * (1.0f / MPB_MARK_UPPER));
-        float mu = a01.x;
-        float var = rem - MPB_MARK_UPPER * nzero;
-        float k3 = var - 2.0f * s3;                                       // sum p(1-p)(1-2p)
-        float amb = nzero + 1024.0f * n255;
+        const float pvar = rem - MPB_MARK_UPPER * nzero;
+        mu += a01.x;
+        var += pvar;
+        k3 += pvar - 2.0f * s3;                                           // sum p(1-p)(1-2p)
+        ambi += (int)nzero + ((int)n255 << 16);
+        };  // panel
+        if (LONG) { for (int pb = 0; pb < ncol; pb += 12 * MPB_PRE_NB) panel(pb, min(ncol, pb + 12 * MPB_PRE_NB)); }
+        else panel(0, ncol);
         // the four lanes of a read, combined in a fixed order: (cl0 + cl1) + (cl2 + cl3)
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
             mu += __shfl_xor(mu, off);
             var += __shfl_xor(var, off);
             k3 += __shfl_xor(k3, off);
-            amb += __shfl_xor(amb, off);
+            ambi += __shfl_xor(ambi, off);
         }
+        const float amb = __int_as_float(ambi);
         if (cl == 0) s_row[w][rb + r16] = make_float4(mu, var, k3, amb);
     }
     wave_lds_fence();          // s_row[w] is private to this wave: no block barrier
@@ -243,22 +259,22 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             const float4 e = s_row[w][lane];
             const float mu = e.x, var = e.y, k3 = e.z;
             const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
-            if (RAGGED && li != len[i]) atomicAdd(bad_len, 1);            // never clamped silently: the host fails the call
-            const int ambi = (int)e.w;                                    // exact: integer-valued float < 2^24
-            const int nzero = ambi & 1023, n255 = ambi >> 10;
+            const int ambi = __float_as_int(e.w);
+            const int nzero = ambi & 0xffff, n255 = ambi >> 16;
             // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
             // rows 0..j* where j* is the first row whose CDF exceeds 1-alpha.
             const float v = fmaxf(var, 1e-12f);
             const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;
-            int rows = (int)floorf(x + 0.5f) + 1;
+            int rows = (int)floorf(fminf(x, 1e9f) + 0.5f) + 1;
             if (prm.flags & 4u) rows = rows / 2;                          // MPB_FLAG_TEST_UNDERPREDICT
             const int scored = li - nzero - n255;
             rows = min(rows, scored + 1);
             rows = max(rows, 1);
-            const int c = c_class_of_rows.t[min(rows, MPB_MAX_LEN + 1)];
-            ns_out[i] = nzero + n255;
+            const bool bad = RAGGED && li != len[i];
+            ns_out[i] = bad ? 0 : nzero + n255;
+            const int c = c_class_of_rows.t[min(rows, MPB_TILE_MAX_ROWS)];
             bool settled = false;
-            if (prm.flags & 8u) {                                         // MPB_FLAG_DECISION_ONLY
+            if (!bad && (prm.flags & 8u)) {                                         // MPB_FLAG_DECISION_ONLY
                 // Chernoff: P(X <= (1-d)mu) <= exp(-d^2 mu / 2) <= 1-alpha for d = clow/sqrt(mu), so the
                 // first CDF row above 1-alpha is > t = mu - clow*sqrt(mu) and ee >= floor(t).  mu is an
                 // fp32 sum of approximated p: shave 1e-4 relative and 0.02 absolute before trusting it.
@@ -266,10 +282,24 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                 const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
                 settled = mu > 1.0f && (double)floorf(t) > limit;
             }
-            if (settled) {
+            if (bad) {
+                // a length outside 0..max_len is never clamped silently: the read gets no result (NaN, rejected) --
+                // also for a caller that never fetches the counts -- and the call that does fetch them fails
+                atomicAdd(bad_len, 1);
+                cls[i] = (uint8_t)MPB_CLS_SETTLED;
+                ee_out[i] = __builtin_nan("");
+                pass_out[i] = 0;
+            } else if (settled) {
                 cls[i] = (uint8_t)(MPB_CLS_SETTLED | (nzero > 0 ? 0x80 : 0));
                 ee_out[i] = __builtin_inf();              // "certainly above the threshold"; NaN stays a failure
                 pass_out[i] = 0;
+            } else if (rows > MPB_TILE_MAX_ROWS) {
+                // wide read: more rows than one wave holds -> listed for k_wide (only possible when max_len >= 1024,
+                // and then the host has provided the list)
+                const int pos = atomicAdd(wide_count, 1);
+                wide_list[pos] = (int32_t)i;
+                wide_rows[pos] = rows;
+                cls[i] = (uint8_t)(MPB_CLS_WIDE | (nzero > 0 ? 0x80 : 0));
             } else {
                 cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
                 atomicAdd(&s_hist[c * nb + (len ? min(MPB_LEN_BINS - 1, li >> MPB_LEN_SHIFT) : 0)], 1);
@@ -392,7 +422,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
 #pragma unroll
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
         int c = c_r[round] == 0xff ? -1 : (c_r[round] & 0x7f);
-        if (c == MPB_CLS_SETTLED) c = -1;         // settled by the prepass: not part of any tile
+        if (c >= MPB_NCLS) c = -1;                // settled by the prepass, or wide (k_wide's list): not part of any tile
         kk_r[round] = c < 0 ? -1 : c * nb + (len ? min(MPB_LEN_BINS - 1, clamp_len(len_r[round], max_len) >> MPB_LEN_SHIFT) : 0);
     }
 #pragma unroll
@@ -783,6 +813,169 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(DpArgs args,
 }
 
 // ------------------------------------------------------------------------------------------
+// k_wide: reads that need more than MPB_TILE_MAX_ROWS rows of the DP table (long AND bad: more than ~1000
+// expected errors).  One workgroup of MPB_WIDE_WAVES waves per read; wave w keeps rows w*1024 .. w*1024+1023 of the
+// running vector in registers (lane l: 16 consecutive rows, as the widest tile class).  The recurrence
+//     v[j] = fl( fl(a*v[j]) + fl(b*v[j-1]) )
+// needs, for the first row of a wave, the last row of the wave before it as it was BEFORE this base -- a stream of
+// one double per base.  So the waves run one 64-base block apart (wave w works on block s - w in step s): wave w
+// writes the pre-update value of its last row for each base of its block into an LDS stream, wave w + 1 reads it
+// one step later; one workgroup barrier per 64 bases, two stream buffers per wave (written in step s, read in
+// step s + 1, rewritten in step s + 2).  Only the waves a read's row budget needs do any work.  The epilogue is
+// the same sequential CDF: the waves take their rows in order, the running sum handed on through LDS.
+// Same arithmetic as the tile classes (three roundings per cell, no FMA), so results are bit-identical with
+// the reference's at any length.
+// ------------------------------------------------------------------------------------------
+#define MPB_WIDE_R 16
+
+// result of one read: ref bernoullimodule.c:170-178 + moira.py:827-831,911,925-926,949-950 (as the tile epilogue)
+__device__ __forceinline__ void wide_report(const DpArgs &A, int idx, int li, int js, double lo, double hi, bool never_crossed)
+{
+    const double thr = A.prm.thr;
+    double e;
+    if (never_crossed) {
+        e = __builtin_nan("");                     // CDF never crosses: the reference runs off its table
+    } else {
+        e = (double)(js - 1) + ((thr - lo) / (hi - lo));
+        if (e < 0) e = 0;
+    }
+    const int nsv = gload(A.ns + idx);
+    if (A.prm.ambig_mode == 0) e = e + (double)nsv;
+    const double limit = (A.prm.maxerrors == A.prm.maxerrors) ? A.prm.maxerrors : (double)li * A.prm.uncert;
+    if (A.prm.flags & 1u) e = floor(e);
+    bool keep_read;
+    if (A.prm.ambig_mode == 2 && (gload(A.cls + idx) & 0x80)) keep_read = false;
+    else keep_read = e <= limit;
+    gstore(A.ee + idx, e);
+    gstore(A.pass + idx, (uint8_t)(keep_read ? 1 : 0));
+}
+
+template <bool FINAL>      // FINAL: every read gets len + 1 rows (the overflow pass); else the prepass' prediction
+__global__ __launch_bounds__(64 * MPB_WIDE_WAVES) void k_wide(DpArgs A, const double2 *__restrict__ lut_g,
+                                                              const int32_t *__restrict__ list,
+                                                              const int32_t *__restrict__ budget,
+                                                              const int32_t *__restrict__ count)
+{
+    constexpr int R = MPB_WIDE_R;
+    __shared__ double s_edge[MPB_WIDE_WAVES][2][64];
+    __shared__ double s_acc[MPB_WIDE_WAVES];        // CDF after the rows of waves 0..w
+    __shared__ int s_found[MPB_WIDE_WAVES];         // ... and whether it has crossed 1 - alpha by then
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (tid < 256) mpb_s_lut[tid] = lut_g[tid];
+    __syncthreads();
+    const int nlist = gload(count);
+    int keep = lane == 0 ? 0 : -1;
+    asm volatile("" : "+v"(keep));
+    const double thr = A.prm.thr;
+    for (int k = blockIdx.x; k < nlist; k += gridDim.x) {          // block-uniform: every barrier below is reached by all
+        const int idx = gload(list + k);
+        const int li = A.len ? clamp_len(gload(A.len + idx), A.prm.max_len) : A.prm.fixed_len;
+        const int rows = FINAL ? li + 1 : gload(budget + k);
+        const int nw = max(1, min(MPB_WIDE_WAVES, (rows + 64 * R - 1) / (64 * R)));
+        const int nblk = (li + 63) >> 6;
+        const uint8_t *row = A.q + (int64_t)idx * A.stride;
+
+        double v[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = 0.0;
+        if (tid == 0) v[0] = 1.0;
+
+        // lane l holds base t*64 + l of the wave's current block; bases past the read's end are byte 0 = the identity step
+        uint32_t curb = 0, nxtb = 0;
+        const int nsteps = nblk + nw - 1;
+        for (int s = 0; s < nsteps; s++) {
+            const int t = s - w;                                   // wave-uniform
+            if (w < nw && t >= 0 && t < nblk) {
+                if (t == 0) curb = (lane < li) ? (uint32_t)gload(row + lane) : 0u;
+                const int nb0 = (t + 1) * 64 + lane;
+                nxtb = (nb0 < li) ? (uint32_t)gload(row + nb0) : 0u;          // next block, in flight during this one
+                __builtin_amdgcn_sched_barrier(0);
+                const double *ein = &s_edge[w > 0 ? w - 1 : 0][(s + 1) & 1][0];   // what wave w-1 wrote in step s-1
+                double *eout = &s_edge[w][s & 1][0];
+#pragma unroll 1
+                for (int kb = 0; kb < 64; kb += 4) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++) {
+                        const uint32_t byte = (uint32_t)__builtin_amdgcn_readlane((int)curb, kb + tt);
+                        const double2 ab = mpb_s_lut[byte];
+                        const double top = v[R - 1];
+                        double cin = dpp_prev_row(top, keep);       // lane 0: 0
+                        if (w > 0) {                                // wave-uniform
+                            const double e = ein[kb + tt];
+                            cin = lane == 0 ? e : cin;
+                        }
+                        if (lane == 63) eout[kb + tt] = top;
+#pragma unroll
+                        for (int r = R - 1; r >= 1; r--) v[r] = cell<false>(ab.x, v[r], ab.y, v[r - 1]);
+                        v[0] = cell<false>(ab.x, v[0], ab.y, cin);
+                    }
+                }
+                curb = nxtb;
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue: sequential CDF over the rows of waves 0 .. nw-1 (ref: bernoullimodule.c:233-251) ----
+        for (int ww = 0; ww < nw; ww++) {
+            if (w == ww) {
+                const double acc0 = ww ? s_acc[ww - 1] : 0.0;
+                const int found0 = ww ? s_found[ww - 1] : 0;
+                double acc = acc0;
+                int found = found0;
+                if (!found0) {                                      // wave-uniform
+                    double acc_in_mine = 0.0;
+                    bool mine = false;
+#pragma unroll 1
+                    for (int g = 0; g < 64; g++) {
+                        double acc_s = acc0;
+                        int found_s = 0;
+                        if (g > 0) {
+                            acc_s = __shfl(acc, g - 1);
+                            found_s = __shfl(found, g - 1);
+                        }
+                        if (lane == g) {
+                            double a = acc_s;
+#pragma unroll
+                            for (int r = 0; r < R; r++) a = a + v[r];
+                            const bool cross = !found_s && (a > thr);
+                            mine = cross;
+                            acc_in_mine = acc_s;
+                            acc = a;
+                            found = found_s | (cross ? 1 : 0);
+                        }
+                    }
+                    if (mine) {
+                        double a = acc_in_mine, lo = 0.0, hi = 0.0;
+                        int js = -1;
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const double na = a + v[r];
+                            const bool hit = (js < 0) && (na > thr);
+                            lo = hit ? a : lo;
+                            hi = hit ? na : hi;
+                            js = hit ? (w * 64 * R + lane * R + r) : js;
+                            a = na;
+                        }
+                        wide_report(A, idx, li, js, lo, hi, false);
+                    }
+                }
+                if (lane == 63) { s_acc[ww] = acc; s_found[ww] = found; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0 && !s_found[nw - 1]) {                        // the CDF did not cross inside the row budget
+            if (FINAL) {
+                wide_report(A, idx, li, -1, 0.0, 0.0, true);
+            } else {
+                const int pos = atomicAdd(A.ovf_count, 1);
+                A.ovf_list[pos] = idx;
+            }
+        }
+        __syncthreads();                                           // s_acc / s_found / s_edge are reused by the next read
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_small: prediction + DP of ONE read per wave, one launch for the whole (small) batch.
 // The batched pipeline costs eight launches and a sort whatever the batch size; a caller that hands
 // over one read at a time (bernoulli.calculate_errors_PB from an unchanged moira.py) pays only
@@ -811,36 +1004,42 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
     if (i >= n) return;                                   // wave-uniform; no barrier below
     const MpbDevParams &prm = args.prm;
     const int li = args.len ? clamp_len(args.len[i], prm.max_len) : prm.fixed_len;
-    // lane k takes the 16-byte chunk k of the row (stride <= 1024: at most 64 chunks)
+    // lane k takes the 16-byte chunks k, k + 64, ... of the row (at most 16 of them: 256 bytes, so the markers peel exactly)
     f32x2 a01 = {0.f, 0.f};
     float s3 = 0.f;
-    const int nv = li - lane * 16;
-    if (nv > 0) {
-        uint4 y = *reinterpret_cast<const uint4 *>(args.q + i * args.stride + lane * 16);
-        y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
-        y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
-        pre_chunk(s_tab, y, a01, s3);
+    for (int c0 = 0; c0 * 16 < li; c0 += 64) {            // wave-uniform trip count
+        const int nv = li - (c0 + lane) * 16;
+        if (nv > 0) {
+            uint4 y = *reinterpret_cast<const uint4 *>(args.q + i * args.stride + (int64_t)(c0 + lane) * 16);
+            y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
+            y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
+            pre_chunk(s_tab, y, a01, s3);
+        }
     }
     const float n255 = floorf(a01.y * (1.0f / MPB_MARK_LOWER));
     const float rem = a01.y - MPB_MARK_LOWER * n255;
     const float nzero_f = floorf(rem * (1.0f / MPB_MARK_UPPER));
     float mu = a01.x, var = rem - MPB_MARK_UPPER * nzero_f;
-    float k3 = var - 2.0f * s3, amb = nzero_f + 1024.0f * n255;
+    float k3 = var - 2.0f * s3;
+    int ambi = (int)nzero_f + ((int)n255 << 16);
 #pragma unroll
     for (int off = 1; off <= 32; off <<= 1) {
         mu += __shfl_xor(mu, off);
         var += __shfl_xor(var, off);
         k3 += __shfl_xor(k3, off);
-        amb += __shfl_xor(amb, off);
+        ambi += __shfl_xor(ambi, off);
     }
-    const int ambi = (int)amb;
-    const int nzero = ambi & 1023, n_lower = ambi >> 10;
+    const int nzero = ambi & 0xffff, n_lower = ambi >> 16;
     const float v = fmaxf(var, 1e-12f);
     const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;           // as k_prepass
-    int rows = (int)floorf(x + 0.5f) + 1;
+    int rows = (int)floorf(fminf(x, 1e9f) + 0.5f) + 1;
     if (prm.flags & 4u) rows = rows / 2;                                  // MPB_FLAG_TEST_UNDERPREDICT
     rows = max(min(rows, li - nzero - n_lower + 1), 1);
-    const int c = c_class_of_rows.t[min(rows, MPB_MAX_LEN + 1)];
+    if (rows > MPB_TILE_MAX_ROWS) {                                       // a wide read: the host sends the batch down the pipeline
+        if (lane == 0) args.pass[i] = 2;
+        return;
+    }
+    const int c = c_class_of_rows.t[rows];
     bool settled = false;
     if (prm.flags & 8u) {                                                 // MPB_FLAG_DECISION_ONLY, as k_prepass
         const float t = mu * (1.0f - 1e-4f) - prm.clow * sqrtf(mu) - 0.02f;
@@ -1061,12 +1260,13 @@ void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
                         double *ee_out, uint8_t *pass_out, hipStream_t s)
 {
-    if (len)
-        hipLaunchKernelGGL((k_prepass<true>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm,
-                           ws.cls, ws.blockhist, ns_out, ee_out, pass_out, ws.bad_len);
-    else
-        hipLaunchKernelGGL((k_prepass<false>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm,
-                           ws.cls, ws.blockhist, ns_out, ee_out, pass_out, ws.bad_len);
+#define MPB_PRE_LAUNCH(RG, LG)                                                                                          \
+    hipLaunchKernelGGL((k_prepass<RG, LG>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, ws.cls,       \
+                       ws.blockhist, ns_out, ee_out, pass_out, ws.bad_len, ws.wide_list, ws.wide_rows, ws.wide_count)
+    const bool long_rows = prm.max_len > 16 * 12 * MPB_PRE_NB;        // more than one panel of 60 chunk columns
+    if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true); else MPB_PRE_LAUNCH(true, false); }
+    else     { if (long_rows) MPB_PRE_LAUNCH(false, true); else MPB_PRE_LAUNCH(false, false); }
+#undef MPB_PRE_LAUNCH
 }
 
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s)
@@ -1125,11 +1325,32 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
         hipLaunchKernelGGL((k_dp<false, false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, ws.tables, ws.perm, chunk_tiles);
 }
 
+// blocks of the wide kernel (one read per block and trip; the list length is only known on the device)
+#define MPB_WIDE_GRID 512
+
+void mpb_launch_wide(const uint8_t *q, int64_t stride, const int32_t *len, const MpbDevParams &prm,
+                     const MpbWorkspace &ws, const int32_t *ns, double *ee, uint8_t *pass, hipStream_t s)
+{
+    DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 0);
+    A.perm_ns = nullptr;
+    hipLaunchKernelGGL((k_wide<false>), dim3(MPB_WIDE_GRID), dim3(64 * MPB_WIDE_WAVES), 0, s, A, ws.lut, ws.wide_list,
+                       ws.wide_rows, ws.wide_count);
+}
+
 void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                          const MpbDevParams &prm, const MpbWorkspace &ws, const int32_t *ns,
                          double *ee, uint8_t *pass, hipStream_t s)
 {
     (void)n;
+    if (prm.max_len + 1 > MPB_TILE_MAX_ROWS) {
+        // no tile class covers len + 1 rows of this batch's longest reads: the overflow list goes to the wide kernel,
+        // every read with len + 1 rows (a short read of such a batch then simply keeps one wave busy)
+        hipLaunchKernelGGL(k_tables_overflow, dim3(1), dim3(64), 0, s, ws.tables2, ws.ovf_count, MPB_NCLS - 1, ws.ovf_total);
+        DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 1);
+        hipLaunchKernelGGL((k_wide<true>), dim3(MPB_WIDE_GRID), dim3(64 * MPB_WIDE_WAVES), 0, s, A, ws.lut, ws.ovf_list,
+                           (const int32_t *)nullptr, ws.ovf_count);
+        return;
+    }
     static const MpbClass classes[MPB_NCLS] = MPB_CLASS_TABLE;
     int wc = MPB_NCLS - 1;
     for (int c = MPB_NCLS - 1; c >= 0; c--)

@@ -350,34 +350,48 @@ def test_host_entry_overlapped_pipeline_ragged_config5(eng, oracle):
     assert same(r2.ee, ee) and r2.n_overflow > 10000
 
 
-def test_lengths_are_validated_never_clamped(eng):
-    """a read of exactly 1024 bases in a stride-1024 ragged batch used to be truncated to 1023
-    silently.  The reference scores every base it is given, so the call must fail instead."""
+def test_lengths_are_validated_never_clamped(eng, oracle):
+    """a length that does not fit its row used to be clamped silently (a 1024-base read in a stride-1024
+    batch was scored on 1023 bases).  The reference scores every base it is given, so: the host entry fails before
+    anything is computed; the device entry -- whose lengths live in HBM -- gives such a read ee = NaN, pass = 0
+    (also when the caller never fetches the counts, so an asynchronous caller can never consume a
+    result computed on a clamped length) and fails the call that does fetch them, once."""
     import ctypes as C
     from moira_amd import _lib as L
-    q = np.full((3, 1024), 30, np.uint8)
-    for bad in (1024, -1):
-        lens = np.array([100, bad, 1023], np.int32)
+    q = np.full((3, 1008), 30, np.uint8)
+    q[2, :] = 12
+    e_ok, _, p_ok, _ = oracle.filter_batch(q, lens=np.array([100, 1008, 1008], np.int32))
+    for bad in (1009, 20000, -1):
+        lens = np.array([100, bad, 1008], np.int32)
         with pytest.raises(ValueError):
             eng.filter(q, lens=lens)
         ee, ns, ps = np.empty(3), np.empty(3, np.int32), np.empty(3, np.uint8)
         prm = eng.params()
-        rc = eng.lib.mpb_filter_host(eng.ctx, q.ctypes.data, 3, 1024, lens.ctypes.data, 0, C.byref(prm),
+        rc = eng.lib.mpb_filter_host(eng.ctx, q.ctypes.data, 3, 1008, lens.ctypes.data, 0, C.byref(prm),
                                      ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, None)
         assert rc == L.E_INVALID
-        # device-resident lengths: the prepass counts what it had to clamp and the call reports it
         d_q, d_len = eng.alloc(q.nbytes).upload(q), eng.alloc(12).upload(lens)
         d_ee, d_ns, d_pass = eng.alloc(24), eng.alloc(12), eng.alloc(3)
+        # asynchronous form (counts = NULL): MPB_OK, and the bad row carries NaN / 0 -- the others their results
+        eng.filter_device(d_q, 3, 1008, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, want_counts=False)
+        eng.synchronize()
+        got_e, got_p = d_ee.download(np.float64, 3), d_pass.download(np.uint8, 3)
+        assert np.isnan(got_e[1]) and got_p[1] == 0
+        assert got_e[0] == e_ok[0] and got_e[2] == e_ok[2] and got_p[0] == p_ok[0] and got_p[2] == p_ok[2]
+        # a host-entry call in between is not failed by the count that call left behind (ADVICE r2)
+        r = eng.filter(q, lens=np.array([100, 1008, 1008], np.int32))
+        assert same(r.ee, e_ok)
+        # synchronous form: the call reports it
         with pytest.raises(ValueError, match="outside"):
-            eng.filter_device(d_q, 3, 1024, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
-        ok = np.array([100, 1023, 1023], np.int32)
+            eng.filter_device(d_q, 3, 1008, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+        ok = np.array([100, 1008, 1008], np.int32)
         d_len.upload(ok)
-        c = eng.filter_device(d_q, 3, 1024, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)   # the error does not stick
-        assert c.n_reads == 3
+        c = eng.filter_device(d_q, 3, 1008, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)   # the error does not stick
+        assert c.n_reads == 3 and same(d_ee.download(np.float64, 3), e_ok)
         for b in (d_q, d_len, d_ee, d_ns, d_pass):
             b.free()
     with pytest.raises(ValueError):
-        eng.filter(q, fixed_len=1024)
+        eng.filter(q, fixed_len=1009)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(alpha=0.05, uncert=0.02), dict(alpha=0.3), dict(maxerrors=6.0, ambigs="ignore"),
