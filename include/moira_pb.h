@@ -125,6 +125,13 @@ int mpb_device_count(void);
  * and :140-145 do, uploaded once. */
 int mpb_create(int device_id, mpb_ctx **out);
 int mpb_destroy(mpb_ctx *ctx);
+/* The table itself, for pinning it in tests ("the LUT values themselves are part of the fixtures"):
+ * a_out[q] = pow(1 - p, 1), b_out[q] = ((1-1+1)/(1.0*1)) * (p/(1-p)) * pow(1 - p, 1) with p = pow(10, q / -10.0),
+ * ref: moira/bernoullimodule.c:202,140-145; entries 0 ('N') and 255 ('n') are the identity step {1, 0}.
+ * mpb_host_lut computes it on the host exactly as mpb_create does (needs no device); mpb_device_lut reads back
+ * what the context uploaded.  256 doubles each. */
+int mpb_host_lut(double *a_out, double *b_out);
+int mpb_device_lut(mpb_ctx *ctx, double *a_out, double *b_out);
 /* The HIP stream the context launches on (as void*), for callers that want to
  * order their own work (e.g. torch) against it. */
 int mpb_stream(mpb_ctx *ctx, void **stream_out);

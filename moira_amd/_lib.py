@@ -45,6 +45,8 @@ PROTOTYPES = {
     "mpb_device_count": (C.c_int, []),
     "mpb_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "mpb_destroy": (C.c_int, [_VP]),
+    "mpb_host_lut": (C.c_int, [_VP, _VP]),
+    "mpb_device_lut": (C.c_int, [_VP, _VP, _VP]),
     "mpb_stream": (C.c_int, [_VP, C.POINTER(_VP)]),
     "mpb_synchronize": (C.c_int, [_VP]),
     "mpb_malloc": (C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),

@@ -149,6 +149,15 @@ static void build_lut(double2 *lut)
     }
 }
 
+int mpb_host_lut(double *a_out, double *b_out)
+{
+    if (!a_out || !b_out) return fail(MPB_E_INVALID, "mpb_host_lut: NULL output");
+    double2 h[256];
+    build_lut(h);
+    for (int q = 0; q < 256; q++) { a_out[q] = h[q].x; b_out[q] = h[q].y; }
+    return MPB_OK;
+}
+
 int mpb_create(int device_id, mpb_ctx **out)
 {
     if (!out) return fail(MPB_E_INVALID, "mpb_create: out is NULL");
@@ -222,6 +231,17 @@ int mpb_destroy(mpb_ctx *c)
         if (!(c)) return fail(MPB_E_INVALID, "%s: ctx is NULL", __func__); \
         HIPCHK(hipSetDevice((c)->device));                            \
     } while (0)
+
+int mpb_device_lut(mpb_ctx *c, double *a_out, double *b_out)
+{
+    CTXCHK(c);
+    if (!a_out || !b_out) return fail(MPB_E_INVALID, "mpb_device_lut: NULL output");
+    double2 h[256];
+    HIPCHK(hipMemcpyAsync(h, c->d_lut, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int q = 0; q < 256; q++) { a_out[q] = h[q].x; b_out[q] = h[q].y; }
+    return MPB_OK;
+}
 
 int mpb_stream(mpb_ctx *c, void **stream_out)
 {

@@ -291,6 +291,12 @@ class Engine:
             out[name] = (ms.value, cnt.value)
         return out
 
+    def device_lut(self):
+        """({1-p}, {p'}) as uploaded to this device (256 doubles each; ref: moira/bernoullimodule.c:202,140-145)."""
+        a, b = np.empty(256), np.empty(256)
+        L.check(self.lib.mpb_device_lut(self.ctx, a.ctypes.data, b.ctypes.data))
+        return a, b
+
     def read_budgets(self, n):
         """Row budget (class cap) of each of the first n reads of the last filter_device call."""
         out = np.empty(n, np.int32)
@@ -304,6 +310,13 @@ class Engine:
         if k < 0:
             L.check(k)
         return {int(caps[i]): int(cnts[i]) for i in range(k)}
+
+
+def host_lut():
+    """The library's Phred -> ({1-p}, {p'}) table computed on the host (no device needed)."""
+    a, b = np.empty(256), np.empty(256)
+    L.check(L.load().mpb_host_lut(a.ctypes.data, b.ctypes.data))
+    return a, b
 
 
 _default_engine = None

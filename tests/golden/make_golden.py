@@ -20,6 +20,13 @@ What runs here
     plus moira.py's make_contig on those alignments in its three consensus modes -> nw_contigs.npz.
   * moira.py's calculate_errors_poisson on >= 2,000 reads incl. the region where it raises
     OverflowError -> poisson.npz.
+  * `--long` (round 3): reads of 1024 .. 4096 bases -> long_reads.npz.  The C reference keeps its whole table on the
+    stack (moira/bernoullimodule.c:214: 8 (L+1) L' bytes, 134 MB at 4096 bases), so this mode re-runs itself in a
+    child process whose stack limit is raised first; the arithmetic is the reference's own, unmodified.  The Python
+    twin is run on the reads it can finish (it makes J^2 L / 2 Python calls).
+  * `--lut` (round 3): the Phred -> probability table and a set of libm probes (pow, exp) are added to kat.json as
+    hex-float strings, so that a libm difference between the build container and a GPU box shows up under its own
+    test name (last bullet).
 Only data (inputs + the reference's outputs) is written into the repo.
 
 The inputs are stored in the packed-qscore encoding of include/moira_pb.h
@@ -225,7 +232,7 @@ def unpack(row, n):
     return seq, quals
 
 
-def run_set(name, q, lens, alpha, ref, pyref, py_every=0):
+def run_set(name, q, lens, alpha, ref, pyref, py_every=0, py_mask=None):
     n = q.shape[0]
     ee_ref = np.full(n, np.nan)
     ns_ref = np.zeros(n, np.int32)
@@ -241,7 +248,7 @@ def run_set(name, q, lens, alpha, ref, pyref, py_every=0):
             ub[i] = 1            # C reads accumulated_probs[-1]; value is garbage, do not pin it
         else:
             ee_ref[i] = e
-        if ub[i] or (py_every and i % py_every == 0):
+        if ub[i] or (py_every and i % py_every == 0) or (py_mask is not None and py_mask[i]):
             # Python twin counts only 'N' (moira.py:1605); feed it the sequence with n->N so both
             # references see the same ambiguous set (the C semantics, which the build follows)
             ep, sp = pyref.calculate_errors_PB(seq.replace("n", "N"), quals, alpha)
@@ -306,11 +313,89 @@ def edge_cases(kat_q):
     return rows, alphas
 
 
+LONG_SPECS = [
+    # (length, q_lo, q_hi_exclusive, copies, also through the Python twin)
+    (1024, 30, 41, 2, True), (1025, 30, 41, 2, True), (1500, 25, 41, 2, True), (2500, 20, 41, 2, True),
+    (4096, 30, 41, 2, True), (1500, 8, 20, 1, True), (1100, 12, 30, 1, True),
+    (1100, 1, 3, 1, False), (1500, 1, 3, 2, False), (2500, 1, 4, 1, False), (2000, 2, 6, 1, False),
+    (4096, 2, 5, 1, False), (3000, 10, 25, 1, False),
+]
+
+
+def make_long_fixture(ref, pyref):
+    """Reads longer than the 1023 bases rounds 1-2 covered, through the REAL reference: rows needed from 3 to > 2000
+    (more than 1024 rows = more than one wave of the HIP path)."""
+    rng = np.random.default_rng(20161006)
+    rows, use_py = [], []
+    for L, lo, hi, copies, py in LONG_SPECS:
+        for c in range(copies):
+            r = rng.integers(lo, hi, L).astype(np.uint8)
+            if c == 1:                                   # ambiguous bases, also beyond column 960
+                r[rng.integers(0, L, 6)] = 0
+                r[rng.integers(960, L, 2)] = 255
+            rows.append(r)
+            use_py.append(py)
+    stride = 4096
+    q = np.zeros((len(rows), stride), np.uint8)
+    lens = np.zeros(len(rows), np.int32)
+    for i, r in enumerate(rows):
+        q[i, :len(r)] = r
+        lens[i] = len(r)
+    run_set("long_reads", q, lens, 0.005, ref, pyref, py_mask=np.array(use_py))
+    _, _, _, need = O.filter_batch(q, lens=lens, alpha=0.005, threads=8)
+    print("long_reads     rows needed: min %d, max %d, > 1024 rows: %d reads" % (need.min(), need.max(), int((need > 1024).sum())))
+
+
+def add_lut_to_kat():
+    """Phred -> {p, 1-p, p'} exactly as moira/bernoullimodule.c:202,140-145 evaluate them with THIS container's libm,
+    plus libm probes of the Poisson tail (moira/moira.py:1671: exp(-Lambda) * Lambda**j / factorial(j)), as hex floats."""
+    import math
+    path = os.path.join(HERE, "kat.json")
+    kat = json.load(open(path))
+    a, b = O.lut()
+    lut = {}
+    for qv in range(1, 255):
+        p = math.pow(10, qv / -10.0)
+        assert math.pow(1 - p, 1) == a[qv]
+        lut[str(qv)] = [float(p).hex(), float(a[qv]).hex(), float(b[qv]).hex()]
+    rng = np.random.default_rng(20161007)
+    probes = []
+    for lam in [0.01, 0.5, 1.0, 2.4, 6.932519986616133, 17.25, 40.0, 88.8, 150.0, 300.5, 700.0] + \
+            [float(x) for x in rng.uniform(0.001, 400.0, 29)]:
+        for j in (1, 2, 7, 33, 120, 170):
+            try:
+                pw = math.pow(lam, j)
+            except OverflowError:
+                pw = math.inf
+            probes.append([float(lam).hex(), j, float(math.exp(-lam)).hex(), float(pw).hex()])
+    kat["lut"] = {"source": "pow(10, q / -10.0), pow(1 - p, 1), ((1-1+1)/(1.0*1)) * (p/(1-p)) * pow(1-p, 1): "
+                            "moira/bernoullimodule.c:202,140-145; glibc of the build container", "q": lut}
+    kat["libm_probes"] = {"source": "exp(-lam), pow(lam, j) as moira/moira.py:1671 calls them", "rows": probes}
+    json.dump(kat, open(path, "w"), indent=0)
+    print("kat.json: lut (%d scores) and %d libm probes added" % (len(lut), len(probes)))
+
+
 def main():
     O.build()
+    if "--lut" in sys.argv:
+        add_lut_to_kat()
+        return
+    if "--long" in sys.argv and not os.environ.get("MAKE_GOLDEN_BIG_STACK"):
+        import resource
+
+        def big_stack():
+            resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+        sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__), "--long"], preexec_fn=big_stack,
+                                 env=dict(os.environ, MAKE_GOLDEN_BIG_STACK="1")))
     ref = O.reference_module()
     assert ref is not None, "oracle/_ref/bernoulli.so missing: make -C oracle ref"
     pyref, tmp = load_python_reference()
+    if "--long" in sys.argv:
+        try:
+            make_long_fixture(ref, pyref)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
     if "--only-new" in sys.argv:          # nw_*.npz and poisson.npz only (the PB sets are already committed)
         try:
             make_nw_fixtures(pyref, tmp)

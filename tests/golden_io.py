@@ -6,7 +6,8 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NPZ_SETS = ["rand_mixed", "rand_alpha05", "edge_alpha_1e-06", "edge_alpha_0.001", "edge_alpha_0.005",
-            "edge_alpha_0.05", "edge_alpha_0.5", "edge_alpha_0.9", "synth300", "synth250", "synth_ragged"]
+            "edge_alpha_0.05", "edge_alpha_0.5", "edge_alpha_0.9", "synth300", "synth250", "synth_ragged",
+            "long_reads"]      # long_reads: 1024 .. 4096 bases, up to 2169 DP rows, from the real reference (round 3)
 
 
 def load_set(name):
@@ -39,3 +40,12 @@ def expected_value(s):
     ub = s["ub"].astype(bool)
     exp[ub] = s["ee_py"][ub]
     return exp
+
+
+def lut_fixture():
+    """{q: (p, 1-p, p')} for q = 1..254 and the libm probes [(lam, j, exp(-lam), pow(lam, j))], decoded from the
+    hex-float strings make_golden.py --lut wrote (values of the build container's glibc)."""
+    kat = load_kat()
+    lut = {int(q): tuple(float.fromhex(x) for x in v) for q, v in kat["lut"]["q"].items()}
+    probes = [(float.fromhex(r[0]), int(r[1]), float.fromhex(r[2]), float.fromhex(r[3])) for r in kat["libm_probes"]["rows"]]
+    return lut, probes

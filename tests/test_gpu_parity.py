@@ -66,6 +66,25 @@ def test_dropin_error_behaviour(eng):
     assert f("NNnN", [20] * 4, 0.005) == (0.0, 4)
 
 
+def test_device_lut_and_box_libm_match_the_committed_fixture(eng):
+    """SURVEY §8c last bullet: what this GPU box's libm produced and the context uploaded, against the hex-float
+    table from the build container (tests/golden/kat.json).  A libm drift between the two machines fails this test by
+    name instead of the vector sets below."""
+    import math
+    lut, probes = G.lut_fixture()
+    a, b = eng.device_lut()
+    for q, (p, am, bm) in lut.items():
+        assert a[q] == am and b[q] == bm, q
+    assert (a[0], b[0], a[255], b[255]) == (1.0, 0.0, 1.0, 0.0)
+    for lam, j, e, pw in probes:                       # the Poisson tail's libm calls run on this box's host
+        assert math.exp(-lam) == e, lam
+        try:
+            got = math.pow(lam, j)
+        except OverflowError:
+            got = math.inf
+        assert got == pw, (lam, j)
+
+
 @pytest.mark.parametrize("name", G.NPZ_SETS)
 def test_reference_vectors_bit_exact(eng, name):
     s = G.load_set(name)

@@ -103,6 +103,41 @@ def test_lut_pins(oracle):
     assert (a[0], b[0], a[255], b[255]) == (1.0, 0.0, 1.0, 0.0)
 
 
+def test_lut_matches_the_committed_fixture(oracle):
+    """the LUT values are fixtures (hex floats from the build container's libm).  A libm that rounds
+    pow differently on another box fails HERE, by name, instead of as unexplained vector mismatches."""
+    lut, _ = G.lut_fixture()
+    a, b = oracle.lut()
+    assert sorted(lut) == list(range(1, 255))
+    for q, (p, am, bm) in lut.items():
+        assert math.pow(10, q / -10.0) == p, q          # this box's libm
+        assert a[q] == am and b[q] == bm, q             # the oracle's table
+
+
+def test_product_lut_matches_the_committed_fixture():
+    """The table libmoira_pb.so uploads (mpb_host_lut: the host-side construction, no device needed)."""
+    from moira_amd.engine import host_lut
+    lut, _ = G.lut_fixture()
+    a, b = host_lut()
+    for q, (p, am, bm) in lut.items():
+        assert a[q] == am and b[q] == bm and b[q] == p, q
+    assert (a[0], b[0], a[255], b[255]) == (1.0, 0.0, 1.0, 0.0)
+
+
+def test_libm_probes_of_the_poisson_tail():
+    """exp(-lam) and pow(lam, j) as moira/moira.py:1671 calls them: the host tail of --error_calc poisson uses this
+    box's libm, so its values are pinned too."""
+    _, probes = G.lut_fixture()
+    assert len(probes) >= 50
+    for lam, j, e, pw in probes:
+        assert math.exp(-lam) == e, lam
+        try:
+            got = math.pow(lam, j)
+        except OverflowError:
+            got = math.inf
+        assert got == pw, (lam, j)
+
+
 def test_synthetic_generator_is_pinned(oracle):
     for name, kw, stride in (("synth300", dict(fixed_len=300, seed=2), 320),
                              ("synth250", dict(fixed_len=250, seed=1), 256),
