@@ -22,6 +22,19 @@ per-kernel events; the per-kernel HIP-event timing behind `roofline` is taken in
 right after it.  Without --steps the timed region is sized to last >= 1 s (1.25 s of steps at the
 warm-up rate).
 
+Collectives (N > 1): the data path has none.  Barriers, the rank-uniform step count and the max over ranks go over a
+gloo group (CPU tensors: nothing that can hang on a GPU communicator brackets the timed region beyond
+torch.cuda.synchronize()); the one optional collective of the path -- the 24-byte pass / fail / overflow totals -- goes
+over RCCL (xGMI) when the communicator comes up, and over gloo otherwise: the RCCL group is created and tried in a helper
+thread with a deadline, every rank votes, and on any failure all ranks use gloo IN THE SAME PROCESS (a process that has
+touched the GPU is never re-executed).  The line records which backend carried the totals and each rank's device.
+`--rehearse-on-one-gpu` (ranks share device 0; at most 5 ranks: a GPU box allows 6 processes on its card) and
+`--rehearse-on-cpu` (no GPU at all: the step is a stub; any world size) exercise this launch / collective code.
+
+Weak-scaling anchor: N > 1 times 125 M reads per GPU (configs[3]); the plain N = 1 run times configs[1] (10 M reads, the
+metric's own configuration).  The single-GPU point of the SAME per-GPU workload is `extras.config4_shard` of the N = 1
+line, or `python bench.py --gpus 1 --reads 125000000`.
+
 One JSON line on rank 0.  Extra objects:
   roofline     dominant kernel (k_dp): algorithmic bytes (L + 13 per read) per launch
                / its mean duration measured with HIP events on the library's stream.
@@ -169,14 +182,193 @@ def _free_port():
     return p
 
 
-def self_launch(n):
+def visible_gpus():
+    """Number of GPUs this process could use, WITHOUT initialising any of them (torch.cuda.device_count() does not
+    create a context on this image; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES are honoured by it)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def self_launch(n, rehearsal):
     """`python bench.py --gpus N` without torchrun: start the ranks as a child job and hand its exit code on.
-    Nothing in THIS process has initialised the GPU (no torch / HIP import yet)."""
+    Nothing in THIS process has initialised the GPU (no HIP call; at most a device count in a grandchild)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not rehearsal:
+        # pre-flight in a throw-away child, so that this process never imports torch
+        try:
+            have = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                                      capture_output=True, text=True, timeout=300, env=env).stdout.strip().splitlines()[-1])
+        except Exception:
+            have = -1
+        if 0 <= have < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible on this node; nothing was started "
+                             "(use --rehearse-on-one-gpu / --rehearse-on-cpu for a dry run)\n" % (n, have))
+            return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+COLLECTIVE_TIMEOUT_S = 120          # rendezvous and every gloo collective; the RCCL attempt has its own deadline below
+RCCL_DEADLINE_S = 90
+
+
+class Collectives:
+    """The few, tiny collectives of an N > 1 run (see the module docstring).  world == 1: all no-ops."""
+
+    def __init__(self, world, rank, local_rank, use_gpu, try_rccl):
+        self.world, self.rank = world, rank
+        self.totals_backend = None
+        self.rccl_error = None
+        self._rccl = None
+        self._hung = False
+        if world == 1:
+            return
+        import datetime
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
+        self.totals_backend = "gloo"
+        if use_gpu and try_rccl:
+            ok = self._try_rccl(local_rank)
+            vote = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)             # every rank, unconditionally
+            if int(vote.item()) == 1:
+                self.totals_backend = "nccl"
+            else:
+                if ok:
+                    self.rccl_error = "another rank's RCCL communicator did not come up"
+                self._rccl = None
+
+    def _try_rccl(self, local_rank):
+        """Create the RCCL group and run one 24-byte all-reduce on it, in a helper thread with a deadline: an exception
+        or a hang on ANY rank turns into "use gloo" for all of them, never into a lost run."""
+        import datetime
+        import threading
+        torch, dist = self.torch, self.dist
+        box = {}
+
+        def attempt():
+            try:
+                torch.cuda.set_device(local_rank)               # the current device is per thread
+                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(minutes=30))
+                t = torch.ones(3, dtype=torch.int64, device="cuda")
+                dist.all_reduce(t, group=g)
+                torch.cuda.synchronize()
+                if int(t[0].item()) != self.world:
+                    raise RuntimeError("RCCL all-reduce returned %d, expected %d" % (int(t[0].item()), self.world))
+                box["group"] = g
+            except Exception as e:                              # noqa: BLE001 -- whatever it is, gloo takes over
+                box["error"] = repr(e)
+
+        th = threading.Thread(target=attempt, daemon=True)
+        th.start()
+        th.join(RCCL_DEADLINE_S)
+        if th.is_alive():
+            self._hung = True                                   # the thread stays parked; the process leaves through os._exit
+            self.rccl_error = "RCCL group creation / first all-reduce did not finish within %d s" % RCCL_DEADLINE_S
+            return False
+        if "error" in box:
+            self.rccl_error = box["error"]
+            return False
+        self._rccl = box["group"]
+        return True
+
+    # -- rank-uniform scalars and barriers: gloo, CPU tensors --
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def allmax(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(self, x):
+        if self.world == 1:
+            return [float(x)]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64)
+        t[self.rank] = float(x)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def gather_text(self, text, width=96):
+        """One short ASCII string per rank (device index / uuid), as fixed-width bytes: nothing is pickled."""
+        if self.world == 1:
+            return [text]
+        raw = text.encode("ascii", "replace")[:width].ljust(width, b" ")
+        t = self.torch.zeros(self.world, width, dtype=self.torch.uint8)
+        t[self.rank] = self.torch.frombuffer(bytearray(raw), dtype=self.torch.uint8)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [bytes(row.tolist()).decode("ascii").rstrip() for row in t]
+
+    def sum_totals(self, triple):
+        """pass / fail / overflow totals of all ranks: the path's one optional collective, over RCCL when up."""
+        if self.world == 1:
+            return [int(v) for v in triple]
+        torch, dist = self.torch, self.dist
+        if self._rccl is not None:
+            t = torch.tensor(list(triple), dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._rccl)
+            return [int(v) for v in t.tolist()]
+        t = torch.tensor(list(triple), dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [int(v) for v in t.tolist()]
+
+    def close(self):
+        if self.world == 1:
+            return
+        self.dist.barrier()
+        if self._hung:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)                                         # a parked RCCL thread must not hold the exit
+        self.dist.destroy_process_group()
+
+
+class StubEngine:
+    """--rehearse-on-cpu: no GPU, no library -- a step is a sleep.  Exists so that the launch shape, the port choice,
+    the rank-uniform step arithmetic and every collective of an N-rank run can be exercised at any world size on a box
+    without GPUs.  Never produces a number anyone should read."""
+
+    class _Counts:
+        n_pass = n_fail = n_overflow = 0
+
+    def __init__(self, n, rank, delay_ms):
+        self.n, self.delay = n, (1.0 + delay_ms * rank) * 1e-3
+        self.pending = 0
+
+    def step(self, counts=False):
+        self.pending += 1
+        if counts:
+            self.synchronize()
+            c = self._Counts()
+            c.n_pass, c.n_fail, c.n_overflow = self.n // 2, self.n - self.n // 2, 0
+            return c
+        return None
+
+    def synchronize(self):
+        time.sleep(self.delay * self.pending)
+        self.pending = 0
+
+
+def plan_steps(t_step_max, steps_arg, warmup):
+    """(steps, settle) from the RANK-UNIFORM step time (the max over ranks) -- plain arithmetic, so that every rank
+    takes the same branches and issues the same collectives (a collective under a rank-local condition
+    pairs up wrongly across ranks).  steps_arg <= 0: >= 1 s of timed work.  A timed region shorter than 1 s is
+    preceded by untimed steps until >= 0.5 s of back-to-back work has run (the chip lowers its clock under sustained
+    FP64 load; the number reported is the sustained one)."""
+    t = max(t_step_max, 1e-5)
+    steps = steps_arg if steps_arg > 0 else int(max(10.0, min(4000.0, 1.25 / t + 1)))
+    settle = int(max(0.0, 0.5 / t - max(warmup, 1) - 1)) if steps * t < 1.0 else 0
+    return steps, settle
 
 
 def main():
@@ -187,7 +379,8 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: as many as make the timed region >= 1 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 10 M at N=1 = configs[1]; "
-                                                          "125 M at N>1 = one eighth of configs[3])")
+                                                          "125 M at N>1 = one eighth of configs[3]; "
+                                                          "`--gpus 1 --reads 125000000` is the N=1 point of the weak-scaling curve)")
     ap.add_argument("--length", type=int, default=300)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--fast-fma", action="store_true", help="non-bit-exact FMA mode (not the headline)")
@@ -197,86 +390,107 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank dry run on a 1-GPU box: every rank uses device 0 and the (tiny) "
                          "collectives go over gloo; exercises the N>1 code path, not a scaling number")
+    ap.add_argument("--rehearse-on-cpu", action="store_true",
+                    help="multi-rank dry run without any GPU: the step is a stub; exercises launch + collectives only")
+    ap.add_argument("--no-rccl", action="store_true", help="do not try RCCL for the 24-byte totals (gloo only)")
+    ap.add_argument("--_rank-delay-ms", type=float, default=0.0, help=argparse.SUPPRESS)    # tests: rank r's stub step takes 1 + r*this ms
+    ap.add_argument("--_die-rank", type=int, default=-1, help=argparse.SUPPRESS)             # tests: this rank dies before the timed region
     args = ap.parse_args()
+    rehearsal = args.rehearse_on_one_gpu or args.rehearse_on_cpu
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-            sys.exit(self_launch(args.gpus))
+            sys.exit(self_launch(args.gpus, rehearsal))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
-
-    import torch
-    import torch.distributed as dist
-    from moira_amd.engine import Engine
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if args.rehearse_on_one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    coll_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
-    backend = None
-    if world > 1:
-        backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
+    use_gpu = not args.rehearse_on_cpu
+    if use_gpu:
+        import torch
+        have = visible_gpus()
+        if have < 1:
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
         if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def allmax(x):
-        if world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+            local_rank = 0
+        elif local_rank >= have:
+            raise SystemExit("rank %d wants GPU %d but only %d GPU(s) are visible (--gpus %d needs %d)"
+                             % (rank, local_rank, have, args.gpus, args.gpus))
+        torch.cuda.set_device(local_rank)
+    coll = Collectives(world, rank, local_rank, use_gpu, try_rccl=not (rehearsal or args.no_rccl))
 
     L = args.length
     n = args.reads or (CONFIG2_READS if world == 1 else CONFIG4_SHARD)
     stride = args.stride or (L + 63) // 64 * 64          # 300 -> 320
-    eng = Engine(local_rank)
-    d_q = eng.alloc(n * stride)
-    d_ee, d_ns, d_pass = eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
-    eng.synth_fill(d_q, n, stride, fixed_len=L, seed=args.seed, first_read=rank * n)
-    params = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", fast_fma=args.fast_fma)
+    if use_gpu:
+        from moira_amd.engine import Engine
+        eng = Engine(local_rank)
+        props = torch.cuda.get_device_properties(local_rank)
+        dev_text = "rank %d: GPU %d %s uuid %s" % (rank, local_rank, props.name, getattr(props, "uuid", "n/a"))
+        d_q = eng.alloc(n * stride)
+        d_ee, d_ns, d_pass = eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
+        eng.synth_fill(d_q, n, stride, fixed_len=L, seed=args.seed, first_read=rank * n)
+        params = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", fast_fma=args.fast_fma)
 
-    def step(counts=False):
-        return eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass,
-                                 params=params, want_counts=counts)
+        def step(counts=False):
+            return eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass,
+                                     params=params, want_counts=counts)
+
+        def device_sync():
+            eng.synchronize()
+            torch.cuda.synchronize()
+    else:
+        eng = StubEngine(n, rank, args._rank_delay_ms)
+        dev_text = "rank %d: no GPU (--rehearse-on-cpu)" % rank
+        step, device_sync = eng.step, eng.synchronize
+    sys.stderr.write(dev_text + "\n")
+    devices = coll.gather_text(dev_text)
+
+    def barrier():
+        device_sync()
+        coll.barrier()
 
     t0 = time.perf_counter()
     for _ in range(max(args.warmup, 1)):
         step()
-    eng.synchronize()
+    device_sync()
     t_warm = (time.perf_counter() - t0) / max(args.warmup, 1)
-    steps = args.steps
-    t1 = time.perf_counter(); step(); eng.synchronize(); t_one = time.perf_counter() - t1
-    t_step = max(min(t_one, t_warm), 1e-5)
-    if steps <= 0:                                        # >= 1 s of timed work, the same count on every rank
-        steps = int(allmax(max(10.0, min(4000.0, 1.25 / t_step + 1))))
-    # A short timed region (the driver's --steps 20 is 80 ms of work) would be measured at whatever clock the chip
-    # happens to hold when it starts; the chip lowers its clock under sustained FP64 load (MI355X_MICROARCH.md, DVFS).
-    # So the K timed steps are preceded by untimed steps until >= 0.5 s of back-to-back work has run: the number
-    # reported is the sustained one.  Reported as `settle_steps`; the timed region is still exactly K steps.
-    settle = int(allmax(max(0.0, 0.5 / t_step - max(args.warmup, 1) - 1))) if steps * t_step < 1.0 else 0
+    t1 = time.perf_counter(); step(); device_sync(); t_one = time.perf_counter() - t1
+    # the step time every decision below is made from is the SAME number on every rank (one unconditional collective)
+    t_step = coll.allmax(max(min(t_one, t_warm), 1e-5))
+    steps, settle = plan_steps(t_step, args.steps, args.warmup)
     for _ in range(settle):
         step()
-    eng.synchronize()
+    device_sync()
+    if rank == args._die_rank:
+        os._exit(3)                                      # tests: a rank that dies must fail the whole job, promptly
     # ---- the timed region: no events, no host round trips ----
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    eng.synchronize()
+    device_sync()
+    dt_rank = time.perf_counter() - t0                   # this rank's own time, before it waits for the others
     barrier()
-    dt_local = time.perf_counter() - t0
-    dt = allmax(dt_local)
+    dt = coll.allmax(time.perf_counter() - t0)
+    per_rank = [n * steps / t for t in coll.gather_floats(dt_rank)]
+    counts = step(counts=True)
+    n_pass, n_fail, n_ovf = coll.sum_totals((counts.n_pass, counts.n_fail, counts.n_overflow))
+
+    if not use_gpu:
+        if rank == 0:
+            print(json.dumps({"metric": "reads/sec filtered (300 bp synthetic)", "value": n * world * steps / dt, "unit": "reads/s",
+                              "n_gpus": world, "steps": steps, "warmup": args.warmup, "settle_steps": settle,
+                              "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f64", "data": "none (CPU rehearsal of the launch / collective code: the step is a stub)",
+                              "config": {"workload": "REHEARSAL ON CPU -- not a measurement", "reads_per_gpu": n,
+                                         "world_size": world, "collective_backend": "gloo (rehearsal)"},
+                              "t_step_rank_uniform_s": t_step, "timed_region_s": dt, "reads_per_s_per_rank": per_rank,
+                              "devices": devices, "outcome": {"pass": n_pass, "fail": n_fail, "overflow_reruns": n_ovf}}))
+        coll.close()
+        return
+
     # ---- per-kernel HIP events on the library's stream, in a pass of their own ----
     ev_steps = min(steps, 20)
     eng.timing(True)
@@ -286,7 +500,6 @@ def main():
     eng.synchronize()
     times = eng.kernel_times()
     eng.timing(False)
-    counts = step(counts=True)
     hist = eng.class_histogram()
     # extra (NOT the headline, work is skipped by design): opt-in MPB_FLAG_DECISION_ONLY, same batch
     extras = {}
@@ -334,21 +547,11 @@ def main():
         r_q.free()
         r_len.free()
         if world == 1:
+            extras["long_reads_ragged_50_2000"] = long_ragged_rate(eng, params)
             extras["host_fed"] = host_fed_rate(eng, L, stride, args.seed)
-            extras["config4_shard"] = config4_shard_rate(eng, L, stride, args.seed, params)
+            if n != CONFIG4_SHARD:
+                extras["config4_shard"] = config4_shard_rate(eng, L, stride, args.seed, params)
         extras["poisson_error_calc"] = poisson_rate(eng, d_q, n, stride, L, d_ee, d_ns)
-
-    per_rank = [n * steps / dt_local]
-    if world > 1:
-        cc = torch.tensor([counts.n_pass, counts.n_fail, counts.n_overflow], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(cc, op=dist.ReduceOp.SUM)      # the one optional collective: 24 bytes of totals
-        n_pass, n_fail, n_ovf = (int(x) for x in cc.tolist())
-        pr = torch.zeros(world, dtype=torch.float64, device=coll_dev)
-        pr[rank] = per_rank[0]
-        dist.all_reduce(pr, op=dist.ReduceOp.SUM)
-        per_rank = [float(x) for x in pr.tolist()]
-    else:
-        n_pass, n_fail, n_ovf = counts.n_pass, counts.n_fail, counts.n_overflow
 
     if rank == 0:
         total_reads = n * world * steps
@@ -378,11 +581,23 @@ def main():
         if world == 1:
             wl = ("BASELINE configs[1]: %d synthetic single-end %d bp reads, poisson_binomial filter, alpha 0.005, "
                   "uncert 0.01, resident in HBM (uint8 %d x %d, seed %d)" % (n, L, n, stride, args.seed))
+            if n == CONFIG4_SHARD:
+                wl = ("one shard of BASELINE configs[3] on one GPU (the N = 1 point of the weak-scaling curve): " + wl.split(": ", 1)[1])
         else:
             wl = ("BASELINE configs[3]: %d synthetic %d bp reads sharded host-side across %d x MI355X, %d reads "
                   "(%.1f GB resident, generated on device, read ids rank*R..) per GPU, poisson_binomial filter, "
                   "alpha 0.005, uncert 0.01 (uint8 %d x %d per GPU, seed %d)"
                   % (n * world, L, world, n, n * stride / 1e9, n, stride, args.seed))
+        if world == 1 and n != CONFIG4_SHARD:
+            shard = extras.get("config4_shard", {})
+            anchor = ("this N = 1 line times configs[1] (%d reads); runs with N > 1 time %d reads per GPU (configs[3]).  The "
+                      "single-GPU point of that per-GPU workload is extras.config4_shard of this line%s, or "
+                      "`python bench.py --gpus 1 --reads %d`"
+                      % (n, CONFIG4_SHARD, (" (%.4g reads/s)" % shard["reads_per_s"]) if "reads_per_s" in shard else "", CONFIG4_SHARD))
+        else:
+            anchor = ("every GPU holds %d reads; the N = 1 point of this curve is `python bench.py --gpus 1 --reads %d` "
+                      "(= extras.config4_shard of the plain N = 1 line), not the plain N = 1 line itself, which times "
+                      "configs[1] (%d reads)" % (n, n, CONFIG2_READS))
         line = {
             "metric": "reads/sec filtered (300 bp synthetic)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "settle_steps": settle,
@@ -391,10 +606,16 @@ def main():
             "config": {"workload": wl,
                        "reads_per_gpu": n, "read_length": L, "row_stride": stride,
                        "parallelism": "host-side split, %d rank(s), no data-path collective" % world,
-                       "collective_backend": ({"nccl": "RCCL", "gloo": "gloo (rehearsal)"}[backend] if backend else None),
+                       "collective_backend": (None if world == 1 else
+                                              {"nccl": "RCCL (24-byte totals); gloo (barriers, step count, max over ranks)",
+                                               "gloo": "gloo%s" % (" (rehearsal)" if rehearsal else
+                                                                   " (RCCL not used: %s)" % (coll.rccl_error or "--no-rccl"))}[coll.totals_backend]),
                        "world_size": world,
                        "mode": "fast_fma (NOT bit-exact)" if args.fast_fma else "bit-exact (no FMA)"},
+            "weak_scaling_anchor": anchor,
+            "devices": devices,
             "timed_region_s": dt,
+            "t_step_rank_uniform_s": t_step,
             "reads_per_s_per_rank": per_rank,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -425,12 +646,48 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line.update(cpu_baseline(args.seed, L, stride))
         print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
     for b in (d_q, d_ee, d_ns, d_pass):
         b.free()
     eng.close()
+    coll.close()
+
+
+def long_ragged_rate(eng, params, n=1_000_000, stride=2048):
+    """Round 3: ragged 50-2,000 bp reads (full-length-16S territory) in one stride-2048 matrix, resident: the tile
+    classes on long rows, the prepass' panel loop and -- for the reads that need more than 1024 DP rows -- k_wide.
+    A parity-test case (tests/test_gpu_long_reads.py), reported for reference; NOT the headline."""
+    out = {"note": "lengths U{50..2000} in one stride-2048 matrix (synthetic quality model of include/mpb_synth.h), resident, "
+                   "bit-exact mode; NOT the headline", "reads": n}
+    bufs = []
+    try:
+        bufs = [eng.alloc(n * stride), eng.alloc(n * 4), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)]
+        d_q, d_len, d_ee, d_ns, d_pass = bufs
+        eng.synth_fill(d_q, n, stride, fixed_len=0, min_len=50, max_len=2000, d_len=d_len, seed=7)
+        run = lambda c=False: eng.filter_device(d_q, n, stride, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass,
+                                                params=params, want_counts=c)
+        for _ in range(2):
+            run()
+        eng.synchronize()
+        k = 5
+        t = time.perf_counter()
+        for _ in range(k):
+            run()
+        eng.synchronize()
+        dt = (time.perf_counter() - t) / k
+        c = run(True)
+        hist = eng.class_histogram()
+        out.update({"ms_per_step": dt * 1e3, "reads_per_s": n / dt, "mean_length": 1025, "bases_per_s": n * 1025 / dt,
+                    "pass": c.n_pass, "overflow_reruns": c.n_overflow,
+                    "reads_in_wide_kernel": int(n - sum(hist.values()))})
+    except Exception as e:                                  # an extra must never cost the headline line
+        out["error"] = repr(e)
+    for b in bufs:
+        try:
+            b.free()
+        except Exception:
+            pass
+    return out
 
 
 def config4_shard_rate(eng, L, stride, seed, params, n=CONFIG4_SHARD, rank=3):

@@ -39,6 +39,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define MPB_OK            0
 #define MPB_E_INVALID    -1   /* bad argument (ValueError on the Python side)   */
@@ -200,6 +204,18 @@ int mpb_decode_ascii_device(mpb_ctx *ctx, const uint8_t *d_seq, const uint8_t *d
  * ref: moira/moira.py:1611,1629 vs moira/bernoullimodule.c:254).
  * d_ee[i] is the value process_data returns (after +Ns / floor).
  * Asynchronous on the context's stream unless `counts` is given.
+ *
+ * Read length: up to 16383 bases (row_stride <= 16384).  A read whose DP needs at most 1024 rows -- every read of
+ * up to 1023 bases, and any longer read with fewer than about a thousand expected errors -- runs in one wave
+ * (the running probability vector in registers, 16 rows per lane); one that needs more is run by a workgroup of up to
+ * 16 waves, the row that crosses a wave boundary travelling through an LDS stream.  Same arithmetic either way.
+ * (The reference's C extension keeps its table on the stack and overruns it near 1000 bases; its Python twin,
+ * ref: moira/moira.py:1561-1634, has no limit -- `--error_calc poisson_binomial_py`.)
+ *
+ * A length in d_len outside 0..min(row_stride, 16383) is NEVER clamped: that read gets ee = NaN, pass = 0, Ns = 0 (so
+ * a caller that passes counts == NULL and never synchronises on an error cannot consume a result computed on a
+ * different length), a device-side counter is raised, and the next call on this context that fetches `counts` from
+ * mpb_filter_device fails with MPB_E_INVALID and clears it.
  */
 int mpb_filter_device(mpb_ctx *ctx,
                       const uint8_t *d_q, int64_t n, int64_t row_stride,
@@ -213,13 +229,14 @@ int mpb_filter_device(mpb_ctx *ctx,
  * Replaces the per-read Pool.apply_async dispatch + .get() barrier of ref: moira/moira.py:431-454
  * with a chunked, double-buffered pipeline: the batch is cut into chunks of <= 128 MiB of qualities
  * (at least four per batch where it is large enough) and the host-to-device copy of chunk k+1, the kernels
- * of chunk k and the device-to-host copy of chunk k-1 run concurrently on three streams through three
- * pinned/device slots.  Inputs in pinned memory (mpb_host_alloc) are copied by DMA from where they lie.
+ * of chunk k and the device-to-host copy of chunk k-1 run concurrently on three streams through FOUR
+ * pinned/device slots (about 0.55 GiB of device memory, and as much pinned host memory when the input is pageable).
+ * Inputs in pinned memory (mpb_host_alloc) are copied by DMA from where they lie.
  * Batches of <= 4096 reads take one launch with one read per wave (what a per-read caller needs is
  * latency; MPB_FLAG_BATCHED_ONLY forces the batched pipeline); results are identical either way.
- * Lengths are validated, never clamped: a len[i] < 0, > row_stride or > 1023 fails the call with
- * MPB_E_INVALID before anything is computed (mpb_filter_device, whose lengths live on the device, reports
- * the same condition from a device-side counter when `counts` is requested).
+ * Lengths are validated, never clamped: a len[i] < 0, > row_stride or > 16383 fails the call with
+ * MPB_E_INVALID before anything is computed (mpb_filter_device, whose lengths live on the device, gives such a
+ * read ee = NaN, pass = 0 and reports the condition from a device-side counter when `counts` is requested).
  */
 int mpb_filter_host(mpb_ctx *ctx,
                     const uint8_t *q, int64_t n, int64_t row_stride,
@@ -293,6 +310,9 @@ int mpb_last_class_histogram(mpb_ctx *ctx, int32_t *caps, int64_t *counts, int32
  * tools/class_efficiency.py uses to build single-class batches.  Synchronises. */
 int mpb_last_read_budgets(mpb_ctx *ctx, int32_t *caps_out, int64_t n);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

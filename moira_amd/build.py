@@ -19,12 +19,14 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmoira_pb.so")
 SOURCES = [os.path.join(CSRC, "mpb_kernels.hip"), os.path.join(CSRC, "mpb_api.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "mpb_internal.h"),
+DEPS = SOURCES + [os.path.join(CSRC, "mpb_internal.h"), os.path.join(CSRC, "libmoira_pb.map"),
                   os.path.join(ROOT, "include", "moira_pb.h"),
                   os.path.join(ROOT, "include", "mpb_synth.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
          "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden",          # only what include/moira_pb.h declares is exported ...
+         "-Wl,--version-script=" + os.path.join(CSRC, "libmoira_pb.map"),   # ... not even weak std:: template instances
          "-x", "hip"]
 
 

@@ -107,14 +107,23 @@ static void parallel_copy(void *dst, const void *src, size_t bytes, int threads)
     if (threads <= 1 || bytes < (size_t)(8u << 20)) { memcpy(dst, src, bytes); return; }
     const size_t per = ((bytes + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;
     std::vector<std::thread> th;
-    for (int t = 1; t < threads; t++) {
-        const size_t lo = per * (size_t)t;
-        if (lo >= bytes) break;
-        const size_t len = bytes - lo < per ? bytes - lo : per;
-        th.emplace_back([=] { memcpy((char *)dst + lo, (const char *)src + lo, len); });
+    size_t done_to = per < bytes ? per : bytes;      // [0, done_to) is this thread's part; helpers take slices above it
+    try {
+        th.reserve((size_t)threads);
+        for (int t = 1; t < threads; t++) {
+            const size_t lo = per * (size_t)t;
+            if (lo >= bytes) break;
+            const size_t len = bytes - lo < per ? bytes - lo : per;
+            th.emplace_back([=] { memcpy((char *)dst + lo, (const char *)src + lo, len); });
+            done_to = lo + len;
+        }
+    } catch (...) {
+        // no thread to be had (a container's limit): nothing crosses the C ABI as an exception -- what the helpers
+        // did not take is copied here
     }
     memcpy(dst, src, bytes < per ? bytes : per);
     for (auto &t : th) t.join();
+    if (done_to < bytes) memcpy((char *)dst + done_to, (const char *)src + done_to, bytes - done_to);
 }
 
 extern "C" {
@@ -540,6 +549,8 @@ static MpbDevParams make_dev_params(const mpb_filter_params *p, int32_t fixed_le
     d.flags = p->flags;
     d.fixed_len = fixed_len;
     d.max_len = max_len;
+    d.len_shift = MPB_LEN_SHIFT;
+    while (((max_len - 1) >> d.len_shift) >= MPB_LEN_BINS) d.len_shift++;
     return d;
 }
 
@@ -649,7 +660,8 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
 #define MPB_SMALL_N 4096
 #endif
 // qualities per chunk of the host pipeline: large enough that a chunk's launch sequence (~0.2 ms fixed) is
-// noise beside its 2 ms of PCIe time, small enough that three slots stay below half a GiB
+// noise beside its 2 ms of PCIe time; the four slots then hold 4 x (128 MiB of qualities + 5.5 MiB of results) of device
+// memory, the same again of pinned staging when the input is pageable, and 4 x 5.5 MiB of pinned results
 #ifndef MPB_HOST_CHUNK_BYTES
 #define MPB_HOST_CHUNK_BYTES (128ll << 20)
 #endif
@@ -1106,12 +1118,20 @@ int mpb_poisson_finish_host(const double *lambda, const int32_t *ns, const int32
     if (threads <= 1) { run(0, n); return MPB_OK; }
     std::vector<std::thread> th;
     const int64_t per = (n + threads - 1) / threads;
-    for (int t = 1; t < threads; t++) {
-        const int64_t lo = per * t, hi = lo + per < n ? lo + per : n;
-        if (lo >= n) break;
-        th.emplace_back(run, lo, hi);
+    int64_t taken = per < n ? per : n;                 // helpers take [per, taken); the rest is done here
+    try {
+        th.reserve((size_t)threads);
+        for (int t = 1; t < threads; t++) {
+            const int64_t lo = per * t, hi = lo + per < n ? lo + per : n;
+            if (lo >= n) break;
+            th.emplace_back(run, lo, hi);
+            taken = hi;
+        }
+    } catch (...) {
+        // thread creation failed: never an exception across the C ABI, the remainder runs on this thread
     }
     run(0, per < n ? per : n);
+    if (taken < n) run(taken, n);
     for (auto &t : th) t.join();
     return MPB_OK;
 }

@@ -49,11 +49,11 @@ struct MpbClass { int cap, G, R; };
 // class byte of a wide read (more than MPB_TILE_MAX_ROWS rows predicted): listed for k_wide, never scattered
 #define MPB_CLS_WIDE 0x7e
 
-// Sort key of a read = (class, length bin of 2^MPB_LEN_SHIFT bases): perm[] is grouped by class and, inside a class,
+// Sort key of a read = (class, length bin of 2^len_shift bases): perm[] is grouped by class and, inside a class,
 // by length, because a DP tile runs as long as its longest read.  Batches with one fixed length use a
-// single bin.
+// single bin.  16 bins: 64 bases wide for rows of up to 1024 bases, wider (MpbDevParams.len_shift) for longer rows.
 #ifndef MPB_LEN_SHIFT
-#define MPB_LEN_SHIFT 6               // bin width 2^6 bases
+#define MPB_LEN_SHIFT 6               // narrowest bin width: 2^6 bases
 #endif
 #define MPB_LEN_BINS (1024 >> MPB_LEN_SHIFT)
 #define MPB_SKEYS (MPB_NCLS * MPB_LEN_BINS)
@@ -83,6 +83,7 @@ struct MpbDevParams {
     uint32_t flags;
     int32_t fixed_len;     // used when d_len == nullptr
     int32_t max_len;       // upper bound of every length in the batch (<= row_stride)
+    int32_t len_shift;     // length-bin width of the sort key: 2^len_shift bases, (max_len - 1) >> len_shift < MPB_LEN_BINS
 };
 
 struct MpbWorkspace {

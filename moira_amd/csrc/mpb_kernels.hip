@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                 cls[i] = (uint8_t)(MPB_CLS_WIDE | (nzero > 0 ? 0x80 : 0));
             } else {
                 cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
-                atomicAdd(&s_hist[c * nb + (len ? min(MPB_LEN_BINS - 1, li >> MPB_LEN_SHIFT) : 0)], 1);
+                atomicAdd(&s_hist[c * nb + (len ? min(MPB_LEN_BINS - 1, li >> prm.len_shift) : 0)], 1);
             }
         }
     }
@@ -396,7 +396,7 @@ __global__ void k_tables_overflow(MpbTables *__restrict__ tb, const int32_t *__r
 // order: no atomics, deterministic perm.
 template <bool RAGGED>
 __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls, int64_t n,
-                                                 const int32_t *__restrict__ len_arg, int max_len,
+                                                 const int32_t *__restrict__ len_arg, int max_len, int len_shift,
                                                  const int32_t *__restrict__ blockhist,
                                                  const MpbTables *__restrict__ tb,
                                                  const int32_t *__restrict__ ns,
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
         int c = c_r[round] == 0xff ? -1 : (c_r[round] & 0x7f);
         if (c >= MPB_NCLS) c = -1;                // settled by the prepass, or wide (k_wide's list): not part of any tile
-        kk_r[round] = c < 0 ? -1 : c * nb + (len ? min(MPB_LEN_BINS - 1, clamp_len(len_r[round], max_len) >> MPB_LEN_SHIFT) : 0);
+        kk_r[round] = c < 0 ? -1 : c * nb + (len ? min(MPB_LEN_BINS - 1, clamp_len(len_r[round], max_len) >> len_shift) : 0);
     }
 #pragma unroll
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
@@ -1280,10 +1280,10 @@ void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const 
                         hipStream_t s)
 {
     if (len)
-        hipLaunchKernelGGL((k_scatter<true>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len,
+        hipLaunchKernelGGL((k_scatter<true>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len, prm.len_shift,
                            ws.blockhist, ws.tables, ns, ws.perm, ws.perm_ns);
     else
-        hipLaunchKernelGGL((k_scatter<false>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len,
+        hipLaunchKernelGGL((k_scatter<false>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len, prm.len_shift,
                            ws.blockhist, ws.tables, ns, ws.perm, ws.perm_ns);
 }
 

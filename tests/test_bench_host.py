@@ -2,8 +2,11 @@
 start `torch.distributed.run` as a CHILD process (never exec, never after a GPU call) with the same arguments, and hand
 its exit code on; under torchrun (WORLD_SIZE set) it must not start anything."""
 import importlib.util
+import json
 import os
+import subprocess
 import sys
+import time
 
 import pytest
 
@@ -25,7 +28,11 @@ def test_plain_command_starts_its_ranks_as_a_child(monkeypatch):
         seen["cmd"], seen["env"] = cmd, env
         return 7
 
+    class Probe:                                                    # the device-count pre-flight (a throw-away child)
+        stdout = "8\n"
+
     monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: Probe())
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
     torch_loaded_before = "torch" in sys.modules
@@ -56,3 +63,73 @@ def test_usable_cpus_is_positive_and_bounded():
     n = bench.usable_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
     assert bench.CONFIG2_READS == 10_000_000 and bench.CONFIG4_SHARD * 8 == 1_000_000_000
+
+
+def test_preflight_refuses_more_ranks_than_gpus(monkeypatch, capsys):
+    """`--gpus 8` on a node that shows fewer GPUs must say so and return non-zero without starting
+    anything (no rendezvous to time out in)."""
+    bench = load_bench()
+
+    class Probe:
+        stdout = "4\n"
+
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: Probe())
+    monkeypatch.setattr(bench.subprocess, "call", lambda *a, **k: pytest.fail("must not launch"))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2
+    assert "only 4 GPU" in capsys.readouterr().err
+
+
+def test_step_plan_is_plain_arithmetic_on_the_rank_uniform_time():
+    """`steps` and `settle` used to be decided from a rank-LOCAL step time, with a collective inside
+    the branch -- at 48.5 ms/step x 20 steps = 0.97 s a 3 % slower rank took the other branch.  Now one unconditional
+    all-reduce(MAX) makes the time rank-uniform and this pure function decides; same input, same output on every rank."""
+    bench = load_bench()
+    assert bench.plan_steps(0.0485, 20, 5) == (20, 4)                # 0.97 s < 1 s: settle to 0.5 s of back-to-back work
+    assert bench.plan_steps(0.0500, 20, 5) == (20, 0)                # exactly 1 s: no settle -- on EVERY rank
+    assert bench.plan_steps(0.0038, 20, 5) == (20, 125)
+    steps, settle = bench.plan_steps(0.0038, 0, 3)                   # auto: >= 1 s of timed work
+    assert steps * 0.0038 >= 1.0 and settle == 0
+    assert bench.plan_steps(10.0, 0, 3)[0] == 10 and bench.plan_steps(1e-9, 0, 3)[0] == 4000
+    import inspect
+    body = inspect.getsource(bench.plan_steps)
+    assert "all_reduce" not in body and "allmax" not in body           # no collective can hide in a branch here
+
+
+def _run_bench(args, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+    return p, time.time() - t
+
+
+def test_eight_rank_rehearsal_on_cpu_with_unequal_ranks():
+    """The launch shape the driver's 8-GPU run uses, at world size 8, on a box with no GPU: the plain command starts
+    torchrun as a child, picks a port, every rank goes through the same collectives (gloo) although rank r's stub
+    step is (1 + 4 r) ms long -- i.e. the ranks measure very different local step times -- and rank 0 prints one line
+    with one rate and one device string per rank."""
+    p, _ = _run_bench(["--gpus", "8", "--rehearse-on-cpu", "--steps", "6", "--warmup", "1", "--reads", "1000", "--_rank-delay-ms", "4"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["steps"] == 6 and line["config"]["world_size"] == 8
+    assert len(line["reads_per_s_per_rank"]) == 8 and len(line["devices"]) == 8
+    assert all(d.startswith("rank %d:" % r) for r, d in enumerate(line["devices"]))
+    rates = line["reads_per_s_per_rank"]
+    assert rates[0] > 2 * rates[7] > 0                               # per-rank rates show the straggler (ADVICE r2, low)
+    assert line["t_step_rank_uniform_s"] >= 0.029                    # the slowest rank's step: 1 + 7 * 4 ms
+    assert line["settle_steps"] > 0                                  # 6 x 29 ms < 1 s: every rank settled, the same count
+    assert line["outcome"]["pass"] + line["outcome"]["fail"] == 8000
+    assert "REHEARSAL" in line["config"]["workload"]
+
+
+def test_a_dead_rank_fails_the_job_promptly():
+    """A rank that dies before the timed region: the plain command must come back non-zero well inside the collective
+    timeout, not hang (the driver gives the run 600 s)."""
+    p, took = _run_bench(["--gpus", "3", "--rehearse-on-cpu", "--steps", "3", "--warmup", "1", "--reads", "1000", "--_die-rank", "1"])
+    assert p.returncode != 0
+    assert took < 150, took
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -89,6 +89,31 @@ def test_bench_starts_its_own_ranks_from_the_plain_command():
     assert len(line["reads_per_s_per_rank"]) == 2 and all(v > 0 for v in line["reads_per_s_per_rank"])
     assert line["outcome"]["pass"] + line["outcome"]["fail"] == 600000
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert len(line["devices"]) == 2 and all("GPU 0" in d for d in line["devices"])
+    assert "gloo" in line["config"]["collective_backend"]
+
+
+def test_bench_four_rank_rehearsal_on_one_gpu():
+    """the widest rehearsal a 1-GPU box allows (the pool admits 6 processes on a card: four ranks, this
+    test process and one spare), 2 M reads per rank: port selection, the build lock under four simultaneous imports,
+    the rank-uniform step plan, per-rank device strings and rates, totals over all ranks.  The 8-rank shape itself is
+    rehearsed without a GPU in tests/test_bench_host.py."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--rehearse-on-one-gpu",
+                        "--reads", "2000000", "--steps", "4", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["steps"] == 4 and line["config"]["world_size"] == 4
+    assert len(line["reads_per_s_per_rank"]) == 4 and all(v > 0 for v in line["reads_per_s_per_rank"])
+    assert line["outcome"]["pass"] + line["outcome"]["fail"] == 8_000_000
+    assert line["settle_steps"] > 0 and line["t_step_rank_uniform_s"] > 0
+    assert "--gpus 1 --reads 2000000" in line["weak_scaling_anchor"]      # which N = 1 run anchors this curve
 
 
 def test_config2_size_order_invariance(eng):

@@ -26,6 +26,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     assert sorted(L.PROTOTYPES) == syms          # the ctypes table covers the whole header
     assert b"gfx950" in lib.mpb_version()
+    # ... and nothing else: the library is built with -fvisibility=hidden and a linker version script, so no mangled
+    # launch wrapper, no compiler-generated id and no weak std:: template instance leaks out (hygiene)
+    import shutil
+    import subprocess
+    if shutil.which("nm"):
+        out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+        assert exported == syms, sorted(set(exported) ^ set(syms))
 
 
 def test_no_cpu_fallback_without_device():
