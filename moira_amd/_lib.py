@@ -90,7 +90,7 @@ def load(build_if_missing=True):
     global LIB_PATH
     override = os.environ.get("MOIRA_PB_LIB")
     if override:
-        # experiment builds (tools/variants.sh) live OUTSIDE the tree and are selected here; the in-tree library
+        # experiment builds (tools/experiments/variants.sh) live OUTSIDE the tree and are selected here; the in-tree library
         # and its stamp are never touched by an experiment
         if not os.path.exists(override):
             raise MoiraPBError("MOIRA_PB_LIB=%s does not exist" % override)

@@ -850,18 +850,22 @@ __device__ __forceinline__ void wide_report(const DpArgs &A, int idx, int li, in
     gstore(A.pass + idx, (uint8_t)(keep_read ? 1 : 0));
 }
 
-template <bool FINAL>      // FINAL: every read gets len + 1 rows (the overflow pass); else the prepass' prediction
-__global__ __launch_bounds__(64 * MPB_WIDE_WAVES) void k_wide(DpArgs A, const double2 *__restrict__ lut_g,
-                                                              const int32_t *__restrict__ list,
-                                                              const int32_t *__restrict__ budget,
-                                                              const int32_t *__restrict__ count)
+// FINAL: every read gets len + 1 rows (the overflow pass); else the prepass' prediction.
+// W: waves per workgroup (2, 4, 8, 16).  An instance takes the reads of its list that need more than W/2 and at most
+// W waves (the W = 2 instance also those that need one: short reads of a long batch in the overflow pass) and skips the
+// others, so that a read of 2,000 rows occupies 128 lanes, not 1,024 -- the four instances are launched back to back.
+template <bool FINAL, int W>
+__global__ __launch_bounds__(64 * W) void k_wide(DpArgs A, const double2 *__restrict__ lut_g,
+                                                 const int32_t *__restrict__ list,
+                                                 const int32_t *__restrict__ budget,
+                                                 const int32_t *__restrict__ count)
 {
     constexpr int R = MPB_WIDE_R;
-    __shared__ double s_edge[MPB_WIDE_WAVES][2][64];
-    __shared__ double s_acc[MPB_WIDE_WAVES];        // CDF after the rows of waves 0..w
-    __shared__ int s_found[MPB_WIDE_WAVES];         // ... and whether it has crossed 1 - alpha by then
+    __shared__ double s_edge[W][2][64];
+    __shared__ double s_acc[W];                     // CDF after the rows of waves 0..w
+    __shared__ int s_found[W];                      // ... and whether it has crossed 1 - alpha by then
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    if (tid < 256) mpb_s_lut[tid] = lut_g[tid];
+    for (int k = tid; k < 256; k += 64 * W) mpb_s_lut[k] = lut_g[k];
     __syncthreads();
     const int nlist = gload(count);
     int keep = lane == 0 ? 0 : -1;
@@ -872,6 +876,7 @@ __global__ __launch_bounds__(64 * MPB_WIDE_WAVES) void k_wide(DpArgs A, const do
         const int li = A.len ? clamp_len(gload(A.len + idx), A.prm.max_len) : A.prm.fixed_len;
         const int rows = FINAL ? li + 1 : gload(budget + k);
         const int nw = max(1, min(MPB_WIDE_WAVES, (rows + 64 * R - 1) / (64 * R)));
+        if (nw > W || (W > 2 && nw <= W / 2)) continue;            // another instance's read (block-uniform)
         const int nblk = (li + 63) >> 6;
         const uint8_t *row = A.q + (int64_t)idx * A.stride;
 
@@ -1325,16 +1330,27 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
         hipLaunchKernelGGL((k_dp<false, false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, ws.tables, ws.perm, chunk_tiles);
 }
 
-// blocks of the wide kernel (one read per block and trip; the list length is only known on the device)
-#define MPB_WIDE_GRID 512
+// blocks of a wide-kernel instance (one read per block and trip; the list length is only known on the device)
+#define MPB_WIDE_GRID 1024
+
+// the instances whose wave count a batch with up to `max_rows` rows per read can need
+template <bool FINAL>
+static void launch_wide(const DpArgs &A, const double2 *lut, const int32_t *list, const int32_t *budget,
+                        const int32_t *count, int max_rows, hipStream_t s)
+{
+    const int max_waves = (max_rows + MPB_TILE_MAX_ROWS - 1) / MPB_TILE_MAX_ROWS;
+    hipLaunchKernelGGL((k_wide<FINAL, 2>), dim3(MPB_WIDE_GRID), dim3(64 * 2), 0, s, A, lut, list, budget, count);
+    if (max_waves > 2) hipLaunchKernelGGL((k_wide<FINAL, 4>), dim3(MPB_WIDE_GRID), dim3(64 * 4), 0, s, A, lut, list, budget, count);
+    if (max_waves > 4) hipLaunchKernelGGL((k_wide<FINAL, 8>), dim3(MPB_WIDE_GRID), dim3(64 * 8), 0, s, A, lut, list, budget, count);
+    if (max_waves > 8) hipLaunchKernelGGL((k_wide<FINAL, 16>), dim3(MPB_WIDE_GRID), dim3(64 * 16), 0, s, A, lut, list, budget, count);
+}
 
 void mpb_launch_wide(const uint8_t *q, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                      const MpbWorkspace &ws, const int32_t *ns, double *ee, uint8_t *pass, hipStream_t s)
 {
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 0);
     A.perm_ns = nullptr;
-    hipLaunchKernelGGL((k_wide<false>), dim3(MPB_WIDE_GRID), dim3(64 * MPB_WIDE_WAVES), 0, s, A, ws.lut, ws.wide_list,
-                       ws.wide_rows, ws.wide_count);
+    launch_wide<false>(A, ws.lut, ws.wide_list, ws.wide_rows, ws.wide_count, prm.max_len + 1, s);
 }
 
 void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
@@ -1347,8 +1363,7 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
         // every read with len + 1 rows (a short read of such a batch then simply keeps one wave busy)
         hipLaunchKernelGGL(k_tables_overflow, dim3(1), dim3(64), 0, s, ws.tables2, ws.ovf_count, MPB_NCLS - 1, ws.ovf_total);
         DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 1);
-        hipLaunchKernelGGL((k_wide<true>), dim3(MPB_WIDE_GRID), dim3(64 * MPB_WIDE_WAVES), 0, s, A, ws.lut, ws.ovf_list,
-                           (const int32_t *)nullptr, ws.ovf_count);
+        launch_wide<true>(A, ws.lut, ws.ovf_list, nullptr, ws.ovf_count, prm.max_len + 1, s);
         return;
     }
     static const MpbClass classes[MPB_NCLS] = MPB_CLASS_TABLE;

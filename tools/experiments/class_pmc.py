@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """One single-class batch (rows of the config-2 workload whose row budget is CAP, replicated on the device) run
-through the pipeline a few times: the workload for `rocprofv3 --pmc ... -- python3 tools/class_pmc.py CAP`."""
+through the pipeline a few times: the workload for `rocprofv3 --pmc ... -- python3 tools/experiments/class_pmc.py CAP`."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from moira_amd.engine import Engine  # noqa: E402

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Instruction mix of the hot loop of every DP class body (from hipcc -S), and the loop text of two of them.
-    python tools/isa_mix.py > profiles/r01_k_dp_hot_loops.txt"""
+    python tools/experiments/isa_mix.py > profiles/r01_k_dp_hot_loops.txt"""
 import os
 import re
 import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out = os.path.join(tempfile.mkdtemp(), "k.s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off",
                        "-fno-fast-math", "-S", "--cuda-device-only", "-x", "hip",

@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from moira_amd.engine import Engine
 n, L, stride = 10_000_000, 300, 320
 def setup(eng, n, first):

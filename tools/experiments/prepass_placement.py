@@ -4,7 +4,7 @@ inside one allocation, (b) fresh allocations."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from moira_amd.engine import Engine  # noqa: E402
 

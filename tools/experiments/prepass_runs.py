@@ -4,7 +4,7 @@ processes of the same binary by up to 14 %)."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from moira_amd.engine import Engine  # noqa: E402
 

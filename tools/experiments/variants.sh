@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX: interleaved in-session comparison of compile-time variants of the library.
-#   tools/variants.sh [-n rounds] [-t] [-p "COUNTERS"] name1:"-DX=1 -DY=2" name2:"" name3:""@path/to/other_kernels.hip ...
+#   tools/experiments/variants.sh [-n rounds] [-t] [-p "COUNTERS"] name1:"-DX=1 -DY=2" name2:"" name3:""@path/to/other_kernels.hip ...
 #     -t            also run the GPU parity tests against every variant first
 #     -p "C1 C2"    also one rocprofv3 --pmc pass per variant (k_dp / k_prepass rows)
-#   VARIANT_CMD="python tools/config5_rate.py 5000000" VARIANT_TAIL=2 tools/variants.sh ...   (another workload)
+#   VARIANT_CMD="python tools/config5_rate.py 5000000" VARIANT_TAIL=2 tools/experiments/variants.sh ...   (another workload)
 # Variants are built into /tmp/var and selected with MOIRA_PB_LIB (moira_amd/_lib.py): the tree's library and
 # its stamp are never touched, so an interrupted run cannot leave an experiment build behind.
 N=3; TESTS=0; PMC=""
