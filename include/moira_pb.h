@@ -246,6 +246,25 @@ int mpb_filter_host(mpb_ctx *ctx,
                     mpb_filter_counts *counts);
 
 /*
+ * The same batch call over SEVERAL contexts (normally one per GPU of the node) from one host process: the batch is
+ * cut into n_ctx contiguous, balanced shards in read order, one host thread per context runs mpb_filter_host
+ * (poisson == 0) or mpb_filter_poisson_host (poisson != 0) on its shard, and every shard's results land in the
+ * caller's arrays at the shard's offset -- gathered in read order, no exchange step, no collective.
+ * Replaces `Pool(args.processors)` of ref: moira/moira.py:398-399 for a host-fed caller: n_ctx PCIe links from one
+ * process.  A context must not be listed twice.  counts (may be NULL) receives the totals over all shards.
+ * On failure the status and message of the first failing shard are returned (other shards may have completed).
+ */
+/* The split mpb_filter_host_multi uses (and moira_amd/shard.py, for one process per GPU): rank r of `world` owns the
+ * contiguous range [*lo, *hi) of n reads; the first n % world ranks get one read more.  Host-only. */
+int mpb_shard_bounds(int64_t n, int32_t world, int32_t rank, int64_t *lo, int64_t *hi);
+int mpb_filter_host_multi(mpb_ctx *const *ctxs, int32_t n_ctx,
+                          const uint8_t *q, int64_t n, int64_t row_stride,
+                          const int32_t *len, int32_t fixed_len,
+                          const mpb_filter_params *params,
+                          double *ee, int32_t *ns, uint8_t *pass,
+                          mpb_filter_counts *counts, int32_t poisson);
+
+/*
  * One read, the exact signature-level twin of
  *   bernoulli.calculate_errors_PB(contig, contig_quals, alpha) -> (ee, Ns)
  * ref: moira/bernoullimodule.c:66-114.  Validates alpha in (0,1) (:79-83),

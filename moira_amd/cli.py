@@ -190,7 +190,11 @@ def build_parser():
     eu.add_argument("-me", "--maxerrors", type=float, help="Maximum allowed errors per sequence.")
     f.add_argument("-a", "--alpha", type=float, default=0.005, help="Alpha cutoff value for the error distributions.")
     f.add_argument("-b", "--bootstrap", type=int, default=100, help="Number of replicates to use with the bootstrap method")
-    f.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK or 0).")
+    f.add_argument("--device", type=str, default=None,
+                   help="(not in moira.py) GPU index (default: LOCAL_RANK or 0), a comma-separated list of indices, or "
+                        "'all': with more than one GPU every chunk is split over them in read order from this one "
+                        "process (one host thread and one PCIe link per GPU) -- the role --processors had for "
+                        "moira.py's per-read pool.")
     f.add_argument("--fast_discard", action="store_true",
                    help="(not in moira.py) skip the exact error calculation for reads that provably exceed the "
                         "threshold; only with --collapse false and the mothur pipeline, where the expected errors "
@@ -407,11 +411,34 @@ def calculate_errors_bootstrap(sequence, quals, alpha, bootstrap):
 # ---------------------------------------------------------------------------------------------
 # the filter half of process_data for a chunk (ref: moira/moira.py:784-833)
 # ---------------------------------------------------------------------------------------------
+def parse_devices(device):
+    """--device value -> [int, ...] or ["all"] (None: LOCAL_RANK or 0)."""
+    if device is None:
+        return [int(os.environ.get("LOCAL_RANK", "0"))]
+    if isinstance(device, int):
+        return [device]
+    text = str(device).strip()
+    if text.lower() == "all":
+        return ["all"]
+    try:
+        devs = [int(x) for x in text.split(",") if x.strip() != ""]
+    except ValueError:
+        devs = []
+    if not devs or min(devs) < 0:
+        raise ValueError("--device wants a GPU index, a comma-separated list of indices, or 'all' (got %r)" % (device,))
+    return devs
+
+
 def make_gpu_backend(device=None):
     """Default (and only product) backend: the HIP library.  Fails loudly without a GPU."""
     from .buckets import filter_bucketed
     from .engine import Engine
-    eng = Engine(int(os.environ.get("LOCAL_RANK", "0")) if device is None else device)
+    devs = parse_devices(device)
+    if len(devs) == 1:
+        eng = Engine(devs[0])
+    else:
+        from .shard import MultiEngine
+        eng = MultiEngine(None if devs == ["all"] else devs)
 
     def backend(seqs, quals, alpha, ambigs, round_, method="poisson_binomial", fast_discard=None):
         if fast_discard is not None and method == "poisson_binomial":

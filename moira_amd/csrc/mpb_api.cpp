@@ -1157,6 +1157,70 @@ int mpb_filter_poisson_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row
     return filter_host_pipeline(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts, 1);
 }
 
+// ---- one host process, several GPUs ("one host thread (or process) + one HIP stream per device") ----
+//
+// The batch is cut into n_ctx contiguous, balanced shards in read order (shard r = reads [r*n/W + min(r, n%W), ...), the
+// same bounds as moira_amd/shard.py:shard_bounds); one host thread per context runs the ordinary host pipeline on its
+// shard and writes straight into the caller's arrays at the shard's offset, so the results come back gathered in read
+// order with no copy and no exchange step.  Every context keeps its own streams, slots and workspace (contexts are
+// independent: tests/test_gpu_parity.py::test_two_contexts_from_two_threads); a host-fed caller thereby drives one
+// PCIe link per GPU from one process -- what moira's `Pool(args.processors)` (moira/moira.py:398-399) was for.
+int mpb_shard_bounds(int64_t n, int32_t world, int32_t rank, int64_t *lo, int64_t *hi)
+{
+    if (n < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return fail(MPB_E_INVALID, "mpb_shard_bounds: bad arguments");
+    const int64_t base = n / world, rem = n % world;
+    *lo = rank * base + (rank < rem ? rank : rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+    return MPB_OK;
+}
+
+int mpb_filter_host_multi(mpb_ctx *const *ctxs, int32_t n_ctx, const uint8_t *q, int64_t n, int64_t row_stride,
+                          const int32_t *len, int32_t fixed_len, const mpb_filter_params *params, double *ee,
+                          int32_t *ns, uint8_t *pass, mpb_filter_counts *counts, int32_t poisson)
+{
+    if (!ctxs || n_ctx < 1) return fail(MPB_E_INVALID, "mpb_filter_host_multi: no context");
+    for (int k = 0; k < n_ctx; k++) {
+        if (!ctxs[k]) return fail(MPB_E_INVALID, "mpb_filter_host_multi: context %d is NULL", k);
+        for (int j = 0; j < k; j++)
+            if (ctxs[j] == ctxs[k]) return fail(MPB_E_INVALID, "mpb_filter_host_multi: context %d is listed twice (calls on one context must not overlap)", k);
+    }
+    if (n < 0) return fail(MPB_E_INVALID, "n < 0");
+    if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
+    struct Shard { int64_t lo = 0, hi = 0; int rc = MPB_OK; mpb_filter_counts c{}; char err[sizeof(g_err)] = ""; };
+    std::vector<Shard> sh((size_t)n_ctx);
+    for (int r = 0; r < n_ctx; r++) (void)mpb_shard_bounds(n, n_ctx, r, &sh[(size_t)r].lo, &sh[(size_t)r].hi);
+    auto work = [&](int r) {
+        Shard &S = sh[(size_t)r];
+        const int64_t m = S.hi - S.lo;
+        const uint8_t *qs = q ? q + S.lo * row_stride : q;
+        const int32_t *ls = len ? len + S.lo : nullptr;
+        if (poisson)
+            S.rc = mpb_filter_poisson_host(ctxs[r], qs, m, row_stride, ls, fixed_len, params, ee ? ee + S.lo : ee,
+                                           ns ? ns + S.lo : ns, pass ? pass + S.lo : pass, &S.c);
+        else
+            S.rc = mpb_filter_host(ctxs[r], qs, m, row_stride, ls, fixed_len, params, ee ? ee + S.lo : ee,
+                                   ns ? ns + S.lo : ns, pass ? pass + S.lo : pass, &S.c);
+        if (S.rc != MPB_OK) snprintf(S.err, sizeof(S.err), "%s", g_err);      // g_err is thread-local: carry it out
+    };
+    std::vector<std::thread> th;
+    int started = 1;                                   // shard 0 runs on the calling thread
+    try {
+        th.reserve((size_t)n_ctx);
+        for (int r = 1; r < n_ctx; r++) { th.emplace_back(work, r); started = r + 1; }
+    } catch (...) {
+        // no thread to be had: the shards that got none run on this thread, one after the other
+    }
+    work(0);
+    for (int r = started; r < n_ctx; r++) work(r);
+    for (auto &t : th) t.join();
+    for (int r = 0; r < n_ctx; r++) {
+        const Shard &S = sh[(size_t)r];
+        if (S.rc != MPB_OK) return fail(S.rc, "shard %d of %d (reads %lld..%lld): %s", r, n_ctx, (long long)S.lo, (long long)S.hi - 1, S.err);
+        if (counts) { counts->n_pass += S.c.n_pass; counts->n_fail += S.c.n_fail; counts->n_overflow += S.c.n_overflow; }
+    }
+    return MPB_OK;
+}
+
 int mpb_synth_fill_device(mpb_ctx *c, uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,
                           int32_t min_len, int32_t max_len, int32_t *d_len, uint64_t seed, int64_t first_read)
 {

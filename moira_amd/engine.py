@@ -57,6 +57,35 @@ class FilterResult:
         self.n_pass, self.n_fail, self.n_overflow = n_pass, len(ee) - n_pass, n_overflow
 
 
+def check_host_batch(q, lens, fixed_len, out, limit):
+    """Argument checks shared by every host-batch entry (one GPU or several): -> (q, n, stride, lens, (ee, ns, ps)).
+    `limit`: longest read the method takes (None: as long as the row)."""
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    if q.ndim != 2:
+        raise ValueError("q must be a 2-D (reads x stride) uint8 matrix")
+    n, stride = q.shape
+    if lens is not None:
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        if lens.shape != (n,):
+            raise ValueError("lens must have one entry per read")
+        if n and (lens.min() < 0 or lens.max() > stride):
+            raise ValueError("a length does not fit the row stride")
+        if n and limit is not None and lens.max() > limit:
+            raise ValueError("reads longer than %d bases are not supported (longest: %d)" % (limit, int(lens.max())))
+    elif fixed_len is None:
+        raise ValueError("give lens or fixed_len")
+    if out is None:
+        res = np.empty(n, np.float64), np.empty(n, np.int32), np.empty(n, np.uint8)
+    else:                                   # caller-owned result arrays (a streaming caller reuses them: fresh
+        ee, ns, ps = out                    # arrays cost a page fault per 4 KiB, ~3 ms per 100 MB of results)
+        if (ee.dtype, ns.dtype, ps.dtype) != (np.float64, np.int32, np.uint8) or \
+                not (len(ee) >= n and len(ns) >= n and len(ps) >= n) or \
+                not (ee.flags.c_contiguous and ns.flags.c_contiguous and ps.flags.c_contiguous):
+            raise ValueError("out must be contiguous (float64, int32, uint8) arrays of at least n entries")
+        res = ee[:n], ns[:n], ps[:n]
+    return q, n, stride, lens, res
+
+
 class Engine:
     """One context on one MI355X (one per process/rank; not thread-safe)."""
 
@@ -197,29 +226,7 @@ class Engine:
         """Filter a packed host matrix q (n x stride uint8).  Returns FilterResult."""
         kw.setdefault("batched_only", self.batched_only)
         params = kw.pop("params", None) or self.params(**kw)
-        q = np.ascontiguousarray(q, dtype=np.uint8)
-        if q.ndim != 2:
-            raise ValueError("q must be a 2-D (reads x stride) uint8 matrix")
-        n, stride = q.shape
-        if lens is not None:
-            lens = np.ascontiguousarray(lens, dtype=np.int32)
-            if lens.shape != (n,):
-                raise ValueError("lens must have one entry per read")
-            if n and (lens.min() < 0 or lens.max() > stride):
-                raise ValueError("a length does not fit the row stride")
-            if n and lens.max() > L.MAX_LEN:
-                raise ValueError("reads longer than %d bases are not supported (longest: %d)" % (L.MAX_LEN, int(lens.max())))
-        elif fixed_len is None:
-            raise ValueError("give lens or fixed_len")
-        if out is None:
-            ee, ns, ps = np.empty(n, np.float64), np.empty(n, np.int32), np.empty(n, np.uint8)
-        else:                                   # caller-owned result arrays (a streaming caller reuses them: fresh
-            ee, ns, ps = out                    # arrays cost a page fault per 4 KiB, ~3 ms per 100 MB of results)
-            if (ee.dtype, ns.dtype, ps.dtype) != (np.float64, np.int32, np.uint8) or \
-                    not (len(ee) >= n and len(ns) >= n and len(ps) >= n) or \
-                    not (ee.flags.c_contiguous and ns.flags.c_contiguous and ps.flags.c_contiguous):
-                raise ValueError("out must be contiguous (float64, int32, uint8) arrays of at least n entries")
-            ee, ns, ps = ee[:n], ns[:n], ps[:n]
+        q, n, stride, lens, (ee, ns, ps) = check_host_batch(q, lens, fixed_len, out, limit=L.MAX_LEN)
         counts = L.FilterCounts()
         L.check(self.lib.mpb_filter_host(self.ctx, q.ctypes.data, n, stride,
                                          lens.ctypes.data if lens is not None else None,
@@ -227,25 +234,17 @@ class Engine:
                                          ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, C.byref(counts)))
         return FilterResult(ee, ns, ps.view(bool), counts.n_pass, counts.n_overflow)   # pass bytes are 0 / 1
 
-    def filter_poisson(self, q, lens=None, fixed_len=None, **kw):
+    def filter_poisson(self, q, lens=None, fixed_len=None, out=None, **kw):
         """--error_calc poisson (moira/moira.py:1637-1679): lambda summed on the GPU in base order,
         scalar CDF tail on the host with the reference's libm calls.  Returns FilterResult."""
         params = kw.pop("params", None) or self.params(**kw)
-        q = np.ascontiguousarray(q, dtype=np.uint8)
-        n, stride = q.shape
-        if lens is not None:
-            lens = np.ascontiguousarray(lens, dtype=np.int32)
-        elif fixed_len is None:
-            raise ValueError("give lens or fixed_len")
-        ee = np.empty(n, np.float64)
-        ns = np.empty(n, np.int32)
-        ps = np.empty(n, np.uint8)
+        q, n, stride, lens, (ee, ns, ps) = check_host_batch(q, lens, fixed_len, out, limit=None)
         counts = L.FilterCounts()
         L.check(self.lib.mpb_filter_poisson_host(self.ctx, q.ctypes.data, n, stride,
                                                  lens.ctypes.data if lens is not None else None,
                                                  0 if lens is not None else int(fixed_len), C.byref(params),
                                                  ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, C.byref(counts)))
-        return FilterResult(ee, ns, ps.astype(bool), counts.n_pass, 0)
+        return FilterResult(ee, ns, ps.view(bool), counts.n_pass, 0)
 
     def calculate_errors_PB(self, contig, contig_quals, alpha):
         """Exact twin of bernoulli.calculate_errors_PB -> (expected_errors, Ns).

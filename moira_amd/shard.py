@@ -25,6 +25,93 @@ RCCL in production (Engine.filter).
 import numpy as np
 
 
+class MultiEngine:
+    """Several contexts -- normally one per GPU of the node -- driven from ONE host process ("one host
+    thread (or process) + one HIP stream per device").  `filter()` / `filter_poisson()` take the same arguments as
+    Engine's and return the same FilterResult: the batch is cut into contiguous shards in read order
+    (`shard_bounds`), one host thread per context runs the chunked H2D / kernels / D2H pipeline on its shard, and every
+    shard writes into its slice of the result arrays, so nothing is gathered afterwards and there is no collective.
+    For a host-fed caller this is what moira's `Pool(args.processors)` (moira/moira.py:398-399) was: all the GPUs
+    (and all their PCIe links) of a node behind one call -- without torchrun.  The split itself lives in the C ABI
+    (`mpb_filter_host_multi`), so a C caller gets it too.
+
+        with MultiEngine() as me:                 # every visible GPU;  MultiEngine([0, 1]) / MultiEngine([0, 0, 0])
+            r = me.filter(q, lens=lens, alpha=0.005)
+
+    Listing a device more than once gives it that many contexts (tests do that on a one-GPU box)."""
+
+    def __init__(self, devices=None):
+        import ctypes as C
+        from . import _lib as L
+        from .engine import Engine
+        if devices is None:
+            devices = list(range(L.load().mpb_device_count()))
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise L.NoDeviceError("no HIP device visible (this library has no CPU path)")
+        self.engines = []
+        try:
+            for d in devices:
+                self.engines.append(Engine(d))
+        except Exception:
+            self.close()
+            raise
+        self.devices = devices
+        self.lib = self.engines[0].lib
+        self._ctxs = (C.c_void_p * len(self.engines))(*[e.ctx for e in self.engines])
+        self.batched_only = False
+
+    def close(self):
+        for e in getattr(self, "engines", []):
+            e.close()
+        self.engines = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # what a host-side caller (cli.py, buckets.py) uses of an Engine, forwarded to the first context
+    def params(self, **kw):
+        return self.engines[0].params(**kw)
+
+    def pack(self, *a, **kw):
+        return self.engines[0].pack(*a, **kw)
+
+    def pack_batch_ascii(self, *a, **kw):
+        return self.engines[0].pack_batch_ascii(*a, **kw)
+
+    def calculate_errors_PB(self, contig, contig_quals, alpha):
+        return self.engines[0].calculate_errors_PB(contig, contig_quals, alpha)
+
+    def _run(self, poisson, q, lens, fixed_len, out, kw):
+        import ctypes as C
+        from . import _lib as L
+        from .engine import FilterResult, check_host_batch
+        if not poisson:
+            kw.setdefault("batched_only", self.batched_only)
+        params = kw.pop("params", None) or self.params(**kw)
+        q, n, stride, lens, (ee, ns, ps) = check_host_batch(q, lens, fixed_len, out, limit=None if poisson else L.MAX_LEN)
+        counts = L.FilterCounts()
+        L.check(self.lib.mpb_filter_host_multi(self._ctxs, len(self.engines), q.ctypes.data, n, stride,
+                                               lens.ctypes.data if lens is not None else None,
+                                               0 if lens is not None else int(fixed_len), C.byref(params),
+                                               ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, C.byref(counts),
+                                               1 if poisson else 0))
+        return FilterResult(ee, ns, ps.view(bool), counts.n_pass, counts.n_overflow)
+
+    def filter(self, q, lens=None, fixed_len=None, out=None, **kw):
+        return self._run(False, q, lens, fixed_len, out, kw)
+
+    def filter_poisson(self, q, lens=None, fixed_len=None, out=None, **kw):
+        return self._run(True, q, lens, fixed_len, out, kw)
+
+    def shards(self, n):
+        """[(lo, hi)] the contexts take of a batch of n reads."""
+        return [shard_bounds(n, len(self.engines), r) for r in range(len(self.engines))]
+
+
 def shard_bounds(n, world, rank):
     """Contiguous, balanced, order-preserving partition of range(n): rank -> [lo, hi)."""
     if world < 1 or not (0 <= rank < world):

@@ -103,3 +103,37 @@ def test_no_object_collectives_in_the_shard_module():
     code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
     assert "all_gather_object" not in code.split('"""', 2)[2] and "gather_object" not in code.split('"""', 2)[2]
     assert "all_gather_into_tensor" in code
+
+
+def test_single_process_split_is_the_same_split(oracle):
+    """mpb_filter_host_multi (one process, one host thread per GPU: MultiEngine) cuts a batch exactly as the
+    process-per-GPU path does -- the C ABI's mpb_shard_bounds against shard.py's shard_bounds -- and filtering the
+    shards one by one (the oracle standing in for the GPU) and laying the results side by side gives the unsplit
+    batch's results, in read order, for every world size incl. more contexts than reads."""
+    import ctypes as C
+    from moira_amd import _lib as L
+    from moira_amd.shard import filter_sharded, shard_bounds
+    lib = L.load()
+    lo, hi = C.c_int64(), C.c_int64()
+    for n in (0, 1, 2, 7, 64, 1000, 1001, 12345, 10_000_000, 1_000_000_007):
+        for world in (1, 2, 3, 5, 8, 13):
+            covered = 0
+            for r in range(world):
+                assert lib.mpb_shard_bounds(n, world, r, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard_bounds(n, world, r)
+                assert lo.value == covered
+                covered = hi.value
+            assert covered == n
+    assert lib.mpb_shard_bounds(10, 0, 0, C.byref(lo), C.byref(hi)) == L.E_INVALID
+    assert lib.mpb_shard_bounds(10, 2, 2, C.byref(lo), C.byref(hi)) == L.E_INVALID
+    q, lens = oracle.synth_fill(2003, 608, min_len=50, max_len=600, seed=5)
+    whole = oracle.filter_batch(q, lens=lens, threads=4)
+    for world in (2, 3, 8):
+        parts = []
+        for r in range(world):
+            a, b = shard_bounds(len(lens), world, r)
+            e, s, p, _ = oracle.filter_batch(q[a:b], lens=lens[a:b], threads=2)
+            parts.append((e, s, p))
+        assert np.array_equal(np.concatenate([x[0] for x in parts]), whole[0])
+        assert np.array_equal(np.concatenate([x[1] for x in parts]), whole[1])
+        assert np.array_equal(np.concatenate([x[2] for x in parts]), whole[2])
