@@ -547,6 +547,7 @@ def main():
         r_q.free()
         r_len.free()
         if world == 1:
+            extras["classified_at_source"] = classified_rate(eng, d_q, n, stride, L, params, d_ee, d_ns, d_pass)
             extras["long_reads_ragged_50_2000"] = long_ragged_rate(eng, params)
             extras["host_fed"] = host_fed_rate(eng, L, stride, args.seed)
             if n != CONFIG4_SHARD:
@@ -651,6 +652,62 @@ def main():
         b.free()
     eng.close()
     coll.close()
+
+
+def classified_rate(eng, d_q, n, stride, L, params, d_ee, d_ns, d_pass):
+    """Round 3 (SURVEY f-4): the batch arrives as raw FASTQ text resident in HBM (built here from the workload's packed
+    matrix by mpb_encode_ascii_device, not timed).  Two ways to results: decode, then the ordinary filter (the packed
+    matrix is written, then read by the prepass, then by the DP) -- or classified at source (the decode pass classifies,
+    the filter starts at the scan: written once, read once).  Same results bit for bit
+    (tests/test_gpu_classified.py).  A different input form than the metric's (text, 2 bytes per base): NOT the headline."""
+    out = {"note": "raw FASTQ text resident in HBM -> results: mpb_decode_ascii_device + mpb_filter_device against "
+                   "mpb_decode_classify_device + mpb_filter_device_classified (no k_prepass launch); NOT the headline", "reads": n}
+    bufs = []
+    try:
+        bufs = [eng.alloc(n * stride) for _ in range(3)]
+        d_seq, d_qual, d_out = bufs
+        eng.encode_ascii_device(d_q, n, stride, d_seq, d_qual)
+        eng.synchronize()
+
+        def two_pass():
+            eng.decode_ascii_device(d_seq, d_qual, n, stride, d_out, fixed_len=L)
+            eng.filter_device(d_out, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=params, want_counts=False)
+
+        def at_source():
+            eng.filter_ascii_device(d_seq, d_qual, n, stride, d_out, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass,
+                                    params=params, want_counts=False)
+        res = {}
+        for name, fn in (("decode_then_filter", two_pass), ("classified_at_source", at_source)):
+            for _ in range(2):
+                fn()
+            eng.synchronize()
+            k = 20
+            t = time.perf_counter()
+            for _ in range(k):
+                fn()
+            eng.synchronize()
+            dt = (time.perf_counter() - t) / k
+            eng.timing(True)
+            eng.timing_reset()
+            for _ in range(5):
+                fn()
+            kt = {kk: v[0] / max(v[1], 1) for kk, v in eng.kernel_times().items() if v[1]}
+            eng.timing(False)
+            res[name] = {"ms_per_step": dt * 1e3, "reads_per_s": n / dt, "kernels_ms": kt}
+        c = eng.filter_ascii_device(d_seq, d_qual, n, stride, d_out, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=params)
+        out.update(res)
+        out["pass"] = c.n_pass
+        out["saved_ms_per_step"] = res["decode_then_filter"]["ms_per_step"] - res["classified_at_source"]["ms_per_step"]
+        out["kernels_note"] = ("kernels_ms.prepass of classified_at_source is the fused decode + classify pass (the plain decode "
+                               "of decode_then_filter is not event-timed: it is the difference of the two step times minus the prepass)")
+    except Exception as e:                                  # an extra must never cost the headline line
+        out["error"] = repr(e)
+    for b in bufs:
+        try:
+            b.free()
+        except Exception:
+            pass
+    return out
 
 
 def long_ragged_rate(eng, params, n=1_000_000, stride=2048):

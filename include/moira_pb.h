@@ -186,6 +186,12 @@ int mpb_decode_ascii_device(mpb_ctx *ctx, const uint8_t *d_seq, const uint8_t *d
                             int64_t row_stride, const int32_t *d_len, int32_t fixed_len,
                             int32_t fastq_offset, uint8_t *d_q_out, int32_t *d_err);
 
+/* The inverse, for tests and benchmarks that need FASTQ-text matrices resident in HBM: packed byte 0 -> ('N', offset+2),
+ * 255 -> ('n', offset+2), Q -> (one of ACGT, chr(Q + offset)).  mpb_decode_ascii_device of its output gives the packed
+ * matrix back for every Q <= 255 - offset. */
+int mpb_encode_ascii_device(mpb_ctx *ctx, const uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fastq_offset,
+                            uint8_t *d_seq_out, uint8_t *d_qual_out);
+
 /* ---- the hot path --------------------------------------------------------- */
 /*
  * Filter a batch that is RESIDENT IN HBM.
@@ -223,6 +229,29 @@ int mpb_filter_device(mpb_ctx *ctx,
                       const mpb_filter_params *params,
                       double *d_ee, int32_t *d_ns, uint8_t *d_pass,
                       mpb_filter_counts *counts);
+
+/*
+ * Classified at source.  For a batch that is PRODUCED on the device -- raw FASTQ text (ref:
+ * moira/moira.py:1177) already in HBM -- the pass that decodes it also classifies it: mpb_decode_classify_device
+ * decodes d_seq / d_qual_ascii into the packed matrix d_q_out exactly as mpb_decode_ascii_device does AND, from the
+ * bytes it holds in registers anyway, sums the row-budget prediction, counts the ambiguous bases (d_ns) and fills the
+ * class histograms.  mpb_filter_device_classified, called next on the same context with the same batch, parameters and
+ * result arrays, starts at the histogram scan: the packed matrix is read once (by the DP), not twice, which removes
+ * the classification pass of mpb_filter_device (16 % of a 300-bp step).  Results are identical to
+ * mpb_decode_ascii_device + mpb_filter_device.  Any other filter call on the context in between invalidates the
+ * classification (mpb_filter_device_classified then fails with MPB_E_INVALID; nothing stale is ever consumed).
+ * Both are asynchronous on the context's stream (unless `counts` is given).
+ */
+int mpb_decode_classify_device(mpb_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual_ascii, int64_t n,
+                               int64_t row_stride, const int32_t *d_len, int32_t fixed_len, int32_t fastq_offset,
+                               const mpb_filter_params *params, uint8_t *d_q_out,
+                               double *d_ee, int32_t *d_ns, uint8_t *d_pass, int32_t *d_err);
+int mpb_filter_device_classified(mpb_ctx *ctx,
+                                 const uint8_t *d_q, int64_t n, int64_t row_stride,
+                                 const int32_t *d_len, int32_t fixed_len,
+                                 const mpb_filter_params *params,
+                                 double *d_ee, int32_t *d_ns, uint8_t *d_pass,
+                                 mpb_filter_counts *counts);
 
 /*
  * Same for a batch in HOST memory; synchronous (results are in the caller's arrays on return).

@@ -60,6 +60,11 @@ PROTOTYPES = {
     "mpb_pack_read_ascii": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, _VP, C.c_int32]),
     "mpb_pack_batch_ascii": (C.c_int, [C.c_char_p, C.c_char_p, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _VP, _VP]),
     "mpb_decode_ascii_device": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int32, C.c_int32, _VP, _VP]),
+    "mpb_encode_ascii_device": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int32, _VP, _VP]),
+    "mpb_decode_classify_device": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int32, C.c_int32,
+                                             C.POINTER(FilterParams), _VP, _VP, _VP, _VP, _VP]),
+    "mpb_filter_device_classified": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int32,
+                                               C.POINTER(FilterParams), _VP, _VP, _VP, C.POINTER(FilterCounts)]),
     "mpb_filter_device": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int32,
                                     C.POINTER(FilterParams), _VP, _VP, _VP, C.POINTER(FilterCounts)]),
     "mpb_filter_host": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int32,

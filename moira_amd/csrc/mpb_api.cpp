@@ -66,6 +66,12 @@ struct mpb_ctx {
     MpbWorkspace ws{};
     void *ws_block = nullptr;
     void *ws_small = nullptr;
+    // what the last classify-at-source call produced (consumed by mpb_filter_device_classified; any other call that
+    // rebuilds the workspace invalidates it)
+    struct Classified {
+        bool valid = false; const uint8_t *q = nullptr; int64_t n = 0, stride = 0; const int32_t *len = nullptr;
+        int32_t fixed_len = 0; mpb_filter_params params{}; double *ee = nullptr; int32_t *ns = nullptr; uint8_t *pass = nullptr;
+    } classified;
     void *ws_wide = nullptr;             // wide-read list + predicted rows, only for batches whose rows hold > 1023 bases
     int64_t ws_wide_cap = 0;
     // timing
@@ -554,13 +560,10 @@ static MpbDevParams make_dev_params(const mpb_filter_params *p, int32_t fixed_le
     return d;
 }
 
-int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride,
-                      const int32_t *d_len, int32_t fixed_len, const mpb_filter_params *params,
-                      double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
+// argument checks shared by mpb_filter_device and the classified-at-source pair; *max_len_out = longest read the batch can hold
+static int check_device_batch(const void *d_q, int64_t n, int64_t row_stride, const int32_t *d_len, int32_t fixed_len,
+                              const void *d_ee, const void *d_ns, const void *d_pass, int32_t *max_len_out)
 {
-    CTXCHK(c);
-    int rc = check_params(params);
-    if (rc) return rc;
     if (n < 0) return fail(MPB_E_INVALID, "n < 0");
     if (n > 0x7fffffffll - 4096) return fail(MPB_E_INVALID, "batch of %lld reads exceeds 2^31; split it", (long long)n);
     if (row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "row_stride must be a positive multiple of 16");
@@ -571,24 +574,34 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     if (max_len > MPB_MAX_LEN)
         return fail(MPB_E_INVALID, "reads longer than %d bases are not supported", MPB_MAX_LEN);
     if (n > 0 && (!d_q || !d_ee || !d_ns || !d_pass)) return fail(MPB_E_INVALID, "NULL device buffer");
-    if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
-    if (n == 0) return MPB_OK;
-    rc = ensure_workspace(c, n);
+    *max_len_out = max_len;
+    return MPB_OK;
+}
+
+// workspace (and, for batches whose rows can hold reads of more than 1023 bases, the wide-read list) of a batch of n reads
+static int prepare_batch(mpb_ctx *c, int64_t n, int32_t max_len)
+{
+    int rc = ensure_workspace(c, n);
     if (rc) return rc;
     // reads of more than 1023 bases may need more DP rows than one wave holds: such reads are listed by the prepass
     // and run by the wide kernel (k_wide).  Batches whose rows cannot hold such a read never see any of it.
-    const bool wide_possible = max_len + 1 > MPB_TILE_MAX_ROWS;
-    hipStream_t s = c->stream;
-    if (wide_possible) {
+    if (max_len + 1 > MPB_TILE_MAX_ROWS) {
         if ((rc = ensure_wide_workspace(c, n))) return rc;
-        HIPCHK(hipMemsetAsync(c->ws.wide_count, 0, sizeof(int32_t), s));
+        HIPCHK(hipMemsetAsync(c->ws.wide_count, 0, sizeof(int32_t), c->stream));
     }
-    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
-    { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
+    return MPB_OK;
+}
+
+// everything after the classification: scan -> scatter -> DP -> wide reads -> overflow pass (-> counts)
+static int filter_device_tail(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len,
+                              const MpbDevParams &prm, double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
+{
+    hipStream_t s = c->stream;
+    const int32_t max_len = prm.max_len;
     { Span t(c, MPB_K_SCAN);     mpb_launch_scan(n, d_len, c->ws, s); }
     { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, d_len, d_ns, prm, c->ws, s); }
     { Span t(c, MPB_K_DP);       mpb_launch_dp(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
-    if (wide_possible) { Span t(c, MPB_K_WIDE); mpb_launch_wide(d_q, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
+    if (max_len + 1 > MPB_TILE_MAX_ROWS) { Span t(c, MPB_K_WIDE); mpb_launch_wide(d_q, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     { Span t(c, MPB_K_OVERFLOW); mpb_launch_overflow(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     HIPCHK(hipGetLastError());
     if (counts) {
@@ -610,6 +623,92 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
         counts->n_fail = n - (int64_t)np;
         counts->n_overflow = novf;
     }
+    return MPB_OK;
+}
+
+int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride,
+                      const int32_t *d_len, int32_t fixed_len, const mpb_filter_params *params,
+                      double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
+{
+    CTXCHK(c);
+    int rc = check_params(params);
+    if (rc) return rc;
+    int32_t max_len = 0;
+    if ((rc = check_device_batch(d_q, n, row_stride, d_len, fixed_len, d_ee, d_ns, d_pass, &max_len))) return rc;
+    if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
+    if (n == 0) return MPB_OK;
+    c->classified.valid = false;                     // the workspace now describes THIS batch
+    if ((rc = prepare_batch(c, n, max_len))) return rc;
+    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
+    { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
+    return filter_device_tail(c, d_q, n, row_stride, d_len, prm, d_ee, d_ns, d_pass, counts);
+}
+
+// ---- classified at source (SURVEY f-4 + VERDICT r2 #6) -------------------------------------------------------------
+// A batch that is PRODUCED on the device -- raw FASTQ text decoded into the packed matrix -- is classified by the kernel
+// that produces it: the decode pass already holds every byte in registers, so it also sums the prediction statistics,
+// counts the ambiguous bases and fills the class histograms.  mpb_filter_device_classified then starts at the scan;
+// the packed matrix is read once (by the DP), not twice.
+
+int mpb_decode_classify_device(mpb_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, int64_t n, int64_t row_stride,
+                               const int32_t *d_len, int32_t fixed_len, int32_t fastq_offset,
+                               const mpb_filter_params *params, uint8_t *d_q_out, double *d_ee, int32_t *d_ns,
+                               uint8_t *d_pass, int32_t *d_err)
+{
+    CTXCHK(c);
+    int rc = check_params(params);
+    if (rc) return rc;
+    int32_t max_len = 0;
+    if ((rc = check_device_batch(d_q_out, n, row_stride, d_len, fixed_len, d_ee, d_ns, d_pass, &max_len))) return rc;
+    if ((((uintptr_t)d_seq | (uintptr_t)d_qual) & 15) != 0) return fail(MPB_E_INVALID, "matrices must be 16-byte aligned");
+    if (n > 0 && (!d_seq || !d_qual)) return fail(MPB_E_INVALID, "NULL device buffer");
+    c->classified.valid = false;
+    if (n == 0) return MPB_OK;
+    if ((rc = prepare_batch(c, n, max_len))) return rc;
+    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
+    { Span t(c, MPB_K_PREPASS);
+      mpb_launch_decode_classify(d_seq, d_qual, fastq_offset, d_q_out, d_err, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
+    HIPCHK(hipGetLastError());
+    c->classified = {true, d_q_out, n, row_stride, d_len, fixed_len, *params, d_ee, d_ns, d_pass};
+    return MPB_OK;
+}
+
+int mpb_filter_device_classified(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride,
+                                 const int32_t *d_len, int32_t fixed_len, const mpb_filter_params *params,
+                                 double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
+{
+    CTXCHK(c);
+    int rc = check_params(params);
+    if (rc) return rc;
+    int32_t max_len = 0;
+    if ((rc = check_device_batch(d_q, n, row_stride, d_len, fixed_len, d_ee, d_ns, d_pass, &max_len))) return rc;
+    if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
+    if (n == 0) return MPB_OK;
+    const auto &k = c->classified;
+    const bool same_params = k.valid && memcmp(&k.params.alpha, &params->alpha, sizeof(double)) == 0 &&
+                             memcmp(&k.params.uncert, &params->uncert, sizeof(double)) == 0 &&
+                             memcmp(&k.params.maxerrors, &params->maxerrors, sizeof(double)) == 0 &&
+                             k.params.ambig_mode == params->ambig_mode && k.params.flags == params->flags;
+    if (!same_params || k.q != d_q || k.n != n || k.stride != row_stride || k.len != d_len || k.fixed_len != fixed_len ||
+        k.ee != d_ee || k.ns != d_ns || k.pass != d_pass)
+        return fail(MPB_E_INVALID, "mpb_filter_device_classified: the last call on this context that classified a batch "
+                                   "(mpb_decode_classify_device) did not produce THIS batch with THESE parameters and result arrays");
+    c->classified.valid = false;                     // consumed: the DP passes overwrite parts of the workspace
+    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
+    return filter_device_tail(c, d_q, n, row_stride, d_len, prm, d_ee, d_ns, d_pass, counts);
+}
+
+int mpb_encode_ascii_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fastq_offset,
+                            uint8_t *d_seq_out, uint8_t *d_qual_out)
+{
+    CTXCHK(c);
+    if (n < 0 || row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "bad matrix shape");
+    if ((((uintptr_t)d_q | (uintptr_t)d_seq_out | (uintptr_t)d_qual_out) & 15) != 0) return fail(MPB_E_INVALID, "matrices must be 16-byte aligned");
+    if (n == 0) return MPB_OK;
+    if (!d_q || !d_seq_out || !d_qual_out) return fail(MPB_E_INVALID, "NULL device buffer");
+    if (n * (row_stride / 16) / 256 > 0x7fffffffll) return fail(MPB_E_INVALID, "too large for one launch; split it");
+    mpb_launch_encode(d_q, n, row_stride, fastq_offset, d_seq_out, d_qual_out, c->stream);
+    HIPCHK(hipGetLastError());
     return MPB_OK;
 }
 
@@ -679,6 +778,7 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
     if (rc) return rc;
     rc = ensure_workspace(c, n);
     if (rc) return rc;
+    c->classified.valid = false;                           // k_small rewrites the class bytes
     if (in_bytes + out_bytes > c->pin_cap) {
         if (c->pin_host) { HIPCHK(hipHostFree(c->pin_host)); c->pin_host = nullptr; c->pin_cap = 0; }
         const int64_t cap = 2 * (in_bytes + out_bytes);

@@ -111,6 +111,10 @@ struct MpbWorkspace {
 void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
                         double *ee_out, uint8_t *pass_out, hipStream_t s);
+void mpb_launch_decode_classify(const uint8_t *seq, const uint8_t *qual, int32_t offset, uint8_t *out, int32_t *err,
+                                int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
+                                const MpbWorkspace &ws, int32_t *ns_out, double *ee_out, uint8_t *pass_out, hipStream_t s);
+void mpb_launch_encode(const uint8_t *q, int64_t n, int64_t stride, int32_t offset, uint8_t *seq, uint8_t *qual, hipStream_t s);
 void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                       const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s);
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s);

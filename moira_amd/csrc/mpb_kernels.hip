@@ -146,9 +146,44 @@ __device__ __forceinline__ void pre_chunk(const float2 *tab, const uint4 x, f32x
         }
 }
 
+// 16 bases of raw FASTQ text -> packed qscores (ref: moira/moira.py:1177 `ord(x) - offset`, bernoullimodule.c:104-107
+// Q0 -> 1, :196 N / n); `pos0` = position of the first base in the read, bases at or past `li` become 0.
+// `bad` counts bytes that decode to Q < 0 or Q > 254 (written as Q1 / Q254).
+__device__ __forceinline__ uint4 decode16(const uint4 sq, const uint4 ql, int pos0, int li, int offset, int &bad)
+{
+    const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w}, qw[4] = {ql.x, ql.y, ql.z, ql.w};
+    uint32_t ow[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const uint32_t b = (sw[t >> 2] >> (8 * (t & 3))) & 0xffu;
+        int qv = (int)((qw[t >> 2] >> (8 * (t & 3))) & 0xffu) - offset;
+        uint32_t o = 0;
+        if (pos0 + t < li) {
+            if (qv < 0) { bad++; qv = 1; }
+            if (qv > 254) { bad++; qv = 254; }
+            if (qv == 0) qv = 1;
+            o = b == 'N' ? 0u : b == 'n' ? 255u : (uint32_t)qv;
+        }
+        ow[t >> 2] |= o << (8 * (t & 3));
+    }
+    return make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+
+// where a DECODE instance of the prepass takes its bytes from, and where it leaves the packed matrix
+struct PreDecode {
+    const uint8_t *seq;       // n x stride base letters
+    const uint8_t *qual;      // n x stride FASTQ quality characters
+    uint8_t *out;             // n x stride packed qscores (written here: the matrix the DP then reads)
+    int32_t offset;           // --fastq_offset
+    int32_t *err;             // device counter of undecodable bytes, may be nullptr
+};
+
 // RAGGED <=> len != nullptr; the fixed-length instance has one length bin and no len loads.
 // LONG <=> rows of more than 960 bytes: walked in panels (below); the short-row instances are one panel by construction.
-template <bool RAGGED, bool LONG>
+// DECODE <=> classified at source: the bytes come from raw FASTQ text resident in HBM (two matrices), are decoded on the
+// way in, written out as the packed matrix and classified in the same pass -- the packed matrix is never re-read to be
+// classified (mpb_decode_classify_device + mpb_filter_device_classified).
+template <bool RAGGED, bool LONG, bool DECODE>
 __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, int64_t n,
                                                  int64_t stride, const int32_t *__restrict__ len_arg,
                                                  MpbDevParams prm, uint8_t *__restrict__ cls,
@@ -159,7 +194,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                                                  int32_t *__restrict__ bad_len,
                                                  int32_t *__restrict__ wide_list,
                                                  int32_t *__restrict__ wide_rows,
-                                                 int32_t *__restrict__ wide_count)
+                                                 int32_t *__restrict__ wide_count, PreDecode dec)
 {
     __shared__ float2 s_tab[256];
     __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts (bits of an int: N | n << 16)}
@@ -196,7 +231,11 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         }
         ncol = __builtin_amdgcn_readfirstlane(ncol);
         nfull = __builtin_amdgcn_readfirstlane(nfull);
-        const uint8_t *src = q + (live ? i : (int64_t)0) * stride + cl * 16;
+        const int row_chunks = (int)(stride >> 4);
+        const int ncol_io = DECODE ? row_chunks : ncol;   // DECODE writes the whole row of the packed matrix (zeros past the read's end)
+        const int64_t row_off = (live ? i : (int64_t)0) * stride + cl * 16;
+        const uint8_t *src = q + row_off;
+        int badq = 0;
         float mu = 0.f, var = 0.f, k3 = 0.f;
         int ambi = 0;                              // 'N' count | 'n' count << 16
         // A panel = 3 * MPB_PRE_NB column quads = at most 240 bytes per lane, so that the ambiguity markers come off
@@ -212,8 +251,17 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             for (int b = 0; b < MPB_PRE_NB; b++) {
                 const int c0 = cb + 4 * b;
                 xs[b] = make_uint4(0, 0, 0, 0);
-                if (c0 < pend && li > (c0 + cl) * 16)
-                    xs[b] = *reinterpret_cast<const uint4 *>(src + c0 * 16);
+                if (!DECODE) {
+                    if (c0 < pend && li > (c0 + cl) * 16)
+                        xs[b] = *reinterpret_cast<const uint4 *>(src + c0 * 16);
+                } else if (c0 < pend && c0 + cl < row_chunks && live) {
+                    if (li > (c0 + cl) * 16) {
+                        const uint4 sq = *reinterpret_cast<const uint4 *>(dec.seq + row_off + c0 * 16);
+                        const uint4 ql = *reinterpret_cast<const uint4 *>(dec.qual + row_off + c0 * 16);
+                        xs[b] = decode16(sq, ql, (c0 + cl) * 16, li, dec.offset, badq);
+                    }
+                    *reinterpret_cast<uint4 *>(dec.out + row_off + c0 * 16) = xs[b];
+                }
             }
 #pragma unroll
             for (int b = 0; b < MPB_PRE_NB; b++) {
@@ -225,7 +273,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                     y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
                     y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
                 }
-                pre_chunk(s_tab, y, a01, s3);
+                if (!DECODE || c0 < ncol) pre_chunk(s_tab, y, a01, s3);    // (wave-uniform) columns past the longest read: written, not summed
             }
         }
         // second component = sum p(1-p) (<= 64) + 128 per 'N' + 65536 per 'n': peel the markers
@@ -238,8 +286,8 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         k3 += pvar - 2.0f * s3;                                           // sum p(1-p)(1-2p)
         ambi += (int)nzero + ((int)n255 << 16);
         };  // panel
-        if (LONG) { for (int pb = 0; pb < ncol; pb += 12 * MPB_PRE_NB) panel(pb, min(ncol, pb + 12 * MPB_PRE_NB)); }
-        else panel(0, ncol);
+        if (LONG) { for (int pb = 0; pb < ncol_io; pb += 12 * MPB_PRE_NB) panel(pb, min(ncol_io, pb + 12 * MPB_PRE_NB)); }
+        else panel(0, ncol_io);
         // the four lanes of a read, combined in a fixed order: (cl0 + cl1) + (cl2 + cl3)
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
@@ -249,6 +297,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             ambi += __shfl_xor(ambi, off);
         }
         const float amb = __int_as_float(ambi);
+        if (DECODE && badq && dec.err) atomicAdd(dec.err, badq);
         if (cl == 0) s_row[w][rb + r16] = make_float4(mu, var, k3, amb);
     }
     wave_lds_fence();          // s_row[w] is private to this wave: no block barrier
@@ -1207,25 +1256,31 @@ __global__ __launch_bounds__(256) void k_decode_ascii(const uint8_t *__restrict_
     const int li = len ? clamp_len(len[i], (int)stride) : fixed_len;
     const uint4 sq = *reinterpret_cast<const uint4 *>(seq + i * stride + (int64_t)c * 16);
     const uint4 ql = *reinterpret_cast<const uint4 *>(qual + i * stride + (int64_t)c * 16);
-    const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w}, qw[4] = {ql.x, ql.y, ql.z, ql.w};
-    uint32_t ow[4] = {0, 0, 0, 0};
     int bad = 0;
+    *reinterpret_cast<uint4 *>(out + i * stride + (int64_t)c * 16) = decode16(sq, ql, c * 16, li, offset, bad);
+    if (bad && err) atomicAdd(err, bad);
+}
+
+// the inverse (tests and bench: builds FASTQ-text matrices from a packed one; decode(encode(q)) == q for Q <= 93 at offset 33)
+__global__ __launch_bounds__(256) void k_encode_ascii(const uint8_t *__restrict__ q, int64_t n, int64_t stride,
+                                                      int32_t offset, uint8_t *__restrict__ seq, uint8_t *__restrict__ qual)
+{
+    const int64_t cpr = stride / 16;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n * cpr) return;
+    const uint4 x = *reinterpret_cast<const uint4 *>(q + g * 16);
+    const uint32_t xw[4] = {x.x, x.y, x.z, x.w};
+    uint32_t sw[4] = {0, 0, 0, 0}, qw[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 16; t++) {
-        const int pos = c * 16 + t;
-        const uint32_t b = (sw[t >> 2] >> (8 * (t & 3))) & 0xffu;
-        int qv = (int)((qw[t >> 2] >> (8 * (t & 3))) & 0xffu) - offset;
-        uint32_t o = 0;
-        if (pos < li) {
-            if (qv < 0) { bad++; qv = 1; }
-            if (qv > 254) { bad++; qv = 254; }
-            if (qv == 0) qv = 1;
-            o = b == 'N' ? 0u : b == 'n' ? 255u : (uint32_t)qv;
-        }
-        ow[t >> 2] |= o << (8 * (t & 3));
+        const uint32_t v = (xw[t >> 2] >> (8 * (t & 3))) & 0xffu;
+        const uint32_t base = v == 0 ? 'N' : v == 255 ? 'n' : (uint32_t)"ACGT"[t & 3];
+        const uint32_t qc = (v == 0 || v == 255) ? (uint32_t)(offset + 2) : min(255u, v + (uint32_t)offset);
+        sw[t >> 2] |= base << (8 * (t & 3));
+        qw[t >> 2] |= qc << (8 * (t & 3));
     }
-    *reinterpret_cast<uint4 *>(out + i * stride + (int64_t)c * 16) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-    if (bad && err) atomicAdd(err, bad);
+    *reinterpret_cast<uint4 *>(seq + g * 16) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+    *reinterpret_cast<uint4 *>(qual + g * 16) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1265,13 +1320,32 @@ void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
                         double *ee_out, uint8_t *pass_out, hipStream_t s)
 {
-#define MPB_PRE_LAUNCH(RG, LG)                                                                                          \
-    hipLaunchKernelGGL((k_prepass<RG, LG>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, ws.cls,       \
-                       ws.blockhist, ns_out, ee_out, pass_out, ws.bad_len, ws.wide_list, ws.wide_rows, ws.wide_count)
+#define MPB_PRE_LAUNCH(RG, LG, DG)                                                                                      \
+    hipLaunchKernelGGL((k_prepass<RG, LG, DG>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, ws.cls,   \
+                       ws.blockhist, ns_out, ee_out, pass_out, ws.bad_len, ws.wide_list, ws.wide_rows, ws.wide_count, dec)
+    const PreDecode dec = {nullptr, nullptr, nullptr, 0, nullptr};
     const bool long_rows = prm.max_len > 16 * 12 * MPB_PRE_NB;        // more than one panel of 60 chunk columns
-    if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true); else MPB_PRE_LAUNCH(true, false); }
-    else     { if (long_rows) MPB_PRE_LAUNCH(false, true); else MPB_PRE_LAUNCH(false, false); }
+    if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true, false); else MPB_PRE_LAUNCH(true, false, false); }
+    else     { if (long_rows) MPB_PRE_LAUNCH(false, true, false); else MPB_PRE_LAUNCH(false, false, false); }
+}
+
+// classified at source: decode raw FASTQ text into the packed matrix `out` and classify it in the same pass
+void mpb_launch_decode_classify(const uint8_t *seq, const uint8_t *qual, int32_t offset, uint8_t *out, int32_t *err,
+                                int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
+                                const MpbWorkspace &ws, int32_t *ns_out, double *ee_out, uint8_t *pass_out, hipStream_t s)
+{
+    const PreDecode dec = {seq, qual, out, offset, err};
+    const uint8_t *q = out;
+    const bool long_rows = stride > 16 * 12 * MPB_PRE_NB;             // a DECODE instance walks the whole row
+    if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true, true); else MPB_PRE_LAUNCH(true, false, true); }
+    else     { if (long_rows) MPB_PRE_LAUNCH(false, true, true); else MPB_PRE_LAUNCH(false, false, true); }
 #undef MPB_PRE_LAUNCH
+}
+
+void mpb_launch_encode(const uint8_t *q, int64_t n, int64_t stride, int32_t offset, uint8_t *seq, uint8_t *qual, hipStream_t s)
+{
+    const int64_t chunks = n * (stride / 16);
+    hipLaunchKernelGGL(k_encode_ascii, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, q, n, stride, offset, seq, qual);
 }
 
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s)

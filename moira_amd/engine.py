@@ -210,6 +210,26 @@ class Engine:
                                                  int(fastq_offset), ptr(d_out),
                                                  ptr(d_err) if d_err is not None else None))
 
+    def encode_ascii_device(self, d_q, n, stride, d_seq_out, d_qual_out, fastq_offset=33):
+        ptr = lambda b: (b.ptr if isinstance(b, DeviceBuffer) else b)
+        L.check(self.lib.mpb_encode_ascii_device(self.ctx, ptr(d_q), n, stride, int(fastq_offset), ptr(d_seq_out), ptr(d_qual_out)))
+
+    def filter_ascii_device(self, d_seq, d_qual, n, stride, d_q_out, d_len=None, fixed_len=0, fastq_offset=33,
+                            d_ee=None, d_ns=None, d_pass=None, d_err=None, params=None, want_counts=True):
+        """Raw FASTQ text resident in HBM -> results, classified at source: the decode pass classifies the reads, the
+        filter starts at the scan (mpb_decode_classify_device + mpb_filter_device_classified)."""
+        params = params or self.params()
+        ptr = lambda b: (b.ptr if isinstance(b, DeviceBuffer) else b)
+        opt = lambda b: (ptr(b) if b is not None else None)
+        L.check(self.lib.mpb_decode_classify_device(self.ctx, ptr(d_seq), ptr(d_qual), n, stride, opt(d_len), int(fixed_len),
+                                                    int(fastq_offset), C.byref(params), ptr(d_q_out), ptr(d_ee), ptr(d_ns),
+                                                    ptr(d_pass), opt(d_err)))
+        counts = L.FilterCounts()
+        L.check(self.lib.mpb_filter_device_classified(self.ctx, ptr(d_q_out), n, stride, opt(d_len), int(fixed_len),
+                                                      C.byref(params), ptr(d_ee), ptr(d_ns), ptr(d_pass),
+                                                      C.byref(counts) if want_counts else None))
+        return counts if want_counts else None
+
     # ---- the hot path -------------------------------------------------------------------------
     def filter_device(self, d_q, n, stride, d_len=None, fixed_len=0, d_ee=None, d_ns=None, d_pass=None,
                       params=None, want_counts=True):
