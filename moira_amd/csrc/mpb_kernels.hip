@@ -146,27 +146,70 @@ __device__ __forceinline__ void pre_chunk(const float2 *tab, const uint4 x, f32x
         }
 }
 
-// 16 bases of raw FASTQ text -> packed qscores (ref: moira/moira.py:1177 `ord(x) - offset`, bernoullimodule.c:104-107
-// Q0 -> 1, :196 N / n); `pos0` = position of the first base in the read, bases at or past `li` become 0.
-// `bad` counts bytes that decode to Q < 0 or Q > 254 (written as Q1 / Q254).
-__device__ __forceinline__ uint4 decode16(const uint4 sq, const uint4 ql, int pos0, int li, int offset, int &bad)
+// Raw FASTQ text -> packed qscores (ref: moira/moira.py:1177 `ord(x) - offset`, bernoullimodule.c:104-107 Q0 -> 1,
+// :196 N / n).  `bad` counts bytes that decode to Q < 0 or Q > 254 (written as Q1 / Q254).
+// Four bases at a time, byte by byte: the plain statement of the rules (and the path for the rare dword that holds
+// a quality character below the offset).  `nv` = bases of this dword inside the read (bytes past it become 0).
+__device__ __forceinline__ uint32_t decode4_bytes(uint32_t sw, uint32_t qw, int nv, int offset, int &bad)
 {
-    const uint32_t sw[4] = {sq.x, sq.y, sq.z, sq.w}, qw[4] = {ql.x, ql.y, ql.z, ql.w};
-    uint32_t ow[4] = {0, 0, 0, 0};
+    uint32_t ow = 0;
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const uint32_t b = (sw[t >> 2] >> (8 * (t & 3))) & 0xffu;
-        int qv = (int)((qw[t >> 2] >> (8 * (t & 3))) & 0xffu) - offset;
+    for (int t = 0; t < 4; t++) {
+        const uint32_t b = (sw >> (8 * t)) & 0xffu;
+        int qv = (int)((qw >> (8 * t)) & 0xffu) - offset;
         uint32_t o = 0;
-        if (pos0 + t < li) {
+        if (t < nv) {
             if (qv < 0) { bad++; qv = 1; }
             if (qv > 254) { bad++; qv = 254; }
             if (qv == 0) qv = 1;
             o = b == 'N' ? 0u : b == 'n' ? 255u : (uint32_t)qv;
         }
-        ow[t >> 2] |= o << (8 * (t & 3));
+        ow |= o << (8 * t);
     }
-    return make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    return ow;
+}
+
+// 0x80 in every byte of x that is zero
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x)
+{
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+}
+
+// The same four bases with word-wide arithmetic (the decode is VALU-bound byte by byte: ~19 instructions per base
+// against ~8 here).  Needs offset >= 1 (then Q <= 254 always); a dword with a character below the offset inside the
+// read takes the byte path, which counts it.
+__device__ __forceinline__ uint32_t decode4(uint32_t sw, uint32_t qw, int nv, int offset, uint32_t off4, int &bad)
+{
+    const uint32_t H = 0x80808080u;
+    const uint32_t d = ((qw | H) - (off4 & ~H)) ^ ((qw ^ ~off4) & H);          // per-byte qw - offset (mod 256), no borrow across bytes
+    uint32_t lt = ((~qw & off4) | (~(qw ^ off4) & d)) & H;                      // 0x80 where the byte of qw is below the offset
+    uint32_t keep = 0xffffffffu;
+    if (nv < 4) keep = nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u);
+    lt &= keep;
+    if (lt) return decode4_bytes(sw, qw, nv, offset, bad);                      // rare
+    uint32_t q = d + (zero_bytes(d) >> 7);                                      // Q0 -> 1
+    // 'N' (0x4E) -> 0, 'n' (0x6E) -> 255: the two letters differ in bit 5 only
+    const uint32_t amb = zero_bytes((sw | 0x20202020u) ^ 0x6e6e6e6eu);
+    const uint32_t amb_full = (amb << 1) - (amb >> 7);                          // 0xff in flagged bytes
+    const uint32_t lower_full = ((sw >> 5) & 0x01010101u) * 255u;               // 0xff where bit 5 is set ('n' among the flagged)
+    q = (amb_full & lower_full) | (~amb_full & q);
+    return q & keep;
+}
+
+// 16 bases; `pos0` = position of the first base in the read, bases at or past `li` become 0
+__device__ __forceinline__ uint4 decode16(const uint4 sq, const uint4 ql, int pos0, int li, int offset, int &bad)
+{
+    const int nv = li - pos0;
+    if (offset < 1)                                                             // wave-uniform; Q = 255 is possible: byte path
+        return make_uint4(decode4_bytes(sq.x, ql.x, nv, offset, bad), decode4_bytes(sq.y, ql.y, nv - 4, offset, bad),
+                          decode4_bytes(sq.z, ql.z, nv - 8, offset, bad), decode4_bytes(sq.w, ql.w, nv - 12, offset, bad));
+    const uint32_t off4 = (uint32_t)(offset & 0xff) * 0x01010101u;
+    if (offset > 255) {                                                         // every character is below the offset
+        return make_uint4(decode4_bytes(sq.x, ql.x, nv, offset, bad), decode4_bytes(sq.y, ql.y, nv - 4, offset, bad),
+                          decode4_bytes(sq.z, ql.z, nv - 8, offset, bad), decode4_bytes(sq.w, ql.w, nv - 12, offset, bad));
+    }
+    return make_uint4(decode4(sq.x, ql.x, nv, offset, off4, bad), decode4(sq.y, ql.y, nv - 4, offset, off4, bad),
+                      decode4(sq.z, ql.z, nv - 8, offset, off4, bad), decode4(sq.w, ql.w, nv - 12, offset, off4, bad));
 }
 
 // where a DECODE instance of the prepass takes its bytes from, and where it leaves the packed matrix
@@ -247,20 +290,35 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         // looked at (a row of 300 bases is one such batch), so a wave keeps 5 KiB in flight
         for (int cb = pb; cb < pend; cb += 4 * MPB_PRE_NB) {
             uint4 xs[MPB_PRE_NB];
+            if (!DECODE) {
 #pragma unroll
-            for (int b = 0; b < MPB_PRE_NB; b++) {
-                const int c0 = cb + 4 * b;
-                xs[b] = make_uint4(0, 0, 0, 0);
-                if (!DECODE) {
+                for (int b = 0; b < MPB_PRE_NB; b++) {
+                    const int c0 = cb + 4 * b;
+                    xs[b] = make_uint4(0, 0, 0, 0);
                     if (c0 < pend && li > (c0 + cl) * 16)
                         xs[b] = *reinterpret_cast<const uint4 *>(src + c0 * 16);
-                } else if (c0 < pend && c0 + cl < row_chunks && live) {
-                    if (li > (c0 + cl) * 16) {
-                        const uint4 sq = *reinterpret_cast<const uint4 *>(dec.seq + row_off + c0 * 16);
-                        const uint4 ql = *reinterpret_cast<const uint4 *>(dec.qual + row_off + c0 * 16);
-                        xs[b] = decode16(sq, ql, (c0 + cl) * 16, li, dec.offset, badq);
+                }
+            } else {
+                // text in: all loads of the batch (two per chunk) are issued before the first chunk is decoded
+                uint4 sqs[MPB_PRE_NB], qls[MPB_PRE_NB];
+#pragma unroll
+                for (int b = 0; b < MPB_PRE_NB; b++) {
+                    const int c0 = cb + 4 * b;
+                    sqs[b] = qls[b] = make_uint4(0, 0, 0, 0);
+                    if (c0 < pend && li > (c0 + cl) * 16) {
+                        sqs[b] = *reinterpret_cast<const uint4 *>(dec.seq + row_off + c0 * 16);
+                        qls[b] = *reinterpret_cast<const uint4 *>(dec.qual + row_off + c0 * 16);
                     }
-                    *reinterpret_cast<uint4 *>(dec.out + row_off + c0 * 16) = xs[b];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < MPB_PRE_NB; b++) {
+                    const int c0 = cb + 4 * b;
+                    xs[b] = make_uint4(0, 0, 0, 0);
+                    if (c0 < pend && c0 + cl < row_chunks && live) {
+                        if (li > (c0 + cl) * 16) xs[b] = decode16(sqs[b], qls[b], (c0 + cl) * 16, li, dec.offset, badq);
+                        *reinterpret_cast<uint4 *>(dec.out + row_off + c0 * 16) = xs[b];
+                    }
                 }
             }
 #pragma unroll

@@ -150,3 +150,21 @@ def test_contig_library_exports_every_declared_symbol():
                          "mct_reverse_complement"}
     for s in syms:
         assert isinstance(getattr(lib, s), ctypes._CFuncPtr)
+
+
+def test_word_wide_fastq_decode_equals_the_byte_rules(tmp_path):
+    """The on-device FASTQ decode works on four bases per instruction (decode4 in mpb_kernels.hip); its byte-by-byte
+    twin (decode4_bytes) states the reference's rules (moira/moira.py:1177, bernoullimodule.c:104-107,196).  Both are
+    plain integer code, so they are cut out of the kernel source and compared on the host: 8 M random dwords."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = open(os.path.join(ROOT, "moira_amd", "csrc", "mpb_kernels.hip")).read()
+    a = src.index("__device__ __forceinline__ uint32_t decode4_bytes(")
+    b = src.index("// 16 bases; `pos0` = position of the first base in the read")
+    (tmp_path / "swar_funcs.h").write_text(src[a:b])
+    exe = str(tmp_path / "check")
+    subprocess.check_call(["g++", "-O2", "-I", str(tmp_path), os.path.join(ROOT, "tests", "helpers", "swar_decode_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-2000:]
