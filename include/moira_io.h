@@ -63,6 +63,15 @@ const char *mio_last_error(void);
 int64_t mio_fastq_index(const char *buf, int64_t len, int32_t final, int64_t max_records,
                         int64_t *idx, int64_t *consumed, int32_t *bad_kind);
 
+/* The same index built by `threads` threads (newline counts per byte slice -> line numbers -> record starts ->
+ * one sequential indexer per range): identical rows, consumed, bad_kind and return value. */
+int64_t mio_fastq_index_mt(const char *buf, int64_t len, int32_t final, int64_t max_records,
+                           int64_t *idx, int64_t *consumed, int32_t *bad_kind, int32_t threads);
+
+/* Read [offset, offset + len) of a regular file into dst with `threads` concurrent preads.  Returns the bytes read
+ * (short only at the end of the file) or a negative MIO_E_*. */
+int64_t mio_pread_mt(int32_t fd, int64_t offset, char *dst, int64_t len, int32_t threads);
+
 /*
  * Pack records sel[0..nsel) (rows of idx; sel == NULL: records 0..nsel-1) into an nsel x row_stride
  * uint8 matrix: Q = byte - fastq_offset, Q0 -> 1, 'N' -> 0, 'n' -> 255 (or an ordinary base when

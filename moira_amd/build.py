@@ -95,7 +95,7 @@ def build_contig(force=False, verbose=False):
 IO_LIB = os.path.join(HERE, "libmoira_io.so")
 IO_SRC = os.path.join(CSRC, "fastio.cpp")
 IO_DEPS = [IO_SRC, os.path.join(ROOT, "include", "moira_io.h")]
-IO_FLAGS = ["-O3", "-fPIC", "-shared", "-std=c++17", "-Wall"]
+IO_FLAGS = ["-O3", "-fPIC", "-shared", "-std=c++17", "-pthread", "-Wall"]
 
 
 def io_stale():

@@ -681,6 +681,13 @@ def _record_error(which, e, args):
     return LengthMismatchError(e.header, args.reverse_fastq)
 
 
+def _text_threads(args):
+    """Threads the text side of a run may use for ONE call (reading, indexing, packing or formatting a chunk):
+    --processors, at most the CPUs this process is granted."""
+    from .contig import usable_cpus
+    return max(1, min(int(args.processors or 1), usable_cpus(), 64))
+
+
 def _fast_chunks(args):
     """(buf, idx, aux) per chunk: reads as they are in the file, or contigs built from the two files."""
     from . import fastio as F
@@ -690,7 +697,7 @@ def _fast_chunks(args):
     if not args.paired:
         fh = open_input_binary(args.forward_fastq)
         try:
-            for buf, idx in F.FastqChunks(fh, CHUNK_READS):
+            for buf, idx in F.FastqChunks(fh, CHUNK_READS, threads=_text_threads(args)):
                 yield buf, idx, None
         except F.RecordError as e:
             raise _record_error(0, e, args)
@@ -700,7 +707,7 @@ def _fast_chunks(args):
     from . import contig as CT
     ffh, rfh = open_input_binary(args.forward_fastq), open_input_binary(args.reverse_fastq)
     try:
-        for fbuf, fidx, rbuf, ridx in F.PairedFastqChunks(ffh, rfh, PAIR_CHUNK_READS):
+        for fbuf, fidx, rbuf, ridx in F.PairedFastqChunks(ffh, rfh, PAIR_CHUNK_READS, threads=_text_threads(args)):
             # forward_header != reverse_header (moira.py:1197-1198); ':' -> '_' on both sides cannot change equality
             bad = F.first_header_mismatch(fbuf, fidx, rbuf, ridx)
             n = len(fidx) if bad < 0 else bad
@@ -880,12 +887,23 @@ def _run_fast_fastq(args, backend, o, say, t0):
     processed = 0
     disc_err = disc_len = disc_ov = 0.0
     groups = F.Collapse() if args.collapse else None
-    threads = max(1, min(8, int(args.processors or 1)))  # --processors (at most 8 here): packing / formatting calls in flight
+    threads = _text_threads(args)                        # --processors: packing / formatting calls in flight
     pool = None
     if threads > 1:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(threads)
     emit = _InOrder()
+    # one writer lane per output file: the files of a chunk are formatted (by the pool) and written side by side, each
+    # file's chunks in order.  Buffered writes to ONE file are serialised by the kernel anyway; different files are not.
+    lanes = {}
+
+    def lane(f):
+        if threads <= 1:
+            return emit
+        k = id(f)
+        if k not in lanes:
+            lanes[k] = _InOrder()
+        return lanes[k]
     ok = False
     try:
         for buf, idx, aux in _prefetched(_fast_chunks(args)):
@@ -913,28 +931,32 @@ def _run_fast_fastq(args, backend, o, say, t0):
                 disc_ov += int((label == 3).sum())
                 disc_err += int(((label == 1) | (label == 2)).sum())
 
-                def write_chunk(buf=buf, idx=idx, aux=aux, ee=ee, label=label, first=processed, n=n):
-                    hdr = dict(relabel=args.relabel or None)
-                    if args.paired:
+                hdr = dict(relabel=args.relabel or None)
+                if args.paired:
+                    def write_report(buf=buf, idx=idx, aux=aux, ee=ee, first=processed, n=n, hdr=hdr):
                         everything = np.arange(n)
                         o.report.write(F.format_report(buf, idx, everything, aux, relabel_index=first + everything,
                                                        ee=ee if usearch else None, **hdr))
-                    good, bad = np.nonzero(label < 0)[0], np.nonzero(label >= 0)[0]
-                    for sel, main_f, qual_f, lab in ((good, o.contig, o.qual, None), (bad, o.bad_contig, o.bad_qual, label)):
-                        if not len(sel):
-                            continue
-                        kw = dict(fastq_offset=in_off, out_offset=args.fastq_offset, clamp_q0=not only, max_len=T,
-                                  relabel_index=first + sel,
-                                  ee=ee[sel] if usearch else None, labels=labels if lab is not None else None,
-                                  label_id=lab[sel] if lab is not None else None, **hdr)
-                        for kind, f in (((F.FMT_FASTQ, main_f),) if fq else ((F.FMT_FASTA, main_f), (F.FMT_QUAL, qual_f))):
-                            for piece in F.format_parallel(pool, threads, buf, idx, sel, kind, **kw):
+                    lane(o.report).submit(write_report)
+                good, bad = np.nonzero(label < 0)[0], np.nonzero(label >= 0)[0]
+                for sel, main_f, qual_f, lab in ((good, o.contig, o.qual, None), (bad, o.bad_contig, o.bad_qual, label)):
+                    if not len(sel):
+                        continue
+                    kw = dict(fastq_offset=in_off, out_offset=args.fastq_offset, clamp_q0=not only, max_len=T,
+                              relabel_index=processed + sel,
+                              ee=ee[sel] if usearch else None, labels=labels if lab is not None else None,
+                              label_id=lab[sel] if lab is not None else None, **hdr)
+                    for kind, f in (((F.FMT_FASTQ, main_f),) if fq else ((F.FMT_FASTA, main_f), (F.FMT_QUAL, qual_f))):
+                        def write_file(buf=buf, idx=idx, sel=sel, kind=kind, f=f, kw=kw):
+                            for piece in F.format_parallel(pool, threads, buf, idx, sel, kind, scratch="fmt%x_" % id(f), **kw):
                                 f.write(piece)
-                emit.submit(write_chunk)
+                        lane(f).submit(write_file)
             processed += n
             if not args.silent:
                 say("%d sequences processed in %.1f seconds." % (processed, time.time() - t0))
         emit.close()
+        for ln in lanes.values():
+            ln.close()
         ok = True
         if args.collapse:
             # the groups by decreasing abundance (moira.py:490-493), then write_results' decisions per group
@@ -965,6 +987,8 @@ def _run_fast_fastq(args, backend, o, say, t0):
     finally:
         if not ok:
             emit.close(raise_errors=False)         # an exception is already on its way
+            for ln in lanes.values():
+                ln.close(raise_errors=False)
         if pool is not None:
             pool.shutdown(wait=True)
         if groups is not None:

@@ -12,7 +12,10 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 namespace {
 
@@ -266,6 +269,143 @@ int64_t mio_fastq_index(const char *buf, int64_t len, int32_t final, int64_t max
         *consumed = pos;
     }
     return n;
+}
+
+// ---- the same index, built by several threads ------------------------------------------------------------------
+// "Every 4 lines are one record whatever they contain" (moira/moira.py:1166-1174) makes a record boundary a LINE COUNT
+// property, not a content property ('@' may start a quality line), so the buffer cannot be cut by looking for '@'.
+// Pass 1 counts the newlines of T byte slices in parallel; the running total gives the line number at every slice
+// start, hence each slice's first record start (the first line start whose number is a multiple of 4) and the row of
+// the index it belongs to.  Pass 2 runs the sequential indexer on [record start of slice t, record start of slice
+// t + 1), writing its rows where they belong.  Results -- rows, consumed, bad_kind, MIO_E_UNSUPPORTED -- are those of
+// mio_fastq_index on the whole buffer (tests/test_fastio.py compares them on quirky inputs).
+int64_t mio_fastq_index_mt(const char *buf, int64_t len, int32_t final, int64_t max_records,
+                           int64_t *idx, int64_t *consumed, int32_t *bad_kind, int32_t threads)
+{
+    if (!buf || len < 0 || max_records < 0 || !idx || !consumed || !bad_kind)
+        return fail(MIO_E_INVALID, "mio_fastq_index_mt: bad arguments");
+    int T = threads;
+    if (T > 64) T = 64;
+    if (T <= 1 || len < (int64_t)T * (64 << 10)) return mio_fastq_index(buf, len, final, max_records, idx, consumed, bad_kind);
+    struct Part {
+        int64_t a = 0, lines = 0;          // slice start, newlines in the slice
+        int64_t rec = 0, row0 = 0;         // first record start at or after `a`, and its row of the index
+        int64_t n = 0, used = 0; int32_t bad = MIO_REC_OK; char err[sizeof(g_err)] = "";
+    };
+    std::vector<Part> P((size_t)T + 1);
+    for (int t = 0; t <= T; t++) P[(size_t)t].a = len / T * t + (t == T ? len % T : 0);
+    auto run = [&](auto &&fn) {            // fn(t) for t = 0..T-1, one thread each (the caller's thread takes t = 0)
+        std::vector<std::thread> th;
+        int started = 1;
+        try {
+            th.reserve((size_t)T);
+            for (int t = 1; t < T; t++) { th.emplace_back(fn, t); started = t + 1; }
+        } catch (...) {}                   // no thread to be had: the rest runs here
+        fn(0);
+        for (int t = started; t < T; t++) fn(t);
+        for (auto &x : th) x.join();
+    };
+    run([&](int t) {
+        const char *p = buf + P[(size_t)t].a, *e = buf + P[(size_t)t + 1].a;
+        int64_t c = 0;
+        for (; p < e; p++) c += *p == '\n';                          // vectorised by the compiler
+        P[(size_t)t].lines = c;
+    });
+    int64_t before = 0;                                                // newlines before the slice
+    for (int t = 0; t <= T; t++) {
+        Part &S = P[(size_t)t];
+        if (t == T) { S.rec = len; S.row0 = (before + 3) / 4; break; }
+        int64_t pos = S.a, line = before;                              // `line` = number of the line that holds byte `pos`
+        bool at_start = pos == 0 || buf[pos - 1] == '\n';
+        for (;;) {
+            if (at_start && line % 4 == 0) break;
+            const char *nl = pos < len ? (const char *)memchr(buf + pos, '\n', (size_t)(len - pos)) : nullptr;
+            if (!nl) { pos = len; break; }                             // no further line start in the buffer
+            pos = nl - buf + 1;
+            line++;
+            at_start = true;
+        }
+        S.rec = pos;
+        S.row0 = pos >= len ? -1 : line / 4;
+        before += S.lines;
+    }
+    for (int t = T - 1; t >= 0; t--)                                    // slices with no record start take the next one's
+        if (P[(size_t)t].row0 < 0) { P[(size_t)t].row0 = P[(size_t)t + 1].row0; P[(size_t)t].rec = P[(size_t)t + 1].rec; }
+    run([&](int t) {
+        Part &S = P[(size_t)t];
+        const Part &N = P[(size_t)t + 1];
+        const bool last = N.rec >= len;                                // nothing starts after this range: it runs to the end
+        int64_t cap = max_records - S.row0;
+        if (!last && N.row0 - S.row0 < cap) cap = N.row0 - S.row0;
+        if (cap <= 0 || S.rec >= len || (!last && N.rec <= S.rec)) return;
+        const int64_t end = last ? len : N.rec;
+        int64_t used = 0;
+        int32_t bad = MIO_REC_OK;
+        int64_t *rows = idx + S.row0 * MIO_IDX_COLS;
+        const int64_t n = mio_fastq_index(buf + S.rec, end - S.rec, last ? final : 0, cap, rows, &used, &bad);
+        S.n = n; S.used = used; S.bad = bad;
+        if (n < 0) { snprintf(S.err, sizeof(S.err), "%s", g_err); return; }
+        const int64_t fix = n + (bad != MIO_REC_OK ? 1 : 0);           // the row after the last holds the offending record
+        for (int64_t k = 0; k < fix; k++) {
+            rows[k * MIO_IDX_COLS + MIO_HDR_OFF] += S.rec;
+            rows[k * MIO_IDX_COLS + MIO_SEQ_OFF] += S.rec;
+            rows[k * MIO_IDX_COLS + MIO_QUAL_OFF] += S.rec;
+        }
+    });
+    *consumed = 0;
+    *bad_kind = MIO_REC_OK;
+    int64_t n = 0;
+    for (int t = 0; t < T; t++) {
+        const Part &S = P[(size_t)t], &N = P[(size_t)t + 1];
+        if (t > 0 && S.rec == P[(size_t)t - 1].rec) continue;           // shared a range with the slice before
+        if (S.rec >= len || S.row0 >= max_records) break;
+        if (S.n < 0) return fail((int)S.n, "%s", S.err);
+        n = S.row0 + S.n;
+        *consumed = S.rec + S.used;
+        if (S.bad != MIO_REC_OK) { *bad_kind = S.bad; break; }
+        const bool last = N.rec >= len;
+        if (!last && S.n < N.row0 - S.row0) break;                      // stopped at max_records
+    }
+    return n;
+}
+
+// Fill dst[0, len) from a regular file at `offset`, the range cut over `threads` preads (page-cache copies and the
+// first-touch faults of a fresh destination scale with the threads).  Returns the bytes read (short only at the end
+// of the file), or -1.
+int64_t mio_pread_mt(int32_t fd, int64_t offset, char *dst, int64_t len, int32_t threads)
+{
+    if (fd < 0 || offset < 0 || len < 0 || (len > 0 && !dst)) return fail(MIO_E_INVALID, "mio_pread_mt: bad arguments");
+    int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    if (len < (int64_t)T * (1 << 20)) T = 1;
+    std::vector<int64_t> got((size_t)T, 0);
+    auto work = [&](int t) {
+        const int64_t a = len / T * t, b = t == T - 1 ? len : len / T * (t + 1);
+        int64_t done = 0;
+        while (a + done < b) {
+            const ssize_t r = pread(fd, dst + a + done, (size_t)(b - a - done), (off_t)(offset + a + done));
+            if (r < 0) { got[(size_t)t] = -1; return; }
+            if (r == 0) break;
+            done += r;
+        }
+        got[(size_t)t] = done;
+    };
+    std::vector<std::thread> th;
+    int started = 1;
+    try {
+        th.reserve((size_t)T);
+        for (int t = 1; t < T; t++) { th.emplace_back(work, t); started = t + 1; }
+    } catch (...) {}
+    work(0);
+    for (int t = started; t < T; t++) work(t);
+    for (auto &x : th) x.join();
+    int64_t total = 0;
+    for (int t = 0; t < T; t++) {
+        if (got[(size_t)t] < 0) return fail(MIO_E_INVALID, "pread failed");
+        total += got[(size_t)t];
+        const int64_t a = len / T * t, b = t == T - 1 ? len : len / T * (t + 1);
+        if (got[(size_t)t] < b - a) break;                              // end of file inside this slice
+    }
+    return total;
 }
 
 int32_t mio_pack(const char *buf, const int64_t *idx, const int64_t *sel, int64_t nsel,

@@ -35,6 +35,8 @@ PROTOTYPES = {
     "mio_version": (C.c_char_p, []),
     "mio_last_error": (C.c_char_p, []),
     "mio_fastq_index": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mio_fastq_index_mt": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "mio_pread_mt": (C.c_int64, [C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int32]),
     "mio_pack": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mio_py2_hash": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
@@ -98,14 +100,20 @@ def header_of(buf, row):
     return bytes(buf[row[HDR_OFF]:row[HDR_OFF] + row[HDR_LEN]]).decode("ascii").replace(":", "_")
 
 
-def index(buf, final, max_records):
-    """-> (idx int64[n, 6], consumed bytes, bad) ; bad is None or a RecordError for the record after the n-th."""
+def index(buf, final, max_records, threads=1):
+    """-> (idx int64[n, 6], consumed bytes, bad) ; bad is None or a RecordError for the record after the n-th.
+    threads > 1: the same index built by that many threads (mio_fastq_index_mt)."""
     L = load()
-    idx = np.empty((max(max_records, 1) + 0, IDX_COLS), np.int64)
+    # one row more than asked for: the row after the last describes a record that failed the reference's checks
+    idx = np.empty((max(max_records, 1) + 1, IDX_COLS), np.int64)
     consumed = C.c_int64(0)
     bad = C.c_int32(0)
-    n = L.mio_fastq_index(_ptr(buf), len(buf), 1 if final else 0, max_records, idx.ctypes.data, C.addressof(consumed),
-                          C.addressof(bad))
+    if threads > 1:
+        n = L.mio_fastq_index_mt(_ptr(buf), len(buf), 1 if final else 0, max_records, idx.ctypes.data,
+                                 C.addressof(consumed), C.addressof(bad), int(threads))
+    else:
+        n = L.mio_fastq_index(_ptr(buf), len(buf), 1 if final else 0, max_records, idx.ctypes.data, C.addressof(consumed),
+                              C.addressof(bad))
     if n == E_UNSUPPORTED:
         raise Unsupported(_err())
     if n < 0:
@@ -172,14 +180,15 @@ def first_header_mismatch(fbuf, fidx, rbuf, ridx):
     return load().mio_first_header_mismatch(_ptr(fbuf), fidx.ctypes.data, _ptr(rbuf), ridx.ctypes.data, len(fidx))
 
 
-def format_parallel(pool, threads, buf, idx, sel, kind, relabel_index=None, ee=None, label_id=None, **kw):
-    """format_records() with the selection split over `threads` calls; returns the pieces in order."""
+def format_parallel(pool, threads, buf, idx, sel, kind, relabel_index=None, ee=None, label_id=None, scratch="format", **kw):
+    """format_records() with the selection split over `threads` calls; returns the pieces in order.  `scratch` names
+    the work buffers: callers that format side by side (one per output file) pass different names."""
     n = len(sel)
     if pool is None or threads <= 1 or n < PARALLEL_MIN:
-        return [format_records(buf, idx, sel, kind, relabel_index=relabel_index, ee=ee, label_id=label_id, **kw)]
+        return [format_records(buf, idx, sel, kind, relabel_index=relabel_index, ee=ee, label_id=label_id, scratch=scratch, **kw)]
     cut = lambda a, lo, hi: None if a is None else a[lo:hi]
     jobs = [pool.submit(format_records, buf, idx, sel[a:b], kind, relabel_index=cut(relabel_index, a, b),
-                        ee=cut(ee, a, b), label_id=cut(label_id, a, b), scratch="format%d" % t, **kw)
+                        ee=cut(ee, a, b), label_id=cut(label_id, a, b), scratch="%s%d" % (scratch, t), **kw)
             for t, (a, b) in enumerate(_parts(n, threads))]
     return [j.result() for j in jobs]
 
@@ -343,14 +352,69 @@ def collapse_format_parallel(pool, threads, groups, sel, kind, label_id=None, ls
     return [j.result() for j in jobs]
 
 
+def _plain_file_fd(fh):
+    """File descriptor of an uncompressed regular file opened for reading, else None."""
+    import io
+    import stat
+    if not isinstance(fh, (io.BufferedReader, io.FileIO)):
+        return None
+    try:
+        fd = fh.fileno()
+        return fd if stat.S_ISREG(os.fstat(fd).st_mode) else None
+    except (OSError, ValueError, io.UnsupportedOperation):
+        return None
+
+
 class FastqChunks:
     """Iterate a binary FASTQ stream as (buf, idx) chunks of at most `max_records` records.
-    Raises Unsupported before anything has been yielded from a chunk the C parser cannot take."""
+    Raises Unsupported before anything has been yielded from a chunk the C parser cannot take.
+    threads > 1: the index of a block is built by that many threads, and an uncompressed regular file is read with
+    that many concurrent preads into a fresh buffer per block (buf is then a uint8 array; no block is ever copied or
+    concatenated, only the partial record at its end is carried over).  Compressed input stays one decompressing
+    stream, read block by block."""
 
-    def __init__(self, fh, max_records, block_bytes=1 << 25):
-        self.fh, self.max_records, self.block = fh, max_records, block_bytes
+    def __init__(self, fh, max_records, block_bytes=None, threads=1):
+        self.fh, self.max_records, self.threads = fh, max_records, max(1, int(threads))
+        self.block = block_bytes or (1 << 25)
+        # an uncompressed file read by several threads: 128 MiB, so that a chunk of 262144 x 250-bp records is one block
+        self.plain_block = block_bytes or (1 << 27)
+
+    def _iter_plain(self, fd):
+        L = load()
+        size = os.fstat(fd).st_size
+        off = self.fh.tell()
+        block = self.plain_block
+        carry = np.empty(0, np.uint8)
+        while True:
+            want = max(0, min(block, size - off))
+            buf = np.empty(len(carry) + want, np.uint8)
+            buf[:len(carry)] = carry
+            got = L.mio_pread_mt(fd, off, buf.ctypes.data + len(carry), want, self.threads) if want else 0
+            if got < 0:
+                raise OSError(_err())
+            off += got
+            eof = got < want or off >= size
+            data = buf[:len(carry) + got]
+            pos = 0
+            while pos < len(data):
+                view = data[pos:]
+                idx, consumed, err = index(view, eof, self.max_records, self.threads)
+                if len(idx):
+                    yield view, idx
+                if err is not None:
+                    raise err
+                pos += consumed
+                if len(idx) < self.max_records:
+                    break                                   # the rest is an incomplete record: read on
+            if eof:
+                return                                      # trailing lines that do not make a record are dropped
+            carry = data[pos:].copy()
 
     def __iter__(self):
+        fd = _plain_file_fd(self.fh) if self.threads > 1 else None
+        if fd is not None:
+            yield from self._iter_plain(fd)
+            return
         tail = b""
         eof = False
         while not eof or tail:
@@ -361,7 +425,7 @@ class FastqChunks:
                 else:
                     eof = True
             while tail:
-                idx, consumed, err = index(tail, eof, self.max_records)
+                idx, consumed, err = index(tail, eof, self.max_records, self.threads)
                 if len(idx):
                     yield tail, idx
                 if err is not None:
@@ -386,8 +450,8 @@ class PairedFastqChunks:
     Stops with the shorter file, as zip() does in the reference's parser (moira/moira.py:1158-1160); a
     record that fails the reference's checks raises only when its pair is reached, forward file first."""
 
-    def __init__(self, ffh, rfh, max_records, block_bytes=1 << 24):
-        self.fh, self.max_records, self.block = (ffh, rfh), max_records, block_bytes
+    def __init__(self, ffh, rfh, max_records, block_bytes=1 << 24, threads=1):
+        self.fh, self.max_records, self.block, self.threads = (ffh, rfh), max_records, block_bytes, max(1, int(threads))
 
     def __iter__(self):
         tail, eof, want = [b"", b""], [False, False], [True, True]
@@ -399,7 +463,7 @@ class PairedFastqChunks:
                         tail[k] = tail[k] + more if tail[k] else more
                     else:
                         eof[k] = True
-            got = [index(tail[k], eof[k], self.max_records) for k in (0, 1)]
+            got = [index(tail[k], eof[k], self.max_records, self.threads) for k in (0, 1)]
             n = min(len(got[0][0]), len(got[1][0]))
             # does file k hold a complete record number n (sound or not)?
             has_next = [len(got[k][0]) > n or got[k][2] is not None for k in (0, 1)]
@@ -413,7 +477,7 @@ class PairedFastqChunks:
             if n:
                 for k in (0, 1):
                     if len(got[k][0]) > n:                   # keep what the other file has not reached yet
-                        got[k] = index(tail[k], eof[k], n)
+                        got[k] = index(tail[k], eof[k], n, self.threads)
                 yield tail[0], got[0][0], tail[1], got[1][0]
                 tail = [tail[k][got[k][1]:] for k in (0, 1)]
             if err is not None:

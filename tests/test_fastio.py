@@ -509,3 +509,94 @@ def test_fasta_qual_paired_and_fallbacks(tmp_path, oracle, monkeypatch):
         with pytest.raises(exc):
             cli.main(args_for(None, str(tmp_path / "o"), forward_fasta=str(tmp_path / "bad.fasta"),
                               forward_qual=str(tmp_path / "bad.qual")), backend=backend, out=open(os.devnull, "w"))
+
+
+def test_parallel_indexer_equals_the_sequential_one():
+    """mio_fastq_index_mt (newline counts per byte slice -> record starts -> one sequential indexer per range) against
+    mio_fastq_index on quirky buffers: quality lines that start with '@' or '+', CRLF, a cut last record, no final
+    newline, records that fail the reference's checks, lone CR / non-ASCII bytes (-> Unsupported), every kind of
+    max_records cap.  Rows, consumed, the offending record and the refusal must be identical."""
+    from moira_amd import fastio as F
+    rng = np.random.default_rng(11)
+
+    def make(nrec, crlf, quirk):
+        out = []
+        for i in range(nrec):
+            L = int(rng.integers(1, 120))
+            seq = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), L))
+            qual = bytes(rng.integers(33, 75, L).astype(np.uint8))
+            if rng.random() < 0.1:
+                qual = b"@" + qual[1:]
+            if rng.random() < 0.05:
+                qual = b"+" + qual[1:]
+            lines = [b"@r%d some:text\tmore" % i, seq, b"+" if rng.random() < 0.8 else b"+r%d" % i, qual]
+            if rng.random() < quirk:
+                k = int(rng.integers(0, 4))
+                if k == 0:
+                    lines[1] = b""
+                elif k == 1:
+                    lines[3] = b"  "
+                elif k == 2:
+                    lines[3] = qual + b"I"
+                else:
+                    lines[0] = b"@@weird "
+            nl = b"\r\n" if crlf else b"\n"
+            out.append(nl.join(lines) + nl)
+        return b"".join(out)
+
+    def run(buf, final, maxr, th):
+        try:
+            idx, cons, err = F.index(buf, final, maxr, th)
+            return ("ok", idx.tobytes(), cons, None if err is None else (err.kind, err.header))
+        except F.Unsupported:
+            return ("unsupported",)
+
+    engaged = 0
+    for it in range(40):
+        nrec = int(rng.integers(3000, 9000))
+        buf = make(nrec, rng.random() < 0.3, rng.choice([0, 0, 0.0002, 0.001]))
+        mode = it % 5
+        if mode == 1:
+            buf = buf[:-int(rng.integers(1, 300))]
+        if mode == 2:
+            buf = buf.rstrip(b"\r\n")
+        if mode == 3:
+            p = int(rng.integers(0, len(buf)))
+            buf = buf[:p] + b"\xc3" + buf[p + 1:]
+        if mode == 4 and it % 2:
+            p = int(rng.integers(0, len(buf)))
+            buf = buf[:p] + b"\r" + buf[p + 1:]
+        final = bool(it & 1)
+        maxr = int(rng.choice([1, 100, nrec // 2, nrec, nrec + 10, 10 ** 6]))
+        want = run(buf, final, maxr, 1)
+        for th in (2, 3, 5, 8):
+            engaged += len(buf) >= th * (64 << 10)
+            assert run(buf, final, maxr, th) == want, (it, th, mode, final, maxr)
+    assert engaged > 100                     # the buffers were large enough for the threaded path to run
+
+
+def test_plain_file_reader_with_threads_equals_the_stream_reader(tmp_path):
+    """FastqChunks(threads > 1) on an uncompressed file (concurrent preads into one fresh buffer per block, the
+    partial record carried over) yields the same records as the one-thread stream reader."""
+    from moira_amd import fastio as F
+    rng = np.random.default_rng(12)
+    path = tmp_path / "r.fastq"
+    with open(path, "wb") as f:
+        for i in range(60000):
+            L = int(rng.integers(30, 200))
+            f.write(b"@read%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), L)) + b"\n+\n"
+                    + bytes(rng.integers(33, 74, L).astype(np.uint8)) + b"\n")
+        f.write(b"@dangling\nACGT\n")                       # trailing lines that do not make a record: dropped
+
+    def records(threads, block):
+        out = []
+        with open(path, "rb") as fh:
+            for buf, idx in F.FastqChunks(fh, 7000, block_bytes=block, threads=threads):
+                assert len(idx) <= 7000
+                for r in idx:
+                    out.append((F.header_of(buf, r), bytes(buf[r[F.SEQ_OFF]:r[F.SEQ_OFF] + r[F.SEQ_LEN]]),
+                                bytes(buf[r[F.QUAL_OFF]:r[F.QUAL_OFF] + r[F.QUAL_LEN]])))
+        return out
+    want = records(1, 1 << 20)
+    assert len(want) == 60000 and want[-1][0] == "read59999"
+    assert records(4, 1 << 20) == want
