@@ -43,7 +43,26 @@ CHUNK_READS = 262144
 # ---------------------------------------------------------------------------------------------
 # exceptions (names and messages of moira/moira.py:973-1055)
 # ---------------------------------------------------------------------------------------------
-class ReadTooLongError(Exception):
+class UnsupportedReadError(Exception):
+    """A read this build cannot score the way the reference would (never scored differently instead): raised BEFORE
+    the chunk is filtered; main() removes the partial output files, prints the message and returns 1."""
+
+
+class QualityTooHighError(UnsupportedReadError):
+    """Not a reference exception: the packed quality matrix holds one byte per base (0 = 'N', 255 = 'n'), so Phred
+    scores above 254 cannot be encoded.  FASTQ cannot produce them (the largest character minus the smallest offset is
+    222) and neither can contig construction from FASTQ input (`--consensus_qscore sum` without a cap: 186); only a
+    .qual file with such integers can (the reference takes any int there, moira/bernoullimodule.c:92-108)."""
+    def __init__(self, header, quality):
+        self.header, self.quality = header, quality
+
+    def __str__(self):
+        return ("Sequence %s has a quality score of %d; this build encodes scores up to 254 (an error probability of "
+                "4e-26). Cap the scores in the .qual file (e.g. at 93, the FASTQ maximum) and run again: a capped score "
+                "changes an error probability that is below 1e-25 either way." % (self.header, self.quality))
+
+
+class ReadTooLongError(UnsupportedReadError):
     """Not a reference exception: the Poisson-binomial kernels cover reads of up to 16383 bases (the reference's
     own C path overruns its stack near 1000; its Python twin has no limit but needs O(J^2 L) Python
     steps).  Raised BEFORE the chunk is filtered; main() removes the partial output files and explains the
@@ -131,7 +150,11 @@ def build_parser():
     def str2bool(value):
         return value.lower() in ("yes", "true", "t", "1")
 
-    p = argparse.ArgumentParser(description="Perform quality filtering on a set of sequences.")
+    p = argparse.ArgumentParser(
+        description="Perform quality filtering on a set of sequences.",
+        epilog="Limits of this build (a run that meets one stops with a message and leaves no partial output): the "
+               "poisson_binomial methods score reads of up to 16383 bases (--error_calc poisson: any length); quality "
+               "scores above 254 cannot be encoded (FASTQ input never has them; a .qual file can).")
     g = p.add_argument_group("General options")
     g.add_argument("-ff", "--forward_fasta", type=str, help="Forward fasta file (can be gzip or bzip2 compressed).")
     g.add_argument("-fq", "--forward_qual", type=str, help="Forward qual file (can be gzip or bzip2 compressed).")
@@ -492,6 +515,10 @@ def process_chunk(records, args, backend):
         quals = [ql if isinstance(ql, QualStr) else                                     # moira.py:814 (Q0 -> 1);
                  (np.maximum(ql, 1) if isinstance(ql, np.ndarray) else [q if q > 0 else 1 for q in ql])
                  for ql in quals]                                                       # QualStr clamps in ints()
+        if args.error_calc in ("poisson_binomial", "poisson_binomial_py", "poisson") and getattr(backend, "methods", None):
+            for i, ql in enumerate(quals):                   # the packed matrix holds one byte per base
+                if not isinstance(ql, QualStr) and len(ql) and int(max(ql)) > 254:
+                    raise QualityTooHighError(records[i][0], int(max(ql)))
         if args.error_calc in ("poisson_binomial", "poisson_binomial_py"):
             for i, sq in enumerate(seqs):
                 if len(sq) > MAX_PB_LEN:
@@ -1116,7 +1143,7 @@ def main(args, backend=None, out=None, _no_fastio=False):
             for p in o.files:
                 say(p)
             say()
-    except ReadTooLongError as e:
+    except UnsupportedReadError as e:
         _close(o)
         for p in o.files:                       # nothing half-written is left behind
             try:

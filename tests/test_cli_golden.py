@@ -312,6 +312,29 @@ def test_over_long_read_fails_cleanly_before_filtering(tmp_path, oracle, monkeyp
     assert os.path.exists(out + ".qc.good.fasta")
 
 
+def test_quality_above_254_fails_cleanly(tmp_path, oracle):
+    """a .qual file may hold any integer (the reference takes them, moira/bernoullimodule.c:92-108); the
+    packed matrix holds one byte per base.  Such a run stops before the chunk is filtered, names the read and the score,
+    returns 1 and leaves no partial output -- it is never scored with a clamped value."""
+    import io
+    fa, qu = tmp_path / "r.fasta", tmp_path / "r.qual"
+    with open(fa, "w") as f, open(qu, "w") as g:
+        for k, top in enumerate((40, 300, 41)):
+            f.write(">r%d\n%s\n" % (k, "ACGT" * 10))
+            g.write(">r%d\n%s\n" % (k, " ".join(str(top if i == 7 else 30) for i in range(40))))
+    out = str(tmp_path / "o")
+    msg = io.StringIO()
+
+    def backend(seqs, quals, alpha, ambigs, round_, **kw):
+        return oracle_backend(oracle)(seqs, quals, alpha, ambigs, round_)
+    backend.methods = ("poisson_binomial", "poisson")
+    a = reference_args(paired=False, forward_fasta=str(fa), forward_qual=str(qu), output_prefix=out, collapse=False, silent=True)
+    assert cli.main(a, backend=backend, out=msg) == 1
+    text = msg.getvalue()
+    assert "r1" in text and "300" in text and "254" in text
+    assert not [p for p in os.listdir(tmp_path) if p.startswith("o.")]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("line_parser", [False, True])
 def test_long_reads_run_with_the_poisson_method_gpu(tmp_path, line_parser):
