@@ -220,18 +220,33 @@ RCCL_DEADLINE_S = 90
 class Collectives:
     """The few, tiny collectives of an N > 1 run (see the module docstring).  world == 1: all no-ops."""
 
-    def __init__(self, world, rank, local_rank, use_gpu, try_rccl):
+    def __init__(self, world, rank, local_rank, use_gpu, try_rccl, selftest=False):
         self.world, self.rank = world, rank
         self.totals_backend = None
         self.rccl_error = None
         self._rccl = None
         self._hung = False
-        if world == 1:
+        self.selftest = None
+        if world == 1 and not selftest:
             return
         import datetime
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        if world == 1:
+            # --rccl-selftest on one GPU: a one-rank group, so that the code below (gloo group, RCCL communicator created
+            # under a deadline, a 24-byte all-reduce on the GPU, the vote) runs on real hardware at least once before
+            # the driver's 8-GPU run -- it says nothing about xGMI, only that RCCL loads and initialises here
+            dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                                    timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
+            ok = self._try_rccl(local_rank)
+            got = self.sum_totals_rccl((1, 2, 3)) if ok else None
+            self.selftest = {"rccl_group": "ok" if ok else "failed: %s" % self.rccl_error,
+                             "all_reduce_3xint64_on_gpu": got, "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())
+                             if hasattr(torch.cuda, "nccl") else None}
+            self.world = 1
+            self.close_selftest()
+            return
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
         self.totals_backend = "gloo"
         if use_gpu and try_rccl:
@@ -322,6 +337,20 @@ class Collectives:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return [int(v) for v in t.tolist()]
 
+    def sum_totals_rccl(self, triple):
+        t = self.torch.tensor(list(triple), dtype=self.torch.int64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self._rccl)
+        return [int(v) for v in t.tolist()]
+
+    def close_selftest(self):
+        if self._hung:
+            return                                              # the parked thread is a daemon; the N = 1 run goes on
+        try:
+            self.dist.destroy_process_group()
+        except Exception:                                       # noqa: BLE001 -- a self-test never costs the headline
+            pass
+        self._rccl = None
+
     def close(self):
         if self.world == 1:
             return
@@ -393,6 +422,9 @@ def main():
     ap.add_argument("--rehearse-on-cpu", action="store_true",
                     help="multi-rank dry run without any GPU: the step is a stub; exercises launch + collectives only")
     ap.add_argument("--no-rccl", action="store_true", help="do not try RCCL for the 24-byte totals (gloo only)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="N = 1 only: before the run, bring up a ONE-rank gloo + RCCL group on this GPU and do the 24-byte "
+                         "all-reduce on it (under the same deadline as an N > 1 run); reported as `rccl_selftest`")
     ap.add_argument("--_rank-delay-ms", type=float, default=0.0, help=argparse.SUPPRESS)    # tests: rank r's stub step takes 1 + r*this ms
     ap.add_argument("--_die-rank", type=int, default=-1, help=argparse.SUPPRESS)             # tests: this rank dies before the timed region
     args = ap.parse_args()
@@ -418,7 +450,8 @@ def main():
             raise SystemExit("rank %d wants GPU %d but only %d GPU(s) are visible (--gpus %d needs %d)"
                              % (rank, local_rank, have, args.gpus, args.gpus))
         torch.cuda.set_device(local_rank)
-    coll = Collectives(world, rank, local_rank, use_gpu, try_rccl=not (rehearsal or args.no_rccl))
+    coll = Collectives(world, rank, local_rank, use_gpu, try_rccl=not (rehearsal or args.no_rccl),
+                       selftest=args.rccl_selftest and world == 1 and use_gpu)
 
     L = args.length
     n = args.reads or (CONFIG2_READS if world == 1 else CONFIG4_SHARD)
@@ -615,6 +648,7 @@ def main():
                        "mode": "fast_fma (NOT bit-exact)" if args.fast_fma else "bit-exact (no FMA)"},
             "weak_scaling_anchor": anchor,
             "devices": devices,
+            "rccl_selftest": coll.selftest,
             "timed_region_s": dt,
             "t_step_rank_uniform_s": t_step,
             "reads_per_s_per_rank": per_rank,

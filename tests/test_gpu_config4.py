@@ -93,6 +93,26 @@ def test_bench_starts_its_own_ranks_from_the_plain_command():
     assert "gloo" in line["config"]["collective_backend"]
 
 
+def test_bench_rccl_selftest_on_this_gpu():
+    """"RCCL has never executed".  On a one-GPU box it can only run with one rank, but that still loads
+    librccl, creates the communicator under bench.py's deadline thread and does the 24-byte all-reduce on the GPU --
+    the code an N > 1 run uses for its totals."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rccl-selftest", "--reads", "300000", "--steps", "3",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    st = line["rccl_selftest"]
+    assert st["rccl_group"] == "ok" and st["all_reduce_3xint64_on_gpu"] == [1, 2, 3], st
+    assert line["n_gpus"] == 1 and line["value"] > 0
+
+
 def test_bench_four_rank_rehearsal_on_one_gpu():
     """the widest rehearsal a 1-GPU box allows (the pool admits 6 processes on a card: four ranks, this
     test process and one spare), 2 M reads per rank: port selection, the build lock under four simultaneous imports,
