@@ -27,6 +27,8 @@ with Engine(0) as eng:
 
     for rep in range(int(os.environ.get("REPS", "3"))):
         for name, fn in (("decode + filter", two_pass), ("classified at source", at_source)):
+            if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+                continue
             fn(); eng.synchronize()
             t = time.perf_counter()
             for _ in range(20):
