@@ -536,7 +536,9 @@ def main():
     hist = eng.class_histogram()
     # extra (NOT the headline, work is skipped by design): opt-in MPB_FLAG_DECISION_ONLY, same batch
     extras = {}
-    if not args.no_extras and rank == 0:
+    # N = 1 only: with more ranks the others would sit in the closing barrier (120 s timeout) while rank 0 runs them,
+    # and they describe the single-GPU library, not the multi-GPU run
+    if not args.no_extras and rank == 0 and world == 1:
         def rate(prm, reps=5, **kw):
             a = dict(d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm)
             a.update(kw)

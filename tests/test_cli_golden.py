@@ -360,3 +360,34 @@ def test_long_reads_run_with_the_poisson_method_gpu(tmp_path, line_parser):
         e, ns = calculate_errors_poisson(s, [ord(c) - 33 for c in q], 0.005)
         where = "good" if e + ns <= len(s) * 0.01 else "bad"
         assert ">r%d" % k in open("%s.qc.%s.fasta" % (out, where)).read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("line_parser", [False, True])
+@pytest.mark.parametrize("method", ["poisson_binomial", "poisson_binomial_py"])
+def test_long_reads_run_with_the_poisson_binomial_method_gpu(tmp_path, oracle, line_parser, method):
+    """Round 3: reads of 1,100 / 2,500 / 4,000 bases go through the CLI under --error_calc poisson_binomial (and its
+    _py alias, which the reference serves with the unlimited Python twin, moira/moira.py:820-821) instead of being
+    refused; a long read of terrible quality (more than 1024 DP rows: k_wide) among them.  The decisions are the
+    oracle's, which is pinned to the real reference at these lengths (tests/golden/long_reads.npz)."""
+    fq = tmp_path / "long.fastq"
+    rng = np.random.default_rng(8)
+    recs = []
+    for k, (n, lo, hi) in enumerate(((300, 25, 41), (1100, 30, 41), (2500, 33, 41), (2500, 1, 4), (4000, 35, 41), (700, 2, 41))):
+        q = "".join(chr(33 + int(v)) for v in rng.integers(lo, hi, n))
+        s = "".join(rng.choice(list("ACGT"), n))
+        recs.append((s, q))
+    with open(fq, "w") as f:
+        for k, (s, q) in enumerate(recs):
+            f.write("@r%d\n%s\n+\n%s\n" % (k, s, q))
+    out = str(tmp_path / "o")
+    a = reference_args(paired=False, forward_fastq=str(fq), output_prefix=out, collapse=False, error_calc=method)
+    assert cli.main(a, out=open(os.devnull, "w"), _no_fastio=line_parser) == 0
+    good, bad = open(out + ".qc.good.fasta").read(), open(out + ".qc.bad.fasta").read()
+    n_good = 0
+    for k, (s, q) in enumerate(recs):
+        e, ns, rows = oracle.ee_rowwise(s, [ord(c) - 33 for c in q], 0.005)
+        keep = e + ns <= len(s) * 0.01
+        n_good += keep
+        assert (">r%d\n" % k in good) == keep and (">r%d\t" % k in bad) == (not keep), (k, e, rows)
+    assert 0 < n_good < len(recs)
