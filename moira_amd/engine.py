@@ -278,11 +278,17 @@ class Engine:
             raise ValueError("Alpha must be between 0 and 1")
         if len(contig_quals) != len(contig):
             raise ValueError("contig and contig_quals must have the same length")
-        qi = np.empty(len(contig_quals), np.int32)
-        for i, v in enumerate(contig_quals):
-            if not isinstance(v, int):
-                raise TypeError("an integer is required")      # PyInt_AsLong on a non-int
-            qi[i] = v
+        qi = None
+        if contig_quals:
+            a = np.asarray(contig_quals)                       # one C loop for the common case: a list of Python ints
+            if a.ndim == 1 and a.dtype.kind in "iub" and (a.dtype.kind == "b" or (a.min() >= -2 ** 31 and a.max() < 2 ** 31)):
+                qi = a.astype(np.int32)
+        if qi is None:                                         # anything else: element by element, as PyInt_AsLong would
+            qi = np.empty(len(contig_quals), np.int32)
+            for i, v in enumerate(contig_quals):
+                if not isinstance(v, int):
+                    raise TypeError("an integer is required")
+                qi[i] = v
         ee, ns = C.c_double(), C.c_int32()
         L.check(self.lib.mpb_calculate_errors_PB(self.ctx, contig.encode(), qi.ctypes.data, len(qi), alpha,
                                                  C.byref(ee), C.byref(ns)))
