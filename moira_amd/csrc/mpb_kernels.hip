@@ -212,7 +212,7 @@ __device__ __forceinline__ uint4 decode16(const uint4 sq, const uint4 ql, int po
                       decode4(sq.z, ql.z, nv - 8, offset, off4, bad), decode4(sq.w, ql.w, nv - 12, offset, off4, bad));
 }
 
-// where a DECODE instance of the prepass takes its bytes from, and where it leaves the packed matrix
+// where the classified-at-source pass (k_classify_linear<., DECODE>) takes its bytes from, and where it leaves the packed matrix
 struct PreDecode {
     const uint8_t *seq;       // n x stride base letters
     const uint8_t *qual;      // n x stride FASTQ quality characters
@@ -221,23 +221,71 @@ struct PreDecode {
     int32_t *err;             // device counter of undecodable bytes, may be nullptr
 };
 
+// where the classification of a read goes
+struct PreOut {
+    uint8_t *cls; int32_t *ns; double *ee; uint8_t *pass;
+    int32_t *bad_len, *wide_list, *wide_rows, *wide_count;
+};
+
+// One read's statistics -> row budget -> class byte, Ns, histogram count (or: settled / wide / bad length).
+// mu, var, k3: fp32 sums of p, p(1-p), p(1-p)(1-2p) over the scored bases; ambi = 'N' count | 'n' count << 16;
+// li = the (clamped) length, bad = the caller-supplied length did not fit the row.
+__device__ __forceinline__ void class_read(int64_t i, float mu, float var, float k3, int ambi, int li, bool bad, bool ragged,
+                                           const MpbDevParams &prm, const PreOut &o, int *s_hist, int nb)
+{
+    const int nzero = ambi & 0xffff, n255 = ambi >> 16;
+    // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
+    // rows 0..j* where j* is the first row whose CDF exceeds 1-alpha.
+    const float v = fmaxf(var, 1e-12f);
+    const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;
+    int rows = (int)floorf(fminf(x, 1e9f) + 0.5f) + 1;
+    if (prm.flags & 4u) rows = rows / 2;                          // MPB_FLAG_TEST_UNDERPREDICT
+    const int scored = li - nzero - n255;
+    rows = min(rows, scored + 1);
+    rows = max(rows, 1);
+    o.ns[i] = bad ? 0 : nzero + n255;
+    const int c = c_class_of_rows.t[min(rows, MPB_TILE_MAX_ROWS)];
+    bool settled = false;
+    if (!bad && (prm.flags & 8u)) {                               // MPB_FLAG_DECISION_ONLY
+        // Chernoff: P(X <= (1-d)mu) <= exp(-d^2 mu / 2) <= 1-alpha for d = clow/sqrt(mu), so the
+        // first CDF row above 1-alpha is > t = mu - clow*sqrt(mu) and ee >= floor(t).  mu is an
+        // fp32 sum of approximated p: shave 1e-4 relative and 0.02 absolute before trusting it.
+        const float t = mu * (1.0f - 1e-4f) - prm.clow * sqrtf(mu) - 0.02f;
+        const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
+        settled = mu > 1.0f && (double)floorf(t) > limit;
+    }
+    if (bad) {
+        // a length outside 0..max_len is never clamped silently: the read gets no result (NaN, rejected) --
+        // also for a caller that never fetches the counts -- and the call that does fetch them fails
+        atomicAdd(o.bad_len, 1);
+        o.cls[i] = (uint8_t)MPB_CLS_SETTLED;
+        o.ee[i] = __builtin_nan("");
+        o.pass[i] = 0;
+    } else if (settled) {
+        o.cls[i] = (uint8_t)(MPB_CLS_SETTLED | (nzero > 0 ? 0x80 : 0));
+        o.ee[i] = __builtin_inf();              // "certainly above the threshold"; NaN stays a failure
+        o.pass[i] = 0;
+    } else if (rows > MPB_TILE_MAX_ROWS) {
+        // wide read: more rows than one wave holds -> listed for k_wide (only possible when max_len >= 1024,
+        // and then the host has provided the list)
+        const int pos = atomicAdd(o.wide_count, 1);
+        o.wide_list[pos] = (int32_t)i;
+        o.wide_rows[pos] = rows;
+        o.cls[i] = (uint8_t)(MPB_CLS_WIDE | (nzero > 0 ? 0x80 : 0));
+    } else {
+        o.cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
+        atomicAdd(&s_hist[c * nb + (ragged ? min(MPB_LEN_BINS - 1, li >> prm.len_shift) : 0)], 1);
+    }
+}
+
 // RAGGED <=> len != nullptr; the fixed-length instance has one length bin and no len loads.
 // LONG <=> rows of more than 960 bytes: walked in panels (below); the short-row instances are one panel by construction.
-// DECODE <=> classified at source: the bytes come from raw FASTQ text resident in HBM (two matrices), are decoded on the
-// way in, written out as the packed matrix and classified in the same pass -- the packed matrix is never re-read to be
-// classified (mpb_decode_classify_device + mpb_filter_device_classified).
-template <bool RAGGED, bool LONG, bool DECODE>
+// (Classified at source -- text in, packed matrix out, classified on the way -- is k_classify_linear below: with three
+// streams to move, a linear walk beats this kernel's row-per-lane shape; for the one stream here it is the other way round.)
+template <bool RAGGED, bool LONG>
 __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, int64_t n,
                                                  int64_t stride, const int32_t *__restrict__ len_arg,
-                                                 MpbDevParams prm, uint8_t *__restrict__ cls,
-                                                 int32_t *__restrict__ blockhist,
-                                                 int32_t *__restrict__ ns_out,
-                                                 double *__restrict__ ee_out,
-                                                 uint8_t *__restrict__ pass_out,
-                                                 int32_t *__restrict__ bad_len,
-                                                 int32_t *__restrict__ wide_list,
-                                                 int32_t *__restrict__ wide_rows,
-                                                 int32_t *__restrict__ wide_count, PreDecode dec)
+                                                 MpbDevParams prm, PreOut o, int32_t *__restrict__ blockhist)
 {
     __shared__ float2 s_tab[256];
     __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts (bits of an int: N | n << 16)}
@@ -274,11 +322,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         }
         ncol = __builtin_amdgcn_readfirstlane(ncol);
         nfull = __builtin_amdgcn_readfirstlane(nfull);
-        const int row_chunks = (int)(stride >> 4);
-        const int ncol_io = DECODE ? row_chunks : ncol;   // DECODE writes the whole row of the packed matrix (zeros past the read's end)
-        const int64_t row_off = (live ? i : (int64_t)0) * stride + cl * 16;
-        const uint8_t *src = q + row_off;
-        int badq = 0;
+        const uint8_t *src = q + (live ? i : (int64_t)0) * stride + cl * 16;
         float mu = 0.f, var = 0.f, k3 = 0.f;
         int ambi = 0;                              // 'N' count | 'n' count << 16
         // A panel = 3 * MPB_PRE_NB column quads = at most 240 bytes per lane, so that the ambiguity markers come off
@@ -290,36 +334,12 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         // looked at (a row of 300 bases is one such batch), so a wave keeps 5 KiB in flight
         for (int cb = pb; cb < pend; cb += 4 * MPB_PRE_NB) {
             uint4 xs[MPB_PRE_NB];
-            if (!DECODE) {
 #pragma unroll
-                for (int b = 0; b < MPB_PRE_NB; b++) {
-                    const int c0 = cb + 4 * b;
-                    xs[b] = make_uint4(0, 0, 0, 0);
-                    if (c0 < pend && li > (c0 + cl) * 16)
-                        xs[b] = *reinterpret_cast<const uint4 *>(src + c0 * 16);
-                }
-            } else {
-                // text in: all loads of the batch (two per chunk) are issued before the first chunk is decoded
-                uint4 sqs[MPB_PRE_NB], qls[MPB_PRE_NB];
-#pragma unroll
-                for (int b = 0; b < MPB_PRE_NB; b++) {
-                    const int c0 = cb + 4 * b;
-                    sqs[b] = qls[b] = make_uint4(0, 0, 0, 0);
-                    if (c0 < pend && li > (c0 + cl) * 16) {
-                        sqs[b] = *reinterpret_cast<const uint4 *>(dec.seq + row_off + c0 * 16);
-                        qls[b] = *reinterpret_cast<const uint4 *>(dec.qual + row_off + c0 * 16);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int b = 0; b < MPB_PRE_NB; b++) {
-                    const int c0 = cb + 4 * b;
-                    xs[b] = make_uint4(0, 0, 0, 0);
-                    if (c0 < pend && c0 + cl < row_chunks && live) {
-                        if (li > (c0 + cl) * 16) xs[b] = decode16(sqs[b], qls[b], (c0 + cl) * 16, li, dec.offset, badq);
-                        *reinterpret_cast<uint4 *>(dec.out + row_off + c0 * 16) = xs[b];
-                    }
-                }
+            for (int b = 0; b < MPB_PRE_NB; b++) {
+                const int c0 = cb + 4 * b;
+                xs[b] = make_uint4(0, 0, 0, 0);
+                if (c0 < pend && li > (c0 + cl) * 16)
+                    xs[b] = *reinterpret_cast<const uint4 *>(src + c0 * 16);
             }
 #pragma unroll
             for (int b = 0; b < MPB_PRE_NB; b++) {
@@ -331,7 +351,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
                     y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
                     y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
                 }
-                if (!DECODE || c0 < ncol) pre_chunk(s_tab, y, a01, s3);    // (wave-uniform) columns past the longest read: written, not summed
+                pre_chunk(s_tab, y, a01, s3);
             }
         }
         // second component = sum p(1-p) (<= 64) + 128 per 'N' + 65536 per 'n': peel the markers
@@ -344,8 +364,8 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         k3 += pvar - 2.0f * s3;                                           // sum p(1-p)(1-2p)
         ambi += (int)nzero + ((int)n255 << 16);
         };  // panel
-        if (LONG) { for (int pb = 0; pb < ncol_io; pb += 12 * MPB_PRE_NB) panel(pb, min(ncol_io, pb + 12 * MPB_PRE_NB)); }
-        else panel(0, ncol_io);
+        if (LONG) { for (int pb = 0; pb < ncol; pb += 12 * MPB_PRE_NB) panel(pb, min(ncol, pb + 12 * MPB_PRE_NB)); }
+        else panel(0, ncol);
         // the four lanes of a read, combined in a fixed order: (cl0 + cl1) + (cl2 + cl3)
 #pragma unroll
         for (int off = 16; off <= 32; off <<= 1) {
@@ -355,7 +375,6 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             ambi += __shfl_xor(ambi, off);
         }
         const float amb = __int_as_float(ambi);
-        if (DECODE && badq && dec.err) atomicAdd(dec.err, badq);
         if (cl == 0) s_row[w][rb + r16] = make_float4(mu, var, k3, amb);
     }
     wave_lds_fence();          // s_row[w] is private to this wave: no block barrier
@@ -364,57 +383,139 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         const int64_t i = wave_row0 + lane;
         if (i < n) {
             const float4 e = s_row[w][lane];
-            const float mu = e.x, var = e.y, k3 = e.z;
             const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
-            const int ambi = __float_as_int(e.w);
-            const int nzero = ambi & 0xffff, n255 = ambi >> 16;
-            // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
-            // rows 0..j* where j* is the first row whose CDF exceeds 1-alpha.
-            const float v = fmaxf(var, 1e-12f);
-            const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;
-            int rows = (int)floorf(fminf(x, 1e9f) + 0.5f) + 1;
-            if (prm.flags & 4u) rows = rows / 2;                          // MPB_FLAG_TEST_UNDERPREDICT
-            const int scored = li - nzero - n255;
-            rows = min(rows, scored + 1);
-            rows = max(rows, 1);
-            const bool bad = RAGGED && li != len[i];
-            ns_out[i] = bad ? 0 : nzero + n255;
-            const int c = c_class_of_rows.t[min(rows, MPB_TILE_MAX_ROWS)];
-            bool settled = false;
-            if (!bad && (prm.flags & 8u)) {                                         // MPB_FLAG_DECISION_ONLY
-                // Chernoff: P(X <= (1-d)mu) <= exp(-d^2 mu / 2) <= 1-alpha for d = clow/sqrt(mu), so the
-                // first CDF row above 1-alpha is > t = mu - clow*sqrt(mu) and ee >= floor(t).  mu is an
-                // fp32 sum of approximated p: shave 1e-4 relative and 0.02 absolute before trusting it.
-                const float t = mu * (1.0f - 1e-4f) - prm.clow * sqrtf(mu) - 0.02f;
-                const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
-                settled = mu > 1.0f && (double)floorf(t) > limit;
-            }
-            if (bad) {
-                // a length outside 0..max_len is never clamped silently: the read gets no result (NaN, rejected) --
-                // also for a caller that never fetches the counts -- and the call that does fetch them fails
-                atomicAdd(bad_len, 1);
-                cls[i] = (uint8_t)MPB_CLS_SETTLED;
-                ee_out[i] = __builtin_nan("");
-                pass_out[i] = 0;
-            } else if (settled) {
-                cls[i] = (uint8_t)(MPB_CLS_SETTLED | (nzero > 0 ? 0x80 : 0));
-                ee_out[i] = __builtin_inf();              // "certainly above the threshold"; NaN stays a failure
-                pass_out[i] = 0;
-            } else if (rows > MPB_TILE_MAX_ROWS) {
-                // wide read: more rows than one wave holds -> listed for k_wide (only possible when max_len >= 1024,
-                // and then the host has provided the list)
-                const int pos = atomicAdd(wide_count, 1);
-                wide_list[pos] = (int32_t)i;
-                wide_rows[pos] = rows;
-                cls[i] = (uint8_t)(MPB_CLS_WIDE | (nzero > 0 ? 0x80 : 0));
-            } else {
-                cls[i] = (uint8_t)(c | (nzero > 0 ? 0x80 : 0));
-                atomicAdd(&s_hist[c * nb + (len ? min(MPB_LEN_BINS - 1, li >> prm.len_shift) : 0)], 1);
-            }
+            class_read(i, e.x, e.y, e.z, __float_as_int(e.w), li, RAGGED && li != len[i], RAGGED, prm, o, s_hist, nb);
         }
     }
     wave_lds_fence();                             // s_row[w] is reused by the next round
     }   // rounds
+    __syncthreads();
+    for (int k = tid; k < MPB_NCLS * nb; k += 256) blockhist[(int64_t)k * gridDim.x + blockIdx.x] = s_hist[k];   // key-major
+}
+
+// ------------------------------------------------------------------------------------------
+// k_classify_linear: the same classification, walking the matrix LINEARLY.
+// k_prepass gives a lane one row (16 rows x 64 bytes per load instruction) so that a read's sums stay in registers.  When
+// the pass also has to move text in and the packed matrix out (classified at source: three streams), that access
+// shape, not the arithmetic, is what limits it.  Here thread t of a block takes the 16-byte chunks t, t + 256, ... of a
+// tile of whole rows -- consecutive lanes read and write consecutive addresses, exactly as the plain decode kernel does --
+// peels its chunk's ambiguity markers at once (16 bytes: always exact), leaves the chunk's partial sums in LDS, and the
+// rows of the tile are then summed from LDS in a fixed order (deterministic) by a few lanes each and classified.
+// Block b still owns reads [1024 b, 1024 b + 1024): the histograms keep the layout k_scan / k_scatter expect.
+// ------------------------------------------------------------------------------------------
+#ifndef MPB_LIN_K
+#define MPB_LIN_K 5                               // chunks per thread and tile, all loaded before the first is used
+#endif
+#define MPB_LIN_CHUNKS (256 * MPB_LIN_K)
+
+template <bool RAGGED, bool DECODE>
+__global__ __launch_bounds__(256) void k_classify_linear(const uint8_t *__restrict__ q, int64_t n, int64_t stride,
+                                                         const int32_t *__restrict__ len_arg, MpbDevParams prm, PreOut o,
+                                                         int32_t *__restrict__ blockhist, PreDecode dec, uint32_t cpr_magic)
+{
+    __shared__ float2 s_tab[256];
+    __shared__ float4 s_part[MPB_LIN_CHUNKS];     // per chunk: {sum p, sum p(1-p), sum p(1-p)(1-2p), ambiguity counts}
+    __shared__ int s_len[MPB_PRE_READS];          // clamped length of each row of the tile
+    __shared__ int s_hist[RAGGED ? MPB_SKEYS : MPB_NCLS];
+    const int32_t *__restrict__ len = RAGGED ? len_arg : nullptr;
+    constexpr int nb = RAGGED ? MPB_LEN_BINS : 1;
+    const int tid = threadIdx.x;
+    {
+        const bool amb = tid == 0 || tid == 255;
+        float p = __builtin_amdgcn_exp2f(-0.33219281f * (float)tid);      // 10^(-q/10)
+        p = amb ? 0.0f : p;
+        s_tab[tid] = make_float2(p, tid == 0 ? MPB_MARK_UPPER : tid == 255 ? MPB_MARK_LOWER : p * (1.0f - p));
+    }
+    for (int k = tid; k < MPB_NCLS * nb; k += 256) s_hist[k] = 0;
+    const int cpr = (int)(stride >> 4);                                   // chunks per row (<= 1024)
+    const int tile_rows = max(1, min(MPB_PRE_READS, MPB_LIN_CHUNKS / cpr));
+    const int64_t first = (int64_t)blockIdx.x * MPB_PRE_READS;
+    const int64_t last = min(n, first + MPB_PRE_READS);
+    // lanes that share a row in the reduction: a power of two, at most 64, as many as the block has to spare
+    int lpr = 1;
+    while (lpr < 64 && lpr * 2 * tile_rows <= 256) lpr *= 2;
+    int badq = 0;
+    for (int64_t row0 = first; row0 < last; row0 += tile_rows) {
+        const int nr = (int)min((int64_t)tile_rows, last - row0);
+        const int nchunks = nr * cpr;
+        __syncthreads();                                                  // s_len / s_part of the tile before (and the tables above)
+        for (int t = tid; t < nr; t += 256) s_len[t] = len ? clamp_len(len[row0 + t], prm.max_len) : prm.fixed_len;
+        __syncthreads();
+        const int64_t base = row0 * stride;
+        // ---- all loads of the tile first ----
+        uint4 xs[MPB_LIN_K], ys[MPB_LIN_K];
+        int nvs[MPB_LIN_K];
+#pragma unroll
+        for (int k = 0; k < MPB_LIN_K; k++) {
+            const int c = tid + k * 256;
+            xs[k] = ys[k] = make_uint4(0, 0, 0, 0);
+            nvs[k] = -1;                                                  // -1: no such chunk in this tile
+            if (c < nchunks) {
+                const int r = cpr_magic ? (int)__umulhi((uint32_t)c, cpr_magic) : c;   // c / cpr (magic 0: cpr == 1), exact for c < 2^16
+                const int col = c - r * cpr;
+                const int nv = s_len[r] - col * 16;                       // bases of the read in this chunk (may be <= 0)
+                nvs[k] = max(nv, 0);
+                if (nv > 0) {
+                    if (DECODE) {
+                        xs[k] = *reinterpret_cast<const uint4 *>(dec.seq + base + (int64_t)c * 16);
+                        ys[k] = *reinterpret_cast<const uint4 *>(dec.qual + base + (int64_t)c * 16);
+                    } else {
+                        xs[k] = *reinterpret_cast<const uint4 *>(q + base + (int64_t)c * 16);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- decode (and write the packed chunk), sum, peel, park the partials ----
+#pragma unroll
+        for (int k = 0; k < MPB_LIN_K; k++) {
+            const int c = tid + k * 256;
+            const int nv = nvs[k];
+            if (nv < 0) continue;
+            uint4 y = xs[k];
+            if (DECODE) {
+                if (nv > 0) y = decode16(xs[k], ys[k], 0, nv, dec.offset, badq);
+                *reinterpret_cast<uint4 *>(dec.out + base + (int64_t)c * 16) = y;     // zeros past the read's end
+            }
+            float4 part = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+            if (nv > 0) {
+                if (nv < 16) {
+                    y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
+                    y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
+                }
+                f32x2 a01 = {0.f, 0.f};
+                float s3 = 0.f;
+                pre_chunk(s_tab, y, a01, s3);
+                const float n255 = floorf(a01.y * (1.0f / MPB_MARK_LOWER));
+                const float rem = a01.y - MPB_MARK_LOWER * n255;
+                const float nzero = floorf(rem * (1.0f / MPB_MARK_UPPER));
+                const float pvar = rem - MPB_MARK_UPPER * nzero;
+                part = make_float4(a01.x, pvar, pvar - 2.0f * s3, __int_as_float((int)nzero + ((int)n255 << 16)));
+            }
+            s_part[c] = part;
+        }
+        __syncthreads();
+        // ---- rows of the tile: lpr lanes each, chunk partials in a fixed order ----
+        const int sub = tid & (lpr - 1);
+        for (int r = tid / lpr; r < nr; r += 256 / lpr) {                 // (256 / lpr) rows per sweep; wave-uniform trip count not needed
+            float mu = 0.f, var = 0.f, k3 = 0.f;
+            int ambi = 0;
+            for (int j = sub; j < cpr; j += lpr) {
+                const float4 e = s_part[r * cpr + j];
+                mu += e.x; var += e.y; k3 += e.z; ambi += __float_as_int(e.w);
+            }
+            for (int off = 1; off < lpr; off <<= 1) {
+                mu += __shfl_xor(mu, off); var += __shfl_xor(var, off);
+                k3 += __shfl_xor(k3, off); ambi += __shfl_xor(ambi, off);
+            }
+            if (sub == 0) {
+                const int64_t i = row0 + r;
+                const int li = s_len[r];
+                class_read(i, mu, var, k3, ambi, li, RAGGED && li != len[i], RAGGED, prm, o, s_hist, nb);
+            }
+        }
+    }
+    if (DECODE && badq && dec.err) atomicAdd(dec.err, badq);
     __syncthreads();
     for (int k = tid; k < MPB_NCLS * nb; k += 256) blockhist[(int64_t)k * gridDim.x + blockIdx.x] = s_hist[k];   // key-major
 }
@@ -1378,13 +1479,23 @@ void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
                         double *ee_out, uint8_t *pass_out, hipStream_t s)
 {
-#define MPB_PRE_LAUNCH(RG, LG, DG)                                                                                      \
-    hipLaunchKernelGGL((k_prepass<RG, LG, DG>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, ws.cls,   \
-                       ws.blockhist, ns_out, ee_out, pass_out, ws.bad_len, ws.wide_list, ws.wide_rows, ws.wide_count, dec)
-    const PreDecode dec = {nullptr, nullptr, nullptr, 0, nullptr};
+#define MPB_PRE_LAUNCH(RG, LG)                                                                                          \
+    hipLaunchKernelGGL((k_prepass<RG, LG>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist)
+    const PreOut o = {ws.cls, ns_out, ee_out, pass_out, ws.bad_len, ws.wide_list, ws.wide_rows, ws.wide_count};
+#ifdef MPB_PREPASS_LINEAR                 // experiment builds: the linear walk for the plain prepass too (measured slower)
+    {
+        const PreDecode dec = {nullptr, nullptr, nullptr, 0, nullptr};
+        const uint32_t cpr = (uint32_t)(stride >> 4);
+        const uint32_t magic = cpr == 1 ? 0u : (uint32_t)(((1ull << 32) + cpr - 1) / cpr);
+        if (len) hipLaunchKernelGGL((k_classify_linear<true, false>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist, dec, magic);
+        else     hipLaunchKernelGGL((k_classify_linear<false, false>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist, dec, magic);
+        return;
+    }
+#endif
     const bool long_rows = prm.max_len > 16 * 12 * MPB_PRE_NB;        // more than one panel of 60 chunk columns
-    if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true, false); else MPB_PRE_LAUNCH(true, false, false); }
-    else     { if (long_rows) MPB_PRE_LAUNCH(false, true, false); else MPB_PRE_LAUNCH(false, false, false); }
+    if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true); else MPB_PRE_LAUNCH(true, false); }
+    else     { if (long_rows) MPB_PRE_LAUNCH(false, true); else MPB_PRE_LAUNCH(false, false); }
+#undef MPB_PRE_LAUNCH
 }
 
 // classified at source: decode raw FASTQ text into the packed matrix `out` and classify it in the same pass
@@ -1392,12 +1503,13 @@ void mpb_launch_decode_classify(const uint8_t *seq, const uint8_t *qual, int32_t
                                 int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                                 const MpbWorkspace &ws, int32_t *ns_out, double *ee_out, uint8_t *pass_out, hipStream_t s)
 {
+    const PreOut o = {ws.cls, ns_out, ee_out, pass_out, ws.bad_len, ws.wide_list, ws.wide_rows, ws.wide_count};
     const PreDecode dec = {seq, qual, out, offset, err};
     const uint8_t *q = out;
-    const bool long_rows = stride > 16 * 12 * MPB_PRE_NB;             // a DECODE instance walks the whole row
-    if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true, true); else MPB_PRE_LAUNCH(true, false, true); }
-    else     { if (long_rows) MPB_PRE_LAUNCH(false, true, true); else MPB_PRE_LAUNCH(false, false, true); }
-#undef MPB_PRE_LAUNCH
+    const uint32_t cpr = (uint32_t)(stride >> 4);
+    const uint32_t magic = cpr == 1 ? 0u : (uint32_t)(((1ull << 32) + cpr - 1) / cpr);    // ceil(2^32 / cpr); 0 stands for cpr == 1
+    if (len) hipLaunchKernelGGL((k_classify_linear<true, true>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist, dec, magic);
+    else     hipLaunchKernelGGL((k_classify_linear<false, true>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist, dec, magic);
 }
 
 void mpb_launch_encode(const uint8_t *q, int64_t n, int64_t stride, int32_t offset, uint8_t *seq, uint8_t *qual, hipStream_t s)
