@@ -156,6 +156,11 @@ typedef struct mio_collapse mio_collapse;
 mio_collapse *mio_collapse_create(void);
 void mio_collapse_destroy(mio_collapse *c);
 int64_t mio_collapse_count(const mio_collapse *c);          /* distinct sequences so far */
+/* Threads mio_collapse_add may use (default 1; at most 64).  The groups live in 64 shards picked by the sequence's
+ * hash, each filled by one thread with its reads in file order; the Python-2 dict ORDER -- the one sequential thing --
+ * is rebuilt at export time from the order in which the distinct sequences first appeared.  Results do not depend on
+ * the thread count. */
+int32_t mio_collapse_set_threads(mio_collapse *c, int32_t threads);
 
 /* Add records 0..n-1 of a chunk in file order.  ee double[n] (after +Ns / floor), flags uint8[n] from
  * mio_pack (may be NULL), max_len as in mio_pack, aux int32[n][3] = overlap length, gaps, mismatches of

@@ -913,8 +913,8 @@ def _run_fast_fastq(args, backend, o, say, t0):
 
     processed = 0
     disc_err = disc_len = disc_ov = 0.0
-    groups = F.Collapse() if args.collapse else None
     threads = _text_threads(args)                        # --processors: packing / formatting calls in flight
+    groups = F.Collapse(threads) if args.collapse else None
     pool = None
     if threads > 1:
         from concurrent.futures import ThreadPoolExecutor
@@ -1000,17 +1000,36 @@ def _run_fast_fastq(args, backend, o, say, t0):
             # header.lstrip('>') on the names line of three kinds of bad groups, and of every group with
             # --only_contig (moira.py:880,894,907,943)
             strip = (label == 0) | (label == 3) | ((label == 2) & bool(args.maxerrors)) | ((label < 0) & only)
+            jobs = []
             for sel, main_f, qual_f, names_f, lab in ((np.nonzero(label < 0)[0], o.contig, o.qual, o.names, None),
                                                       (np.nonzero(label >= 0)[0], o.bad_contig, o.bad_qual, o.bad_names, label)):
                 if not len(sel):
                     continue
                 kw = dict(labels=labels if lab is not None else None, label_id=lab[sel] if lab is not None else None, **hdr)
-                jobs = [(F.FMT_FASTQ, main_f, kw)] if fq else [(F.FMT_FASTA, main_f, kw), (F.FMT_QUAL, qual_f, kw)]
+                jobs += [(sel, F.FMT_FASTQ, main_f, kw)] if fq else [(sel, F.FMT_FASTA, main_f, kw), (sel, F.FMT_QUAL, qual_f, kw)]
                 if names:
-                    jobs.append((F.FMT_NAMES, names_f, dict(lstrip_gt=strip[sel], **hdr)))
-                for kind, f, k in jobs:
-                    for piece in F.collapse_format_parallel(pool, threads, groups, sel, kind, **k):
-                        f.write(piece)
+                    jobs.append((sel, F.FMT_NAMES, names_f, dict(lstrip_gt=strip[sel], **hdr)))
+
+            def write_file(sel, kind, f, k, tag):
+                for piece in F.collapse_format_parallel(pool, threads, groups, sel, kind, scratch="cf%d_" % tag, **k):
+                    f.write(piece)
+            if threads > 1 and len(jobs) > 1:
+                # every output file on its own thread: formatting goes to the pool, and writes to different files
+                # do not wait for each other
+                lanes_end = [_InOrder() for _ in jobs]
+                for tag, (ln, (sel, kind, f, k)) in enumerate(zip(lanes_end, jobs)):
+                    ln.submit(lambda sel=sel, kind=kind, f=f, k=k, tag=tag: write_file(sel, kind, f, k, tag))
+                errs = []
+                for ln in lanes_end:
+                    try:
+                        ln.close()
+                    except BaseException as e:      # noqa: B902 -- every lane is joined before anything is raised
+                        errs.append(e)
+                if errs:
+                    raise errs[0]
+            else:
+                for tag, (sel, kind, f, k) in enumerate(jobs):
+                    write_file(sel, kind, f, k, tag)
     finally:
         if not ok:
             emit.close(raise_errors=False)         # an exception is already on its way

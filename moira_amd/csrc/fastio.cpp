@@ -74,6 +74,55 @@ struct Out {
 
 // ---- collapse of identical sequences (ref: moira/moira.py:459-475, :490-493) --------------------
 
+// CPython 2.7's dict as far as iteration order goes (PyDict_MINSIZE 8; insertdict_clean into the first empty slot of the
+// probe sequence; dictresize to 4 x used, 2 x above 50000 used, when the table is 2/3 full; no deletions)
+struct Py2DictOrder {
+    struct Slot { uint64_t hash; int64_t id; };              // id < 0: empty
+    std::vector<Slot> slots;
+    uint64_t mask = 7, used = 0;
+    Py2DictOrder() : slots(8, Slot{0, -1}) {}
+    void place(uint64_t h, int64_t id)
+    {
+        uint64_t i = h & mask, perturb = h;
+        for (;;) {
+            Slot &sl = slots[i & mask];
+            if (sl.id < 0) { sl.hash = h; sl.id = id; return; }
+            i = (i << 2) + i + perturb + 1;
+            perturb >>= 5;
+        }
+    }
+    void insert_new(uint64_t h, int64_t id)
+    {
+        place(h, id);
+        used++;
+        if (used * 3 < (mask + 1) * 2) return;
+        const uint64_t minused = (used > 50000 ? 2 : 4) * used;      // dictresize(): 4 x used, 2 x above 50000
+        uint64_t newsize = 8;
+        while (newsize <= minused) newsize <<= 1;
+        std::vector<Slot> old;
+        old.swap(slots);
+        slots.assign(newsize, Slot{0, -1});
+        mask = newsize - 1;
+        // re-inserted in old slot order; the target line of the entry 16 slots ahead is requested now (a table of
+        // millions of keys is one cache miss per placement otherwise -- and a run re-places every key about 4 times)
+        const size_t no = old.size();
+        for (size_t k = 0; k < no; k++) {
+            if (k + 16 < no && old[k + 16].id >= 0) __builtin_prefetch(&slots[old[k + 16].hash & mask], 1);
+            if (old[k].id >= 0) place(old[k].hash, old[k].id);
+        }
+    }
+    void prefetch(uint64_t h) const { __builtin_prefetch(&slots[h & mask], 1); }
+};
+
+// The reference's `uniques` is ONE Python-2 dict, and its iteration order (the slot order of CPython 2.7's open
+// addressing, which depends on the hashes, the insertion order of the distinct keys and the resize history) decides the
+// output order of groups of equal abundance.  Only that ORDER is sequential; the work per read -- hash the sequence, find
+// its group, compare, copy a new sequence, link the header -- is not.  So the groups live in 64 shards picked by hash,
+// each a plain table with its own storage that one thread fills (reads in file order, so "first seen wins ties" and the
+// order of names_info are kept shard by shard), and every group remembers the global number of the read that created
+// it; after the shards of a chunk are filled, the chunk's NEW keys are replayed in that order into a simulated
+// CPython-2.7 dict (insertdict / dictresize: ~0.1 us per new key -- the one sequential step, and it runs on the writer
+// thread while the next chunks are read, packed and filtered); mio_collapse_export reads the slot order off it.
 struct mio_collapse {
     struct Uniq {
         int64_t seq_off, qual_off;       // arena offsets; the rep's qualities are re-pointed on a better rep
@@ -83,79 +132,78 @@ struct mio_collapse {
         int32_t aux[3];                  // overlap_length, gaps, mismatches of the representative
         int64_t size;                    // len(names_info)
         int64_t front, back_head, back_tail;   // names: front-inserted (newest first), then first seen + appended
+        uint64_t hash;                   // CPython-2.7 hash(str) of the sequence
+        int64_t first_seen;              // global number of the read that created the group
     };
     struct Name { int64_t off; int32_t len; int64_t next; };
-    struct Slot { uint64_t hash; int64_t uid; };             // uid < 0: empty
-    // append-only byte store in 64 MiB blocks (no reallocation copies; an item never straddles blocks)
-    static constexpr int ARENA_SHIFT = 26;
-    std::vector<std::unique_ptr<char[]>> blocks;
-    int64_t block_used = 0;
-    std::vector<Uniq> uniq;
-    std::vector<Name> names;
-    std::vector<Slot> slots;                                 // CPython 2.7 dict layout: PyDict_MINSIZE 8
-    uint64_t mask = 7;
-    std::vector<int64_t> order;                              // output order, built by mio_collapse_export
-    mio_collapse() : slots(8, Slot{0, -1}) {}
+    struct Shard {
+        // append-only byte store in 1 MiB blocks (no reallocation copies; an item never straddles blocks)
+        static constexpr int ARENA_SHIFT = 20;
+        std::vector<std::unique_ptr<char[]>> blocks;
+        int64_t block_used = 0;
+        std::vector<Uniq> uniq;
+        std::vector<Name> names;
+        std::vector<int64_t> tab;        // open addressing, linear probing: uid or -1 (order irrelevant here)
+        uint64_t tmask = 0;
 
-    char *reserve(int64_t n, int64_t *off)
-    {
-        const int64_t cap = (int64_t)1 << ARENA_SHIFT;
-        if (n > cap) throw std::bad_alloc();
-        if (blocks.empty() || block_used + n > cap) {
-            blocks.emplace_back(new char[(size_t)cap]);
-            block_used = 0;
-        }
-        *off = ((int64_t)(blocks.size() - 1) << ARENA_SHIFT) | block_used;
-        char *p = blocks.back().get() + block_used;
-        block_used += n;
-        return p;
-    }
-    int64_t put(const char *p, int64_t n)
-    {
-        int64_t off;
-        memcpy(reserve(n, &off), p, (size_t)n);
-        return off;
-    }
-    const char *at(int64_t off) const { return blocks[(size_t)(off >> ARENA_SHIFT)].get() + (off & (((int64_t)1 << ARENA_SHIFT) - 1)); }
-    // lookdict / insertdict_clean of CPython 2.7 (no deletions): first empty slot of the probe sequence
-    int64_t *find(uint64_t h, const char *key, int64_t len, Slot **where)
-    {
-        uint64_t i = h & mask, perturb = h;
-        for (;;) {
-            Slot &sl = slots[i & mask];
-            if (sl.uid < 0) { *where = &sl; return nullptr; }
-            if (sl.hash == h) {
-                const Uniq &u = uniq[sl.uid];
-                if (u.len == len && memcmp(at(u.seq_off), key, (size_t)len) == 0) return &sl.uid;
+        char *reserve(int64_t n, int64_t *off)
+        {
+            const int64_t cap = (int64_t)1 << ARENA_SHIFT;
+            if (n > cap) throw std::bad_alloc();
+            if (blocks.empty() || block_used + n > cap) {
+                blocks.emplace_back(new char[(size_t)cap]);
+                block_used = 0;
             }
-            i = (i << 2) + i + perturb + 1;
-            perturb >>= 5;
+            *off = ((int64_t)(blocks.size() - 1) << ARENA_SHIFT) | block_used;
+            char *p = blocks.back().get() + block_used;
+            block_used += n;
+            return p;
         }
-    }
-    void place(uint64_t h, int64_t uid)
-    {
-        uint64_t i = h & mask, perturb = h;
-        for (;;) {
-            Slot &sl = slots[i & mask];
-            if (sl.uid < 0) { sl.hash = h; sl.uid = uid; return; }
-            i = (i << 2) + i + perturb + 1;
-            perturb >>= 5;
+        int64_t put(const char *p, int64_t n)
+        {
+            int64_t off;
+            memcpy(reserve(n, &off), p, (size_t)n);
+            return off;
         }
-    }
-    void maybe_resize()
-    {
-        const uint64_t used = uniq.size();
-        if (used * 3 < (mask + 1) * 2) return;
-        const uint64_t minused = (used > 50000 ? 2 : 4) * used;      // dictresize(): 4 x used, 2 x above 50000
-        uint64_t newsize = 8;
-        while (newsize <= minused) newsize <<= 1;
-        std::vector<Slot> old;
-        old.swap(slots);
-        slots.assign(newsize, Slot{0, -1});
-        mask = newsize - 1;
-        for (const Slot &e : old)                                     // re-inserted in old slot order
-            if (e.uid >= 0) place(e.hash, e.uid);
-    }
+        const char *at(int64_t off) const { return blocks[(size_t)(off >> ARENA_SHIFT)].get() + (off & (((int64_t)1 << ARENA_SHIFT) - 1)); }
+        void grow()
+        {
+            const uint64_t size = tab.empty() ? 1024 : (tmask + 1) * 2;
+            std::vector<int64_t> nt(size, -1);
+            for (int64_t uid = 0; uid < (int64_t)uniq.size(); uid++) {
+                uint64_t i = (uniq[(size_t)uid].hash * 0x9E3779B97F4A7C15ull >> 20) & (size - 1);
+                while (nt[i] >= 0) i = (i + 1) & (size - 1);
+                nt[i] = uid;
+            }
+            tab.swap(nt);
+            tmask = size - 1;
+        }
+        // uid of the group whose sequence is key[0, len), or -1 with *slot = where it would go
+        int64_t find(uint64_t h, const char *key, int64_t len, uint64_t *slot)
+        {
+            if (tab.empty() || (uniq.size() + 1) * 2 > tmask + 1) grow();
+            uint64_t i = (h * 0x9E3779B97F4A7C15ull >> 20) & tmask;
+            for (;; i = (i + 1) & tmask) {
+                const int64_t uid = tab[i];
+                if (uid < 0) { *slot = i; return -1; }
+                const Uniq &u = uniq[(size_t)uid];
+                if (u.hash == h && u.len == len && memcmp(at(u.seq_off), key, (size_t)len) == 0) return uid;
+            }
+        }
+    };
+    static constexpr int NSHARD = 64;
+    static int shard_of(uint64_t h) { return (int)((h * 0x9E3779B97F4A7C15ull) >> 58); }
+    Shard shard[NSHARD];
+    int threads = 1;
+    int64_t reads_seen = 0;
+    Py2DictOrder dict;                   // ids = positions in `created`
+    struct Ref { int64_t local; uint8_t sid; };
+    std::vector<Ref> created;            // the groups in the order the reference's dict met their keys
+    // output order, built by mio_collapse_export: group k is shard[g_shard[k]].uniq[g_local[k]]
+    std::vector<uint8_t> g_shard;
+    std::vector<int64_t> g_local;
+    bool exported = false;
+    int64_t count() const { int64_t n = 0; for (const auto &sh : shard) n += (int64_t)sh.uniq.size(); return n; }
 };
 
 namespace {
@@ -665,24 +713,31 @@ int64_t mio_format_report(const char *buf, const int64_t *idx, const int64_t *se
 
 mio_collapse *mio_collapse_create(void) { return new (std::nothrow) mio_collapse(); }
 void mio_collapse_destroy(mio_collapse *c) { delete c; }
-int64_t mio_collapse_count(const mio_collapse *c) { return c ? (int64_t)c->uniq.size() : 0; }
+int64_t mio_collapse_count(const mio_collapse *c) { return c ? c->count() : 0; }
+int32_t mio_collapse_set_threads(mio_collapse *c, int32_t threads)
+{
+    if (!c) return fail(MIO_E_INVALID, "mio_collapse_set_threads: bad arguments");
+    c->threads = threads < 1 ? 1 : (threads > mio_collapse::NSHARD ? mio_collapse::NSHARD : threads);
+    return MIO_OK;
+}
 
 int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, int64_t n, int32_t max_len,
                          const double *ee, const uint8_t *flags, const int32_t *aux)
 {
     if (!c || !buf || !idx || n < 0 || (n > 0 && !ee)) return fail(MIO_E_INVALID, "mio_collapse_add: bad arguments");
-    try {
-        c->order.clear();
-        // the string hash is one dependent multiply-xor per byte: four records' chains run interleaved
-        std::vector<uint64_t> hashes((size_t)n);
-        auto seq_of = [&](int64_t k, int64_t *L) {
-            const int64_t *r = idx + k * MIO_IDX_COLS;
-            *L = r[MIO_SEQ_LEN];
-            if (max_len > 0 && *L > max_len) *L = max_len;
-            return (const unsigned char *)buf + r[MIO_SEQ_OFF];
-        };
-        int64_t k4 = 0;
-        for (; k4 + 4 <= n; k4 += 4) {
+    c->exported = false;
+    std::vector<uint64_t> hashes;
+    try { hashes.resize((size_t)n); } catch (const std::bad_alloc &) { return fail(MIO_E_INVALID, "out of memory while collapsing"); }
+    auto seq_of = [&](int64_t k, int64_t *L) {
+        const int64_t *r = idx + k * MIO_IDX_COLS;
+        *L = r[MIO_SEQ_LEN];
+        if (max_len > 0 && *L > max_len) *L = max_len;
+        return (const unsigned char *)buf + r[MIO_SEQ_OFF];
+    };
+    // the string hash is one dependent multiply-xor per byte: four records' chains run interleaved
+    auto hash_range = [&](int64_t lo, int64_t hi) {
+        int64_t k4 = lo;
+        for (; k4 + 4 <= hi; k4 += 4) {
             const unsigned char *p[4];
             int64_t len4[4], common = INT64_MAX;
             for (int j = 0; j < 4; j++) { p[j] = seq_of(k4 + j, &len4[j]); common = len4[j] < common ? len4[j] : common; }
@@ -699,46 +754,93 @@ int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, i
                 hashes[(size_t)(k4 + j)] = x[j] == ~0ull ? ~0ull - 1 : x[j];
             }
         }
-        for (; k4 < n; k4++) { int64_t L; const unsigned char *q = seq_of(k4, &L); hashes[(size_t)k4] = py2_hash(q, L); }
-        for (int64_t k = 0; k < n; k++) {
-            const int64_t *r = idx + k * MIO_IDX_COLS;
-            int64_t L = r[MIO_SEQ_LEN];
-            if (max_len > 0 && L > max_len) L = max_len;
-            const char *seq = buf + r[MIO_SEQ_OFF];
-            const int64_t hl = r[MIO_HDR_LEN];
-            int64_t hoff;
-            char *hw = c->reserve(hl, &hoff);
-            const char *hs = buf + r[MIO_HDR_OFF];
-            for (int64_t i = 0; i < hl; i++) hw[i] = hs[i] == ':' ? '_' : hs[i];      // moira.py:1175
-            const int64_t name_id = (int64_t)c->names.size();
-            c->names.push_back({hoff, (int32_t)hl, -1});
-            const uint64_t h = hashes[(size_t)k];
-            mio_collapse::Slot *where = nullptr;
-            int64_t *hit = c->find(h, seq, L, &where);
-            if (!hit) {                                                             // moira.py:461-464
-                mio_collapse::Uniq u;
-                u.seq_off = c->put(seq, L);
-                u.qual_off = c->put(buf + r[MIO_QUAL_OFF], L);
-                u.len = (int32_t)L; u.flags = flags ? flags[k] : 0; u.ee = ee[k]; u.size = 1;
-                for (int a = 0; a < 3; a++) u.aux[a] = aux ? aux[3 * k + a] : 0;
-                u.front = -1; u.back_head = u.back_tail = name_id;
-                where->hash = h; where->uid = (int64_t)c->uniq.size();
-                c->uniq.push_back(u);
-                c->maybe_resize();
-            } else {
-                mio_collapse::Uniq &u = c->uniq[*hit];
-                u.size++;
-                if (ee[k] < u.ee) {                                                 // moira.py:466-471: strict <
-                    u.ee = ee[k];
+        for (; k4 < hi; k4++) { int64_t L; const unsigned char *q = seq_of(k4, &L); hashes[(size_t)k4] = py2_hash(q, L); }
+    };
+    const int T = n < 8192 ? 1 : c->threads;
+    std::vector<int> oom((size_t)T, 0);
+    const int64_t base = c->reads_seen;
+    // reads of the shards s with s % T == t, in file order (moira.py:461-475)
+    auto fill = [&](int t) {
+        try {
+            for (int64_t k = 0; k < n; k++) {
+                const uint64_t h = hashes[(size_t)k];
+                const int sid = mio_collapse::shard_of(h);
+                if (sid % T != t) continue;
+                mio_collapse::Shard &S = c->shard[sid];
+                const int64_t *r = idx + k * MIO_IDX_COLS;
+                int64_t L = r[MIO_SEQ_LEN];
+                if (max_len > 0 && L > max_len) L = max_len;
+                const char *seq = buf + r[MIO_SEQ_OFF];
+                const int64_t hl = r[MIO_HDR_LEN];
+                int64_t hoff;
+                char *hw = S.reserve(hl, &hoff);
+                const char *hs = buf + r[MIO_HDR_OFF];
+                for (int64_t i = 0; i < hl; i++) hw[i] = hs[i] == ':' ? '_' : hs[i];      // moira.py:1175
+                const int64_t name_id = (int64_t)S.names.size();
+                S.names.push_back({hoff, (int32_t)hl, -1});
+                uint64_t slot = 0;
+                const int64_t hit = S.find(h, seq, L, &slot);
+                if (hit < 0) {                                                          // moira.py:461-464
+                    mio_collapse::Uniq u;
+                    u.seq_off = S.put(seq, L);
+                    u.qual_off = S.put(buf + r[MIO_QUAL_OFF], L);
+                    u.len = (int32_t)L; u.flags = flags ? flags[k] : 0; u.ee = ee[k]; u.size = 1;
                     for (int a = 0; a < 3; a++) u.aux[a] = aux ? aux[3 * k + a] : 0;
-                    u.qual_off = c->put(buf + r[MIO_QUAL_OFF], L);
-                    c->names[name_id].next = u.front;                               // names_info.insert(0, header)
-                    u.front = name_id;
-                } else {                                                            // names_info.append(header)
-                    c->names[u.back_tail].next = name_id;
-                    u.back_tail = name_id;
+                    u.front = -1; u.back_head = u.back_tail = name_id;
+                    u.hash = h; u.first_seen = base + k;
+                    S.tab[slot] = (int64_t)S.uniq.size();
+                    S.uniq.push_back(u);
+                } else {
+                    mio_collapse::Uniq &u = S.uniq[(size_t)hit];
+                    u.size++;
+                    if (ee[k] < u.ee) {                                                 // moira.py:466-471: strict <
+                        u.ee = ee[k];
+                        for (int a = 0; a < 3; a++) u.aux[a] = aux ? aux[3 * k + a] : 0;
+                        u.qual_off = S.put(buf + r[MIO_QUAL_OFF], L);
+                        S.names[(size_t)name_id].next = u.front;                        // names_info.insert(0, header)
+                        u.front = name_id;
+                    } else {                                                            // names_info.append(header)
+                        S.names[(size_t)u.back_tail].next = name_id;
+                        u.back_tail = name_id;
+                    }
                 }
             }
+        } catch (const std::bad_alloc &) {
+            oom[(size_t)t] = 1;
+        }
+    };
+    auto run = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        int started = 1;
+        try {
+            th.reserve((size_t)T);
+            for (int t = 1; t < T; t++) { th.emplace_back(fn, t); started = t + 1; }
+        } catch (...) {}
+        fn(0);
+        for (int t = started; t < T; t++) fn(t);
+        for (auto &x : th) x.join();
+    };
+    int64_t before[mio_collapse::NSHARD];
+    for (int sid = 0; sid < mio_collapse::NSHARD; sid++) before[sid] = (int64_t)c->shard[sid].uniq.size();
+    run([&](int t) { hash_range(n / T * t, t == T - 1 ? n : n / T * (t + 1)); });
+    run(fill);
+    c->reads_seen += n;
+    for (int t = 0; t < T; t++)
+        if (oom[(size_t)t]) return fail(MIO_E_INVALID, "out of memory while collapsing");
+    // the keys this chunk created, in the order the reads came: into the simulated Python-2 dict
+    try {
+        struct Key { int64_t first_seen; int64_t local; uint8_t sid; };
+        std::vector<Key> fresh;
+        for (int sid = 0; sid < mio_collapse::NSHARD; sid++)
+            for (int64_t u = before[sid]; u < (int64_t)c->shard[sid].uniq.size(); u++)
+                fresh.push_back({c->shard[sid].uniq[(size_t)u].first_seen, u, (uint8_t)sid});
+        std::sort(fresh.begin(), fresh.end(), [](const Key &a, const Key &b) { return a.first_seen < b.first_seen; });
+        std::vector<uint64_t> hs(fresh.size());
+        for (size_t k = 0; k < fresh.size(); k++) hs[k] = c->shard[fresh[k].sid].uniq[(size_t)fresh[k].local].hash;
+        for (size_t k = 0; k < fresh.size(); k++) {
+            if (k + 12 < fresh.size()) c->dict.prefetch(hs[k + 12]);
+            c->dict.insert_new(hs[k], (int64_t)c->created.size());
+            c->created.push_back({fresh[k].local, fresh[k].sid});
         }
     } catch (const std::bad_alloc &) {
         return fail(MIO_E_INVALID, "out of memory while collapsing");
@@ -749,19 +851,48 @@ int32_t mio_collapse_add(mio_collapse *c, const char *buf, const int64_t *idx, i
 int32_t mio_collapse_export(mio_collapse *c, double *ee, int64_t *len, int64_t *size, uint8_t *flags, int32_t *aux)
 {
     if (!c) return fail(MIO_E_INVALID, "mio_collapse_export: bad arguments");
-    // sorted(uniques, key=abundance, reverse=True): stable, on dict iteration (= slot) order  moira.py:492
-    c->order.clear();
-    for (const auto &sl : c->slots)
-        if (sl.uid >= 0) c->order.push_back(sl.uid);
-    std::stable_sort(c->order.begin(), c->order.end(),
-                     [c](int64_t a, int64_t b) { return c->uniq[a].size > c->uniq[b].size; });
-    for (size_t k = 0; k < c->order.size(); k++) {
-        const auto &u = c->uniq[c->order[k]];
-        if (ee) ee[k] = u.ee;
-        if (len) len[k] = u.len;
-        if (size) size[k] = u.size;
-        if (flags) flags[k] = u.flags;
-        if (aux) for (int a = 0; a < 3; a++) aux[3 * k + a] = u.aux[a];
+    try {
+        auto group = [&](int64_t g) -> const mio_collapse::Uniq & {
+            const auto &r = c->created[(size_t)g];
+            return c->shard[r.sid].uniq[(size_t)r.local];
+        };
+        // sorted(uniques, key=abundance, reverse=True): stable, on dict iteration (= slot) order  moira.py:492
+        std::vector<int64_t> order;
+        order.reserve(c->created.size());
+        for (const auto &sl : c->dict.slots)
+            if (sl.id >= 0) order.push_back(sl.id);
+        std::vector<int64_t> sizes(order.size());
+        int64_t top = 0;
+        for (size_t k = 0; k < order.size(); k++) { sizes[k] = group(order[k]).size; top = sizes[k] > top ? sizes[k] : top; }
+        std::vector<int64_t> sorted(order.size());
+        if (top <= (int64_t)(4 * order.size() + 1024)) {
+            // a counting sort by abundance, descending, stable: most groups of a real run are small
+            std::vector<int64_t> start((size_t)top + 2, 0);
+            for (size_t k = 0; k < order.size(); k++) start[(size_t)(top - sizes[k]) + 1]++;
+            for (size_t v = 1; v < start.size(); v++) start[v] += start[v - 1];
+            for (size_t k = 0; k < order.size(); k++) sorted[(size_t)start[(size_t)(top - sizes[k])]++] = order[k];
+        } else {
+            std::vector<size_t> pos(order.size());
+            for (size_t k = 0; k < pos.size(); k++) pos[k] = k;
+            std::stable_sort(pos.begin(), pos.end(), [&](size_t a, size_t b) { return sizes[a] > sizes[b]; });
+            for (size_t k = 0; k < pos.size(); k++) sorted[k] = order[pos[k]];
+        }
+        c->g_shard.resize(sorted.size());
+        c->g_local.resize(sorted.size());
+        for (size_t k = 0; k < sorted.size(); k++) {
+            const auto &r = c->created[(size_t)sorted[k]];
+            c->g_shard[k] = r.sid;
+            c->g_local[k] = r.local;
+            const auto &u = group(sorted[k]);
+            if (ee) ee[k] = u.ee;
+            if (len) len[k] = u.len;
+            if (size) size[k] = u.size;
+            if (flags) flags[k] = u.flags;
+            if (aux) for (int a = 0; a < 3; a++) aux[3 * k + a] = u.aux[a];
+        }
+        c->exported = true;
+    } catch (const std::bad_alloc &) {
+        return fail(MIO_E_INVALID, "out of memory while ordering the groups");
     }
     return MIO_OK;
 }
@@ -774,22 +905,23 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
     if (!c || nsel < 0 || (nsel > 0 && !sel) || kind < MIO_FMT_FASTA || kind > MIO_FMT_REPORT || cap < 0 ||
         (cap > 0 && !out) || (label_id && !labels))
         return fail(MIO_E_INVALID, "mio_collapse_format: bad arguments");
-    if (c->order.size() != c->uniq.size()) return fail(MIO_E_INVALID, "call mio_collapse_export first");
+    if (!c->exported) return fail(MIO_E_INVALID, "call mio_collapse_export first");
     Out o{out, cap, 0};
     const int64_t relabel_len = relabel ? (int64_t)strlen(relabel) : 0;
     char num[96];
     std::vector<char> hdr;
     for (int64_t k = 0; k < nsel; k++) {
-        if (sel[k] < 0 || sel[k] >= (int64_t)c->order.size()) return fail(MIO_E_INVALID, "selection out of range");
-        const auto &u = c->uniq[c->order[sel[k]]];
-        const auto &rep = c->names[u.front >= 0 ? u.front : u.back_head];           // names_info[0] == rep_header
+        if (sel[k] < 0 || sel[k] >= (int64_t)c->g_local.size()) return fail(MIO_E_INVALID, "selection out of range");
+        const mio_collapse::Shard &S = c->shard[c->g_shard[(size_t)sel[k]]];
+        const auto &u = S.uniq[(size_t)c->g_local[(size_t)sel[k]]];
+        const auto &rep = S.names[(size_t)(u.front >= 0 ? u.front : u.back_head)];  // names_info[0] == rep_header
         hdr.clear();
         if (relabel) {                                                              // moira.py:854-855, index from 1
             hdr.insert(hdr.end(), relabel, relabel + relabel_len);
             const int m = snprintf(num, sizeof(num), "%lld", (long long)(sel[k] + 1));
             hdr.insert(hdr.end(), num, num + m);
         } else {
-            hdr.insert(hdr.end(), c->at(rep.off), c->at(rep.off) + rep.len);
+            hdr.insert(hdr.end(), S.at(rep.off), S.at(rep.off) + rep.len);
         }
         if (usearch) {                                                              // moira.py:858-863
             const int m = snprintf(num, sizeof(num), ";ee=%.2f;size=%lld;", u.ee, (long long)u.size);
@@ -808,10 +940,10 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
             o.ch('\t');
             bool first = true;
             for (int pass = 0; pass < 2; pass++)
-                for (int64_t id = pass == 0 ? u.front : u.back_head; id >= 0; id = c->names[id].next) {
+                for (int64_t id = pass == 0 ? u.front : u.back_head; id >= 0; id = S.names[(size_t)id].next) {
                     if (!first) o.ch(',');
                     first = false;
-                    o.put(c->at(c->names[id].off), c->names[id].len);
+                    o.put(S.at(S.names[(size_t)id].off), S.names[(size_t)id].len);
                 }
             o.ch('\n');
             continue;
@@ -824,9 +956,9 @@ int64_t mio_collapse_format(const mio_collapse *c, const int64_t *sel, int64_t n
             o.put(lab, (int64_t)strlen(lab));
         }
         o.ch('\n');
-        if (kind != MIO_FMT_QUAL) { o.put(c->at(u.seq_off), u.len); o.ch('\n'); }
-        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); put_qual_string(o, (const unsigned char *)c->at(u.qual_off), u.len, fastq_offset, out_offset, clamp_q0 ? 1 : 0); o.ch('\n'); }
-        if (kind == MIO_FMT_QUAL) { put_quals(o, (const unsigned char *)c->at(u.qual_off), u.len, fastq_offset, clamp_q0 ? 1 : 0); o.ch('\n'); }
+        if (kind != MIO_FMT_QUAL) { o.put(S.at(u.seq_off), u.len); o.ch('\n'); }
+        if (kind == MIO_FMT_FASTQ) { o.ch('+'); o.ch('\n'); put_qual_string(o, (const unsigned char *)S.at(u.qual_off), u.len, fastq_offset, out_offset, clamp_q0 ? 1 : 0); o.ch('\n'); }
+        if (kind == MIO_FMT_QUAL) { put_quals(o, (const unsigned char *)S.at(u.qual_off), u.len, fastq_offset, clamp_q0 ? 1 : 0); o.ch('\n'); }
     }
     if (needed) *needed = o.n;
     if (o.n > cap) return fail(MIO_E_SPACE, "output needs %lld bytes", (long long)o.n);

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "mio_collapse_create": (C.c_void_p, []),
     "mio_collapse_destroy": (None, [C.c_void_p]),
     "mio_collapse_count": (C.c_int64, [C.c_void_p]),
+    "mio_collapse_set_threads": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mio_collapse_add": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "mio_collapse_export": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -272,11 +273,12 @@ class Collapse:
     """The reference's `uniques` dict (moira/moira.py:459-475) kept in C: add chunks, export the groups
     in output order, format them."""
 
-    def __init__(self):
+    def __init__(self, threads=1):
         self.lib = load()
         self.h = self.lib.mio_collapse_create()
         if not self.h:
             raise MemoryError("mio_collapse_create failed")
+        self.lib.mio_collapse_set_threads(self.h, int(threads))
 
     def close(self):
         if self.h:
@@ -341,14 +343,15 @@ class Collapse:
         return memoryview(out)[:w]
 
 
-def collapse_format_parallel(pool, threads, groups, sel, kind, label_id=None, lstrip_gt=None, **kw):
-    """Collapse.format() with the selection split over `threads` calls (the object is only read)."""
+def collapse_format_parallel(pool, threads, groups, sel, kind, label_id=None, lstrip_gt=None, scratch="format", **kw):
+    """Collapse.format() with the selection split over `threads` calls (the object is only read).  `scratch` names the
+    work buffers: callers that format several files side by side pass different names."""
     n = len(sel)
     if pool is None or threads <= 1 or n < PARALLEL_MIN:
-        return [groups.format(sel, kind, label_id=label_id, lstrip_gt=lstrip_gt, **kw)]
+        return [groups.format(sel, kind, label_id=label_id, lstrip_gt=lstrip_gt, scratch=scratch, **kw)]
     cut = lambda a, lo, hi: None if a is None else a[lo:hi]
     jobs = [pool.submit(groups.format, sel[a:b], kind, label_id=cut(label_id, a, b), lstrip_gt=cut(lstrip_gt, a, b),
-                        scratch="format%d" % t, **kw) for t, (a, b) in enumerate(_parts(n, threads))]
+                        scratch="%s%d" % (scratch, t), **kw) for t, (a, b) in enumerate(_parts(n, threads))]
     return [j.result() for j in jobs]
 
 

@@ -600,3 +600,49 @@ def test_plain_file_reader_with_threads_equals_the_stream_reader(tmp_path):
     want = records(1, 1 << 20)
     assert len(want) == 60000 and want[-1][0] == "read59999"
     assert records(4, 1 << 20) == want
+
+
+def test_sharded_collapse_is_the_python2_dict(tmp_path):
+    """The collapse keeps its groups in 64 shards filled by several threads and rebuilds the Python-2 dict ORDER at
+    export time from the order in which the distinct sequences first appeared (moira/moira.py:459-475, :492).  40,000
+    reads with heavy duplication, ties in the expected errors and in the abundances: (1) one thread and eight threads
+    give identical exports and identical formatted files; (2) the group order equals what moira_amd/py2dict.py (the
+    Python restatement of CPython 2.7's dict) yields for the same insertion sequence, sorted by abundance."""
+    from moira_amd.py2dict import Py2Dict
+    rng = np.random.default_rng(21)
+    pool = ["".join(rng.choice(list("ACGT"), int(rng.integers(20, 60)))) for _ in range(9000)]
+    n = 40000
+    pick = np.minimum((rng.random(n) ** 3 * len(pool)).astype(int), len(pool) - 1)      # a few very abundant, many singletons
+    recs = []
+    for i in range(n):
+        sq = pool[pick[i]]
+        recs.append("@r:%d\n%s\n+\n%s\n" % (i, sq, "".join(chr(33 + int(v)) for v in rng.integers(2, 41, len(sq)))))
+    buf = "".join(recs).encode()
+    idx, consumed, err = F.index(buf, True, n)
+    assert len(idx) == n and err is None
+    ee = np.round(rng.random(n) * 3, 1)                                              # one decimal: plenty of ties
+    flags = (rng.random(n) < 0.05).astype(np.uint8)
+    outs = []
+    for threads in (1, 8):
+        g = F.Collapse(threads)
+        for lo in range(0, n, 15000):                                               # three chunks: 15000 > the 8192 threshold
+            g.add(buf, idx[lo:lo + 15000], ee[lo:lo + 15000], flags[lo:lo + 15000])
+        gee, glen, gsize, gfl, gaux = g.export()
+        sel = np.arange(len(gee))
+        files = [bytes(g.format(sel, kind)) for kind in (F.FMT_FASTA, F.FMT_QUAL, F.FMT_NAMES, F.FMT_FASTQ)]
+        outs.append((gee.tobytes(), glen.tobytes(), gsize.tobytes(), gfl.tobytes(), files))
+        if threads == 1:
+            seqs_in_order = [l for l in files[0].decode().split("\n")[1::2]]
+            sizes = gsize.copy()
+        g.close()
+    assert outs[0] == outs[1]
+    d = Py2Dict()
+    count = {}
+    for i in range(n):
+        sq = pool[pick[i]]
+        if sq not in d:
+            d[sq] = True
+        count[sq] = count.get(sq, 0) + 1
+    want = sorted(list(d), key=lambda k: count[k], reverse=True)                    # stable, on dict order: moira.py:492
+    assert seqs_in_order == want
+    assert [count[k] for k in want] == sizes.tolist()
