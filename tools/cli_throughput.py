@@ -41,7 +41,12 @@ def write_fastq(pth, prefix, bases, quals):
 bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (n, 250))]
 bases[q[:, :250] == 0] = ord("N")
 write_fastq(path, "r", bases, (np.maximum(q[:, :250], 1) + 33).astype(np.uint8))
-del bases
+# the same reads drawn from a pool of n / 40 distinct sequences: what an amplicon run looks like to the collapse step
+dup_path = os.path.join(tmp, "synth_dup.fastq")
+pool_n = max(n // 40, 1)
+pick = np.minimum((rng.random(n) ** 2 * pool_n).astype(np.int64), pool_n - 1)
+write_fastq(dup_path, "r", bases[:pool_n][pick], (np.maximum(q[:, :250], 1) + 33).astype(np.uint8))
+del bases, pick
 
 
 def run(label, extra, env=None):
@@ -49,7 +54,7 @@ def run(label, extra, env=None):
     if env:
         os.environ.update(env)
     try:
-        out = os.path.join(tmp, "out_" + label.replace(" ", "_"))
+        out = os.path.join(tmp, "out_" + "".join(ch if ch.isalnum() else "_" for ch in label))
         args = cli.parse_arguments(["-ffq", path, "-op", out, "--silent"] + extra)
         t = time.perf_counter()
         rc = cli.main(args, out=open(os.devnull, "w"))
@@ -90,7 +95,12 @@ run("fastq in, fastq out, no collapse, -p 1", ["-c", "false", "-o", "fastq"])
 run("fastq in, fastq out, no collapse, -p " + P, ["-c", "false", "-o", "fastq", "-p", P])
 run("fastq in, fasta+qual out, no collapse, -p 1", ["-c", "false"])
 run("fastq in, fasta+qual out, no collapse, -p " + P, ["-c", "false", "-p", P])
-run("fastq in, fasta+qual out, collapse, -p " + P, ["-c", "true", "-p", P])
+run("fastq in, fasta+qual out, collapse (every read distinct: worst case), -p " + P, ["-c", "true", "-p", P])
+_keep = path
+path = dup_path
+run("fastq in, fasta+qual out, collapse (reads drawn from n/40 distinct sequences), -p " + P, ["-c", "true", "-p", P])
+run("fastq in, fasta+qual out, collapse (reads drawn from n/40 distinct sequences), -p 1", ["-c", "true"])
+path = _keep
 if n <= 1_000_000:
     run("line parser: fasta+qual out, no collapse", ["-c", "false"], {"MOIRA_NO_FASTIO": "1"})
 
