@@ -18,6 +18,9 @@ void mpb_launch_dp(const uint8_t *, int64_t, int64_t, const int32_t *, const Mpb
 void mpb_launch_overflow(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, const int32_t *, double *, uint8_t *, hipStream_t) STUB
 void mpb_launch_lambda(const uint8_t *, int64_t, int64_t, const int32_t *, int32_t, const double2 *, double *, int32_t *, int32_t *, hipStream_t) STUB
 void mpb_launch_decode(const uint8_t *, const uint8_t *, int64_t, int64_t, const int32_t *, int32_t, int32_t, uint8_t *, int32_t *, hipStream_t) STUB
+void mpb_launch_wide(const uint8_t *, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, const int32_t *, double *, uint8_t *, hipStream_t) STUB
+void mpb_launch_decode_classify(const uint8_t *, const uint8_t *, int32_t, uint8_t *, int32_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int32_t *, double *, uint8_t *, hipStream_t) STUB
+void mpb_launch_encode(const uint8_t *, int64_t, int64_t, int32_t, uint8_t *, uint8_t *, hipStream_t) STUB
 void mpb_launch_count(const uint8_t *, int64_t, const MpbWorkspace &, hipStream_t) STUB
 void mpb_launch_synth(uint8_t *, int64_t, int64_t, int32_t, int32_t, int32_t, int32_t *, uint64_t, int64_t, hipStream_t) STUB
 CPP
