@@ -249,7 +249,7 @@ class Collectives:
             return
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
         self.totals_backend = "gloo"
-        if use_gpu and try_rccl:
+        if try_rccl:
             ok = self._try_rccl(local_rank)
             vote = torch.tensor([1 if ok else 0], dtype=torch.int32)
             dist.all_reduce(vote, op=dist.ReduceOp.MIN)             # every rank, unconditionally
@@ -259,6 +259,9 @@ class Collectives:
                 if ok:
                     self.rccl_error = "another rank's RCCL communicator did not come up"
                 self._rccl = None
+                # some rank's communicator is half-made: tearing the groups down could wait for it, AFTER the line is
+                # out -- every rank leaves through os._exit once the closing barrier has been passed
+                self._hung = True
 
     def _try_rccl(self, local_rank):
         """Create the RCCL group and run one 24-byte all-reduce on it, in a helper thread with a deadline: an exception
@@ -427,6 +430,7 @@ def main():
                          "all-reduce on it (under the same deadline as an N > 1 run); reported as `rccl_selftest`")
     ap.add_argument("--_rank-delay-ms", type=float, default=0.0, help=argparse.SUPPRESS)    # tests: rank r's stub step takes 1 + r*this ms
     ap.add_argument("--_die-rank", type=int, default=-1, help=argparse.SUPPRESS)             # tests: this rank dies before the timed region
+    ap.add_argument("--_try-rccl", action="store_true", help=argparse.SUPPRESS)              # tests: attempt RCCL even in a rehearsal (where it must fail) -> the fallback
     args = ap.parse_args()
     rehearsal = args.rehearse_on_one_gpu or args.rehearse_on_cpu
 
@@ -450,7 +454,8 @@ def main():
             raise SystemExit("rank %d wants GPU %d but only %d GPU(s) are visible (--gpus %d needs %d)"
                              % (rank, local_rank, have, args.gpus, args.gpus))
         torch.cuda.set_device(local_rank)
-    coll = Collectives(world, rank, local_rank, use_gpu, try_rccl=not (rehearsal or args.no_rccl),
+    coll = Collectives(world, rank, local_rank, use_gpu,
+                       try_rccl=(use_gpu and not rehearsal and not args.no_rccl) or args._try_rccl,
                        selftest=args.rccl_selftest and world == 1 and use_gpu)
 
     L = args.length
@@ -518,7 +523,9 @@ def main():
                               "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": "f64", "data": "none (CPU rehearsal of the launch / collective code: the step is a stub)",
                               "config": {"workload": "REHEARSAL ON CPU -- not a measurement", "reads_per_gpu": n,
-                                         "world_size": world, "collective_backend": "gloo (rehearsal)"},
+                                         "world_size": world,
+                                         "collective_backend": "gloo (rehearsal)" if not args._try_rccl else
+                                         "gloo (RCCL not used: %s)" % coll.rccl_error},
                               "t_step_rank_uniform_s": t_step, "timed_region_s": dt, "reads_per_s_per_rank": per_rank,
                               "devices": devices, "outcome": {"pass": n_pass, "fail": n_fail, "overflow_reruns": n_ovf}}))
         coll.close()
@@ -644,7 +651,7 @@ def main():
                        "parallelism": "host-side split, %d rank(s), no data-path collective" % world,
                        "collective_backend": (None if world == 1 else
                                               {"nccl": "RCCL (24-byte totals); gloo (barriers, step count, max over ranks)",
-                                               "gloo": "gloo%s" % (" (rehearsal)" if rehearsal else
+                                               "gloo": "gloo%s" % (" (rehearsal)" if rehearsal and not args._try_rccl else
                                                                    " (RCCL not used: %s)" % (coll.rccl_error or "--no-rccl"))}[coll.totals_backend]),
                        "world_size": world,
                        "mode": "fast_fma (NOT bit-exact)" if args.fast_fma else "bit-exact (no FMA)"},

@@ -133,3 +133,15 @@ def test_a_dead_rank_fails_the_job_promptly():
     assert p.returncode != 0
     assert took < 150, took
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_rccl_failure_falls_back_to_gloo_in_the_same_process():
+    """if the RCCL communicator does not come up the ranks must carry the 24-byte totals over gloo IN THE
+    SAME PROCESS and still print the line.  Without a GPU the attempt fails on every rank (no device to put the
+    communicator on): three ranks, the vote, the fallback, the totals, the exit without tearing down a half-made group."""
+    p, took = _run_bench(["--gpus", "3", "--rehearse-on-cpu", "--steps", "3", "--warmup", "1", "--reads", "1000", "--_try-rccl"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["outcome"]["pass"] + line["outcome"]["fail"] == 3000
+    assert "RCCL not used" in line["config"]["collective_backend"]
+    assert took < 120
