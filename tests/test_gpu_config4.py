@@ -113,6 +113,25 @@ def test_bench_rccl_selftest_on_this_gpu():
     assert line["n_gpus"] == 1 and line["value"] > 0
 
 
+def test_bench_rccl_failure_falls_back_to_gloo_on_hardware():
+    """The failure an N > 1 run has to survive, provoked on real hardware: two ranks that share this box's one GPU try to
+    build an RCCL communicator ("Duplicate GPU detected"); the ranks vote, carry the 24-byte totals over gloo in the same
+    process, print the line and leave with rc 0 (VERDICT r2 #2: never re-exec a process that has touched the GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--_try-rccl",
+                        "--reads", "300000", "--steps", "3", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert "RCCL not used" in line["config"]["collective_backend"]
+    assert line["outcome"]["pass"] + line["outcome"]["fail"] == 600000 and line["n_gpus"] == 2
+
+
 def test_bench_four_rank_rehearsal_on_one_gpu():
     """VERDICT r2 #2: the widest rehearsal a 1-GPU box allows (the pool admits 6 processes on a card: four ranks, this
     test process and one spare), 2 M reads per rank: port selection, the build lock under four simultaneous imports,
