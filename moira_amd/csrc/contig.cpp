@@ -161,44 +161,67 @@ void nw_diagonal(const int16_t *__restrict d2, const int16_t *__restrict d1, int
     }
 }
 
-// The same diagonal, 32 cells per instruction, for CPUs with AVX-512BW/VL (the GPU boxes' EPYC 9575F has full-width
-// AVX-512); picked once per process.  Same integer operations in the same order as the loop above: wrapping 16-bit
-// adds, max, and the tie-break encoded as  left > max(diag, up) ? LEFT : (diag >= up ? DIAG : UP).
-__attribute__((target("avx512f,avx512bw,avx512vl")))
-void nw_diagonal_avx512(const int16_t *__restrict d2, const int16_t *__restrict d1, int16_t *__restrict cur,
-                        uint8_t *__restrict ptr, const char *__restrict a, const char *__restrict b,
-                        int ilo, int ihi, int16_t match, int16_t mismatch, int16_t gap)
+// On CPUs with AVX-512BW/VL (the GPU boxes' EPYC 9575F has full-width AVX-512) the same diagonal runs 32 cells per
+// instruction (nw_fill_avx512 below; picked once per process): the same integer operations in the same order -- wrapping
+// 16-bit adds, max, and the tie-break encoded as  left > max(diag, up) ? LEFT : (diag >= up ? DIAG : UP).
+// The whole fill, diagonal by diagonal, in one function per instruction set: a 2 x 250-base pair has 500 diagonals of
+// 125 cells on average, so a call through a pointer per diagonal (re-broadcasting the three scores each time) cost as
+// much as the cells themselves.  base[d] as in nw_align_diag; s2r = seq_2 reversed.
+typedef void (*nw_fill_fn)(int16_t *S, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
+                           int16_t match, int16_t mismatch, int16_t gap);
+
+void nw_fill_generic(int16_t *S, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
+                     int16_t match, int16_t mismatch, int16_t gap)
 {
-    const __m512i vmatch = _mm512_set1_epi16(match), vmis = _mm512_set1_epi16(mismatch), vgap = _mm512_set1_epi16(gap);
-    const __m512i one = _mm512_set1_epi16(PTR_UP), two = _mm512_set1_epi16(PTR_LEFT);
-    for (int i = ilo; i <= ihi; i += 32) {
-        const int rem = ihi - i + 1;
-        const __mmask32 k = rem >= 32 ? (__mmask32)0xffffffffu : (__mmask32)((1u << rem) - 1u);
-        const __m256i av = _mm256_maskz_loadu_epi8(k, a + i), bv = _mm256_maskz_loadu_epi8(k, b + i);
-        const __mmask32 eq = _mm256_cmpeq_epi8_mask(av, bv);
-        const __m512i dg = _mm512_add_epi16(_mm512_maskz_loadu_epi16(k, d2 + i - 1), _mm512_mask_blend_epi16(eq, vmis, vmatch));
-        const __m512i up = _mm512_add_epi16(_mm512_maskz_loadu_epi16(k, d1 + i - 1), vgap);
-        const __m512i lf = _mm512_add_epi16(_mm512_maskz_loadu_epi16(k, d1 + i), vgap);
-        const __m512i mx = _mm512_max_epi16(dg, up);
-        const __mmask32 left = _mm512_cmpgt_epi16_mask(lf, mx);
-        const __mmask32 diag = _mm512_cmpge_epi16_mask(dg, up);
-        _mm512_mask_storeu_epi16(cur + i, k, _mm512_max_epi16(lf, mx));
-        __m512i p = _mm512_mask_blend_epi16(diag, one, _mm512_setzero_si512());      // DIAG = 0 where diag >= up, else UP
-        p = _mm512_mask_blend_epi16(left, p, two);
-        _mm256_mask_storeu_epi8(ptr + i, k, _mm512_cvtepi16_epi8(p));
+    const int D = n1 + n2;
+    for (int d = 2; d <= D; d++) {
+        const int ilo = d - n2 > 1 ? d - n2 : 1, ihi = d - 1 < n1 ? d - 1 : n1;
+        if (ilo > ihi) continue;
+        // b[i] = s2[(d - i) - 1] = s2r[n2 - d + i]
+        nw_diagonal(S + base[d - 2], S + base[d - 1], S + base[d], P + base[d], A, s2r + (n2 - d), ilo, ihi, match, mismatch, gap);
     }
 }
 
-typedef void (*nw_diag_fn)(const int16_t *, const int16_t *, int16_t *, uint8_t *, const char *, const char *, int, int,
-                           int16_t, int16_t, int16_t);
-
-nw_diag_fn pick_diagonal()
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+void nw_fill_avx512(int16_t *S, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
+                    int16_t match, int16_t mismatch, int16_t gap)
 {
-    if (getenv("MOIRA_CONTIG_NO_AVX512")) return nw_diagonal;
+    const __m512i vmatch = _mm512_set1_epi16(match), vmis = _mm512_set1_epi16(mismatch), vgap = _mm512_set1_epi16(gap);
+    const __m512i one = _mm512_set1_epi16(PTR_UP), two = _mm512_set1_epi16(PTR_LEFT), zero = _mm512_setzero_si512();
+    const int D = n1 + n2;
+    for (int d = 2; d <= D; d++) {
+        const int ilo = d - n2 > 1 ? d - n2 : 1, ihi = d - 1 < n1 ? d - 1 : n1;
+        if (ilo > ihi) continue;
+        const int16_t *d2 = S + base[d - 2], *d1 = S + base[d - 1];
+        int16_t *cur = S + base[d];
+        uint8_t *ptr = P + base[d];
+        const char *b = s2r + (n2 - d);
+        for (int i = ilo; i <= ihi; i += 32) {
+            const int rem = ihi - i + 1;
+            const __mmask32 k = rem >= 32 ? (__mmask32)0xffffffffu : (__mmask32)((1u << rem) - 1u);
+            const __m256i av = _mm256_maskz_loadu_epi8(k, A + i), bv = _mm256_maskz_loadu_epi8(k, b + i);
+            const __mmask32 eq = _mm256_cmpeq_epi8_mask(av, bv);
+            const __m512i dg = _mm512_add_epi16(_mm512_maskz_loadu_epi16(k, d2 + i - 1), _mm512_mask_blend_epi16(eq, vmis, vmatch));
+            const __m512i up = _mm512_add_epi16(_mm512_maskz_loadu_epi16(k, d1 + i - 1), vgap);
+            const __m512i lf = _mm512_add_epi16(_mm512_maskz_loadu_epi16(k, d1 + i), vgap);
+            const __m512i mx = _mm512_max_epi16(dg, up);
+            const __mmask32 left = _mm512_cmpgt_epi16_mask(lf, mx);
+            const __mmask32 diag = _mm512_cmpge_epi16_mask(dg, up);
+            _mm512_mask_storeu_epi16(cur + i, k, _mm512_max_epi16(lf, mx));
+            __m512i p = _mm512_mask_blend_epi16(diag, one, zero);        // DIAG = 0 where diag >= up, else UP
+            p = _mm512_mask_blend_epi16(left, p, two);
+            _mm256_mask_storeu_epi8(ptr + i, k, _mm512_cvtepi16_epi8(p));
+        }
+    }
+}
+
+nw_fill_fn pick_fill()
+{
+    if (getenv("MOIRA_CONTIG_NO_AVX512")) return nw_fill_generic;
     __builtin_cpu_init();
     if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl"))
-        return nw_diagonal_avx512;
-    return nw_diagonal;
+        return nw_fill_avx512;
+    return nw_fill_generic;
 }
 
 struct DiagScratch {
@@ -231,14 +254,8 @@ int nw_align_diag(const char *s1, int n1, const char *s2, int n2, int match, int
     sc.s2r.resize((size_t)n2 + 1);
     for (int t = 0; t < n2; t++) sc.s2r[t] = s2[n2 - 1 - t];
     const char *A = s1 - 1;                              // A[i] = s1[i - 1]
-    static const nw_diag_fn diagonal = pick_diagonal();
-    for (int d = 2; d <= D; d++) {
-        const int ilo = d - n2 > 1 ? d - n2 : 1, ihi = d - 1 < n1 ? d - 1 : n1;
-        if (ilo > ihi) continue;
-        // b[i] = s2[(d - i) - 1] = s2r[n2 - d + i]
-        diagonal(S + sc.base[d - 2], S + sc.base[d - 1], S + sc.base[d], P + sc.base[d], A,
-                    sc.s2r.data() + (n2 - d), ilo, ihi, (int16_t)match, (int16_t)mismatch, (int16_t)gap);
-    }
+    static const nw_fill_fn fill = pick_fill();
+    fill(S, P, sc.base.data(), A, sc.s2r.data(), n1, n2, (int16_t)match, (int16_t)mismatch, (int16_t)gap);
     auto at = [&](int i, int j) { return sc.base[i + j] + i; };
     // 3' overlap fix-up (:155-201): last maximum (>=) of the last column and of the last row
     int best_col_score = -10000, best_col_idx = 0;
