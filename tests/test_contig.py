@@ -171,3 +171,35 @@ def test_make_contig_against_reference_fixture():
                              int(c["caps"][mi]), bool(c["trims"][mi]))
         want = (contigs[r], [int(v) for v in c["cq"][c["cqoff"][r]:c["cqoff"][r + 1]]]) + tuple(int(v) for v in c["stats"][r])
         assert got == want, (r, k, mi)
+
+
+@pytest.mark.parametrize("isa", ["generic", "avx2", "avx512"])
+def test_every_instruction_set_path_reproduces_the_reference_alignments(isa):
+    """The fill of the score matrix exists once per instruction set (plain loop, AVX2: 16 cells per instruction, AVX-512:
+    32; picked once per process, MOIRA_CONTIG_ISA forces one).  Each path, in a process of its own, must reproduce the
+    reference's Cython alignments of tests/golden/nw_pairs.npz -- strings and scores -- exactly.  A path the CPU lacks
+    falls back to the best it has (still compared)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path[:0] = [%r, %r]
+import numpy as np, golden_io as G
+from moira_amd import contig as CT
+z = G.load_set("nw_pairs")
+params = z["params"]
+bad = 0
+n = len(z["score"])
+for k in range(0, n, 2):
+    s1 = bytes(z["seq1"][z["off1"][k]:z["off1"][k + 1]]).decode(); s2 = bytes(z["seq2"][z["off2"][k]:z["off2"][k + 1]]).decode()
+    m, mm, g = (int(v) for v in params[z["param"][k]])
+    a1, a2, sc = CT.nw_align(s1, s2, m, mm, g)
+    want1 = bytes(z["aln1"][z["aoff1"][k]:z["aoff1"][k + 1]]).decode(); want2 = bytes(z["aln2"][z["aoff2"][k]:z["aoff2"][k + 1]]).decode()
+    bad += (a1, a2, sc) != (want1, want2, int(z["score"][k]))
+print("checked", (n + 1) // 2, "bad", bad)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOIRA_CONTIG_ISA=isa)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().endswith("bad 0") and "checked 2404" in out.stdout, out.stdout
