@@ -734,7 +734,8 @@ def _fast_chunks(args):
     from . import contig as CT
     ffh, rfh = open_input_binary(args.forward_fastq), open_input_binary(args.reverse_fastq)
     try:
-        for fbuf, fidx, rbuf, ridx in F.PairedFastqChunks(ffh, rfh, PAIR_CHUNK_READS, threads=_text_threads(args)):
+        # reading + indexing the two files runs one chunk ahead of contig construction, on a thread of its own
+        for fbuf, fidx, rbuf, ridx in _prefetched(iter(F.PairedFastqChunks(ffh, rfh, PAIR_CHUNK_READS, threads=_text_threads(args))), depth=1):
             # forward_header != reverse_header (moira.py:1197-1198); ':' -> '_' on both sides cannot change equality
             bad = F.first_header_mismatch(fbuf, fidx, rbuf, ridx)
             n = len(fidx) if bad < 0 else bad
