@@ -625,12 +625,64 @@ def write_results(index, header, sequence, quals, expected_errors, names_info, o
     return bad(label, nh, (1, 0, 0))
 
 
+class _BlockCompressedWriter:
+    """A .gz / .bz2 output written as a sequence of independently compressed blocks (gzip members / bzip2 streams -- both
+    formats define the concatenation of valid files as a valid file, and gzip / bz2 / zcat / bzcat read it as one), so
+    that the blocks of a write are compressed on several threads (zlib and bz2 release the GIL).  One compressor thread
+    per file is what bounds a run with compressed output otherwise: ~80 MB/s of text per file at gzip level 4."""
+    BLOCK = 4 << 20
+    _pool = None
+
+    @classmethod
+    def pool(cls):
+        if cls._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            from .contig import usable_cpus
+            cls._pool = ThreadPoolExecutor(max(2, min(usable_cpus(), 32)))
+        return cls._pool
+
+    def __init__(self, path, kind):
+        self.f = open(path, "wb")
+        self.kind = kind
+        self.pending = bytearray()
+
+    def _pack(self, block):
+        if self.kind == "gz":
+            return gzip.compress(block, compresslevel=4)        # same content, ~4x the speed of level 9
+        return bz2.compress(block)
+
+    def _flush(self, everything):
+        while len(self.pending) >= self.BLOCK or (everything and self.pending):
+            take = min(len(self.pending), 16 * self.BLOCK)
+            if not everything:
+                take = take // self.BLOCK * self.BLOCK
+            chunk = bytes(self.pending[:take])
+            del self.pending[:take]
+            parts = [chunk[a:a + self.BLOCK] for a in range(0, len(chunk), self.BLOCK)]
+            for packed in self.pool().map(self._pack, parts):   # in order
+                self.f.write(packed)
+
+    def write(self, data):
+        self.pending += data
+        if len(self.pending) >= self.BLOCK:
+            self._flush(False)
+        return len(data)
+
+    def close(self):
+        if self.f is not None:
+            if not self.pending and self.f.tell() == 0:
+                self.f.write(self._pack(b""))                   # an empty file is still a valid archive
+            self._flush(True)
+            self.f.close()
+            self.f = None
+
+
 def _open_outputs(args, output_name, binary=False):
     mode = "wb" if binary else "wt"
     if args.output_compression == "gz":
-        opener, suffix = (lambda p: gzip.open(p, mode, compresslevel=4)), ".gz"    # same content, ~4x the speed of level 9
+        opener, suffix = (lambda p: _BlockCompressedWriter(p, "gz") if binary else gzip.open(p, mode, compresslevel=4)), ".gz"
     elif args.output_compression == "bz2":
-        opener, suffix = (lambda p: bz2.open(p, mode)), ".bz2"
+        opener, suffix = (lambda p: _BlockCompressedWriter(p, "bz2") if binary else bz2.open(p, mode)), ".bz2"
     else:
         opener, suffix = (lambda p: open(p, mode[:2] if binary else "w")), ""
     o = Outputs()

@@ -646,3 +646,28 @@ def test_sharded_collapse_is_the_python2_dict(tmp_path):
     want = sorted(list(d), key=lambda k: count[k], reverse=True)                    # stable, on dict order: moira.py:492
     assert seqs_in_order == want
     assert [count[k] for k in want] == sizes.tolist()
+
+
+@pytest.mark.parametrize("kind", ["gz", "bz2"])
+def test_block_compressed_outputs_hold_the_same_text(tmp_path, oracle, monkeypatch, kind):
+    """Compressed outputs of the byte-level path are written as independently compressed blocks (gzip members / bzip2
+    streams) so that several threads compress them; read back with the standard modules they must hold exactly the
+    text of an uncompressed run.  The block size is shrunk so that every file has many members."""
+    import bz2
+    from test_cli_golden import oracle_backend, reference_args
+    monkeypatch.setattr(cli._BlockCompressedWriter, "BLOCK", 700)
+    rng = np.random.default_rng(31)
+    fq = tmp_path / "r.fastq"
+    fq.write_text(make_fastq(rng, 900, quirks=False))
+    outs = {}
+    for comp in ("none", kind):
+        pre = str(tmp_path / ("o_" + comp))
+        a = reference_args(paired=False, forward_fastq=str(fq), output_prefix=pre, collapse=True, output_compression=comp,
+                           processors=4)
+        assert cli.main(a, backend=oracle_backend(oracle), out=open(os.devnull, "w")) == 0
+        opener = {"none": open, "gz": gzip.open, "bz2": bz2.open}[comp]
+        outs[comp] = {f.split(".", 1)[1].replace("." + kind, ""): opener(tmp_path / f, "rb").read()
+                      for f in sorted(os.listdir(tmp_path)) if f.startswith("o_" + comp + ".")}
+    assert outs["none"].keys() == outs[kind].keys() and len(outs["none"]) >= 6
+    assert outs["none"] == outs[kind]
+    assert sum(len(v) for v in outs["none"].values()) > 50_000          # many 700-byte members per file

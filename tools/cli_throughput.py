@@ -115,6 +115,21 @@ if n:
     if n <= 1_000_000:
         run("line parser: fasta+qual out, no collapse", ["-c", "false"], {"MOIRA_NO_FASTIO": "1"})
 n = n_keep
+if os.environ.get("CLI_GZ"):
+    # compressed output (block-parallel members) and compressed input (one inflating stream per file) on the first 2 M reads
+    import subprocess
+    m_gz = min(n, 2_000_000)
+    small = os.path.join(tmp, "small.fastq")
+    rec_bytes = os.path.getsize(path) // n
+    with open(path, "rb") as f, open(small, "wb") as g:
+        g.write(f.read(rec_bytes * m_gz))
+    _keep, _n, path, n = path, n, small, m_gz
+    run("fastq in, fastq.gz out, no collapse, -p " + P, ["-c", "false", "-o", "fastq", "-oc", "gz", "-p", P])
+    run("fastq in, fastq.gz out, no collapse, -p 1", ["-c", "false", "-o", "fastq", "-oc", "gz"])
+    subprocess.check_call(["gzip", "-1", "-k", "-f", small])
+    path = small + ".gz"
+    run("fastq.gz in, fastq out, no collapse, -p " + P, ["-c", "false", "-o", "fastq", "-p", P])
+    path, n = _keep, _n
 
 m = min(n, int(os.environ.get("CLI_PAIRS", "200000")))
 r1, r2 = paired_files(m)
