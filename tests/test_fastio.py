@@ -656,6 +656,7 @@ def test_block_compressed_outputs_hold_the_same_text(tmp_path, oracle, monkeypat
     import bz2
     from test_cli_golden import oracle_backend, reference_args
     monkeypatch.setattr(cli._BlockCompressedWriter, "BLOCK", 700)
+    monkeypatch.setattr(cli._BlockCompressedWriter, "WINDOW", 3)
     rng = np.random.default_rng(31)
     fq = tmp_path / "r.fastq"
     fq.write_text(make_fastq(rng, 900, quirks=False))
