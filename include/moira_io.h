@@ -72,6 +72,25 @@ int64_t mio_fastq_index_mt(const char *buf, int64_t len, int32_t final, int64_t 
  * (short only at the end of the file) or a negative MIO_E_*. */
 int64_t mio_pread_mt(int32_t fd, int64_t offset, char *dst, int64_t len, int32_t threads);
 
+/* ---- gzip input (ref: moira/moira.py:1058-1090 reads it through Python's gzip module) ----------------------------------
+ * A DEFLATE stream cannot be cut across threads, so the stream decoder itself is what bounds a run on compressed input:
+ * this one (csrc/inflate.cpp, written from RFC 1951 / 1952) is resumable at any byte of input and output.
+ *   in[0, in_len)   the next compressed bytes; in[in_len, in_len + 8) must be READABLE (any content: it is never used as data)
+ *   final           != 0: the input ends with this call
+ *   out             out[0, hist) holds the last `hist` (<= 32768 is enough) bytes of the output produced so far (what
+ *                   matches may reach back into); new output is written to out[hist, out_cap)
+ * Returns 0: every complete symbol of the input has been decoded -- call again with the unconsumed tail
+ *            in[*in_used, in_len) followed by more data;  1: the output is full (call again with a new output buffer and
+ *            the unconsumed input);  2: the gzip file (all members; zero padding ignored) ended cleanly;  < 0: corrupt or
+ *            truncated input, mio_inflate_error() says what (CRC-32 and length of every member are checked). */
+typedef struct mio_inflate mio_inflate;
+mio_inflate *mio_inflate_create(void);
+void mio_inflate_destroy(mio_inflate *s);
+const char *mio_inflate_error(void);
+int32_t mio_inflate_gzip(mio_inflate *s, const uint8_t *in, int64_t in_len, int32_t final, uint8_t *out, int64_t hist,
+                         int64_t out_cap, int64_t *in_used, int64_t *out_used);
+uint32_t mio_crc32(uint32_t crc, const uint8_t *p, int64_t n);      /* CRC-32 of RFC 1952 (start with 0) */
+
 /*
  * Pack records sel[0..nsel) (rows of idx; sel == NULL: records 0..nsel-1) into an nsel x row_stride
  * uint8 matrix: Q = byte - fastq_offset, Q0 -> 1, 'N' -> 0, 'n' -> 255 (or an ordinary base when

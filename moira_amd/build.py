@@ -94,7 +94,8 @@ def build_contig(force=False, verbose=False):
 
 IO_LIB = os.path.join(HERE, "libmoira_io.so")
 IO_SRC = os.path.join(CSRC, "fastio.cpp")
-IO_DEPS = [IO_SRC, os.path.join(ROOT, "include", "moira_io.h")]
+IO_SRC2 = os.path.join(CSRC, "inflate.cpp")
+IO_DEPS = [IO_SRC, IO_SRC2, os.path.join(ROOT, "include", "moira_io.h")]
 IO_FLAGS = ["-O3", "-fPIC", "-shared", "-std=c++17", "-pthread", "-Wall"]
 
 
@@ -106,7 +107,7 @@ def build_io(force=False, verbose=False):
     """CPU-only text I/O library of the CLI (g++, no HIP): FASTQ indexing, packing, record formatting."""
     if not force and not io_stale():
         return IO_LIB
-    cmd = [CXX] + IO_FLAGS + [IO_SRC, "-o", IO_LIB]
+    cmd = [CXX] + IO_FLAGS + [IO_SRC, IO_SRC2, "-o", IO_LIB]
     return _locked_build(IO_LIB, IO_DEPS, IO_FLAGS, cmd, force, verbose)
 
 

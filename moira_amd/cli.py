@@ -310,14 +310,78 @@ def open_input(filename):
     return f
 
 
+class _ReadAhead:
+    """A compressed input read on a thread of its own: decompression (zlib / bz2 release the GIL) of the next blocks runs
+    while the current one is indexed, packed and filtered -- and, for paired input, the two files inflate side by side
+    instead of one after the other.  read(n) hands out the blocks as they come (at most n bytes, b"" at the end)."""
+
+    def __init__(self, fh, block=1 << 25, depth=3):
+        import queue
+        import threading
+        self.fh, self.block = fh, block
+        self.q = queue.Queue(maxsize=depth)
+        self.left = b""
+        self.done = False
+        self.stop = threading.Event()
+        self.t = threading.Thread(target=self._work, daemon=True)
+        self.t.start()
+
+    def _work(self):
+        import queue
+        item = None
+        try:
+            while not self.stop.is_set():
+                if item is None:
+                    data = self.fh.read(self.block)
+                    item = (data, None)
+                try:
+                    self.q.put(item, timeout=0.1)
+                except queue.Full:
+                    continue
+                if not item[0]:
+                    return
+                item = None
+        except BaseException as e:          # noqa: B902 -- re-raised by read()
+            while not self.stop.is_set():
+                try:
+                    self.q.put((b"", e), timeout=0.1)
+                    return
+                except queue.Full:
+                    continue
+
+    def read(self, n=-1):
+        if not self.left and not self.done:
+            data, err = self.q.get()
+            if err is not None:
+                self.done = True
+                raise err
+            if not data:
+                self.done = True
+            self.left = data
+        if n is None or n < 0 or n >= len(self.left):
+            out, self.left = self.left, b""
+        else:
+            out, self.left = self.left[:n], self.left[n:]
+        return out
+
+    def close(self):
+        self.stop.set()
+        self.t.join()
+        self.fh.close()
+
+
 def open_input_binary(filename):
     """Same sniffing, bytes out: the C parser (moira_amd/fastio.py) takes whole blocks."""
     with io.open(filename, "rb") as fh:
         start = fh.read(3)
     if start.startswith(b"\x42\x5a\x68"):
-        return bz2.open(filename, "rb")
+        return _ReadAhead(bz2.open(filename, "rb"))
     if start.startswith(b"\x1f\x8b\x08"):
-        return gzip.open(filename, "rb")
+        # libmoira_io's own inflate (csrc/inflate.cpp): about twice zlib's text rate, on a thread of its own
+        if os.environ.get("MOIRA_ZLIB_INPUT"):
+            return _ReadAhead(gzip.open(filename, "rb"))
+        from . import fastio as F
+        return _ReadAhead(F.GzipReader(io.open(filename, "rb", buffering=0)))
     return io.open(filename, "rb", buffering=0)
 
 

@@ -1,0 +1,168 @@
+"""libmoira_io's own gzip / DEFLATE decoder (csrc/inflate.cpp, written from RFC 1951 / 1952) against zlib: every
+compression level and strategy, stored / fixed / dynamic blocks, multi-member files, padding, chunk boundaries at every
+offset of input and output, truncated and corrupt input.  CPU only."""
+import gzip
+import io
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from moira_amd import fastio as F
+
+
+def fastq_text(rng, n):
+    out = []
+    for i in range(n):
+        L = int(rng.integers(30, 260))
+        out.append(b"@M0:%d:x%d\n" % (i % 7, i) + bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), L, p=[.245, .245, .245, .245, .02]))
+                   + b"\n+\n" + bytes((np.clip(38 - (np.arange(L) / L) ** 3 * rng.integers(4, 30) - rng.integers(0, 6, L), 2, 40) + 33).astype(np.uint8)) + b"\n")
+    return b"".join(out)
+
+
+def payloads():
+    rng = np.random.default_rng(5)
+    yield "fastq", fastq_text(rng, 4000)
+    yield "random", bytes(rng.integers(0, 256, 300_000, dtype=np.uint8))
+    yield "zeros", bytes(200_000)
+    yield "runs", b"".join(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 700)) for _ in range(2000))
+    yield "short_period", (b"abcde" * 50_000) + (b"xy" * 70_000) + (b"0123456" * 30_000)
+    yield "far_matches", b"".join([bytes(rng.integers(0, 256, 20_000, dtype=np.uint8))] * 12)        # distances ~20,000
+    yield "tiny", b"A"
+    yield "empty", b""
+    yield "text", (b"The quick brown fox jumps over the lazy dog. " * 3000)
+    yield "two_symbols", bytes(rng.integers(0, 2, 150_000, dtype=np.uint8))
+
+
+def compress_variants(data):
+    for level in range(0, 10):
+        yield "level%d" % level, gzip.compress(data, compresslevel=level)
+    for name, strat in (("filtered", zlib.Z_FILTERED), ("huffman_only", zlib.Z_HUFFMAN_ONLY), ("rle", zlib.Z_RLE), ("fixed", zlib.Z_FIXED)):
+        c = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strat)
+        yield name, c.compress(data) + c.flush()
+    c = zlib.compressobj(1, zlib.DEFLATED, 31, 1)                        # memLevel 1: many small blocks
+    yield "small_blocks", c.compress(data) + c.flush()
+    c = zlib.compressobj(6, zlib.DEFLATED, 31)                           # sync flushes: empty stored blocks in between
+    parts = [c.compress(data[a:a + 10_000]) + c.flush(zlib.Z_SYNC_FLUSH) for a in range(0, len(data), 10_000)]
+    yield "sync_flushes", b"".join(parts) + c.flush()
+
+
+def decode(comp, read_size=1 << 20, in_block=1 << 16):
+    r = F.GzipReader(io.BytesIO(comp), in_block=in_block)
+    out = []
+    while True:
+        b = r.read(read_size)
+        if not b:
+            break
+        out.append(b)
+    r.close()
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("name,data", list(payloads()), ids=[p[0] for p in payloads()])
+def test_every_level_and_strategy(name, data):
+    for vname, comp in compress_variants(data):
+        assert zlib.decompress(comp, 31) == data
+        got = decode(comp)
+        assert got == data, (name, vname, len(got), len(data))
+
+
+def test_chunk_boundaries_everywhere():
+    """Input handed over in pieces of 4096..4200 bytes and output taken 1, 7, 300 or 65,537 bytes at a time: the decoder is
+    stopped and resumed at (nearly) every phase and bit position."""
+    rng = np.random.default_rng(9)
+    data = fastq_text(rng, 600) + bytes(rng.integers(0, 256, 5000, dtype=np.uint8)) + b"z" * 9000
+    for level in (0, 1, 6, 9):
+        comp = gzip.compress(data, compresslevel=level)
+        for in_block in (4096, 4097, 4133, 4200):
+            for read_size in (1, 7, 300, 65_537):
+                if read_size == 1 and in_block != 4096:
+                    continue
+                assert decode(comp, read_size, in_block) == data, (level, in_block, read_size)
+
+
+def test_multi_member_and_padding():
+    rng = np.random.default_rng(10)
+    a, b, c = fastq_text(rng, 300), b"", bytes(rng.integers(0, 256, 70_000, dtype=np.uint8))
+    comp = gzip.compress(a, 9) + gzip.compress(b) + gzip.compress(c, 1) + bytes(37)
+    assert gzip.decompress(comp) == a + b + c
+    assert decode(comp) == a + b + c
+    assert decode(comp, read_size=11, in_block=4096) == a + b + c
+    # header fields: name, comment, extra, header CRC
+    buf = io.BytesIO()
+    with gzip.GzipFile(filename="reads.fastq", mode="wb", fileobj=buf, mtime=12345) as g:
+        g.write(a)
+    assert decode(buf.getvalue()) == a
+    raw = gzip.compress(a)
+    with_fields = raw[:3] + bytes([4 | 8 | 16 | 2]) + raw[4:10] + b"\x05\x00hello" + b"name\x00" + b"a comment\x00" + b"\x12\x34" + raw[10:]
+    assert decode(with_fields) == a
+
+
+def test_corrupt_and_truncated_input_is_an_error_not_garbage():
+    rng = np.random.default_rng(11)
+    data = fastq_text(rng, 200)
+    comp = gzip.compress(data, 6)
+    for cut in list(range(0, 40)) + list(range(len(comp) - 20, len(comp))) + [len(comp) // 2, len(comp) // 3]:
+        with pytest.raises(OSError):
+            decode(comp[:cut])
+    bad_crc = comp[:-8] + bytes([comp[-8] ^ 1]) + comp[-7:]
+    with pytest.raises(OSError, match="CRC"):
+        decode(bad_crc)
+    bad_len = comp[:-1] + bytes([comp[-1] ^ 0x40])
+    with pytest.raises(OSError, match="length"):
+        decode(bad_len)
+    with pytest.raises(OSError, match="not a gzip"):
+        decode(b"plain text, not gzip at all" * 10)
+    with pytest.raises(OSError):
+        decode(b"")
+    # flipped bits inside the stream: an error or a CRC failure, never a silent wrong result
+    silent = 0
+    for k in range(200):
+        pos = int(rng.integers(12, len(comp) - 9))
+        broken = comp[:pos] + bytes([comp[pos] ^ (1 << int(rng.integers(0, 8)))]) + comp[pos + 1:]
+        try:
+            out = decode(broken)
+            silent += out != data
+        except OSError:
+            pass
+    assert silent == 0
+
+
+def test_crc32_is_zlibs():
+    rng = np.random.default_rng(12)
+    L = F.load()
+    for n in (0, 1, 7, 8, 9, 63, 1000, 100_003):
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        assert L.mio_crc32(0, a.ctypes.data, n) == zlib.crc32(a.tobytes())
+    a = rng.integers(0, 256, 5000, dtype=np.uint8)
+    c = L.mio_crc32(0, a.ctypes.data, 1234)
+    assert L.mio_crc32(c, a.ctypes.data + 1234, 5000 - 1234) == zlib.crc32(a.tobytes())
+
+
+def test_large_file_and_rate(tmp_path):
+    """40 MB of FASTQ text through the reader exactly as the CLI uses it (32 MiB reads); also prints the rate against
+    Python's gzip module (informational)."""
+    import time
+    rng = np.random.default_rng(13)
+    block = fastq_text(rng, 20_000)
+    data = b"".join(block[i:] + block[:i] for i in (0, 1001, 20_003, 77_777, 123_457, 300_001, 424_243, 999_331))
+    path = tmp_path / "big.fastq.gz"
+    with gzip.open(path, "wb", compresslevel=6) as f:
+        f.write(data)
+    t = time.perf_counter()
+    with F.GzipReader(open(path, "rb")) as r:
+        got = []
+        while True:
+            b = r.read(1 << 25)
+            if not b:
+                break
+            got.append(b)
+    dt = time.perf_counter() - t
+    assert b"".join(got) == data
+    t = time.perf_counter()
+    with gzip.open(path, "rb") as f:
+        ref = f.read()
+    dz = time.perf_counter() - t
+    assert ref == data
+    print("\ninflate: %.0f MB/s (zlib through gzip.open: %.0f MB/s) on %d MB of FASTQ text" % (len(data) / dt / 1e6, len(data) / dz / 1e6, len(data) >> 20))

@@ -129,6 +129,9 @@ if os.environ.get("CLI_GZ"):
     subprocess.check_call(["gzip", "-1", "-k", "-f", small])
     path = small + ".gz"
     run("fastq.gz in, fastq out, no collapse, -p " + P, ["-c", "false", "-o", "fastq", "-p", P])
+    run("fastq.gz in through zlib (MOIRA_ZLIB_INPUT=1), fastq out, no collapse, -p " + P, ["-c", "false", "-o", "fastq", "-p", P],
+        {"MOIRA_ZLIB_INPUT": "1"})
+    os.environ.pop("MOIRA_ZLIB_INPUT", None)
     path, n = _keep, _n
 
 m = min(n, int(os.environ.get("CLI_PAIRS", "200000")))
