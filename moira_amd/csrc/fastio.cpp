@@ -266,7 +266,7 @@ void put_qual_string(Out &o, const unsigned char *ql, int64_t L, int32_t fastq_o
 
 extern "C" {
 
-const char *mio_version(void) { return "moira_io 0.1"; }
+const char *mio_version(void) { return "moira_io 0.3"; }
 const char *mio_last_error(void) { return g_err; }
 
 int64_t mio_fastq_index(const char *buf, int64_t len, int32_t final, int64_t max_records,

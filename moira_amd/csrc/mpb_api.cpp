@@ -18,7 +18,7 @@
 #include <thread>
 #include <vector>
 
-#define MPB_VERSION_STR "moira_pb 0.1.0 (gfx950)"
+#define MPB_VERSION_STR "moira_pb 0.3.0 (gfx950)"
 
 static thread_local char g_err[512] = "";
 
