@@ -91,6 +91,22 @@ int32_t mio_inflate_gzip(mio_inflate *s, const uint8_t *in, int64_t in_len, int3
                          int64_t out_cap, int64_t *in_used, int64_t *out_used);
 uint32_t mio_crc32(uint32_t crc, const uint8_t *p, int64_t n);      /* CRC-32 of RFC 1952 (start with 0) */
 
+/* BGZF (SAM/BAM specification section 4.1; what bgzip and Illumina's FASTQ writers produce, and what this package's own
+ * .gz outputs are): gzip members of at most 64 KiB that state their compressed size in a 'B','C' extra subfield, so
+ * their boundaries are known without decoding and the members inflate on several threads.
+ * mio_bgzf_scan walks in[0, in_len) from a member boundary and fills, for up to max_blocks COMPLETE BGZF members whose
+ * stated output sizes sum to at most max_out (the first one is always taken), offs[k] (start), sizes[k] (compressed
+ * size) and out_offs[k] (start of its output; out_offs[n] = total, so out_offs needs max_blocks + 1 entries).  Returns
+ * n; *why says what stopped it: 0 the next member is incomplete (more input needed), 1 the next member is not BGZF
+ * (hand the rest to mio_inflate_gzip), 2 a limit.
+ * mio_bgzf_inflate_mt decodes those members into out[out_offs[k], out_offs[k+1]) on `threads` threads with the CRC-32
+ * and length checks of mio_inflate_gzip; a member that decodes to anything but its stated size is an error.
+ * in[in_len, in_len + 8) must be readable, as for mio_inflate_gzip. */
+int64_t mio_bgzf_scan(const uint8_t *in, int64_t in_len, int64_t max_blocks, int64_t max_out, int64_t *offs, int32_t *sizes,
+                      int64_t *out_offs, int32_t *why);
+int32_t mio_bgzf_inflate_mt(const uint8_t *in, const int64_t *offs, const int32_t *sizes, const int64_t *out_offs, int64_t n,
+                            uint8_t *out, int32_t threads);
+
 /*
  * Pack records sel[0..nsel) (rows of idx; sel == NULL: records 0..nsel-1) into an nsel x row_stride
  * uint8 matrix: Q = byte - fastq_offset, Q0 -> 1, 'N' -> 0, 'n' -> 255 (or an ordinary base when

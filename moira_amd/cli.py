@@ -28,8 +28,10 @@ import gzip
 import io
 import math
 import os
+import struct
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -370,8 +372,10 @@ class _ReadAhead:
         self.fh.close()
 
 
-def open_input_binary(filename):
-    """Same sniffing, bytes out: the C parser (moira_amd/fastio.py) takes whole blocks."""
+def open_input_binary(filename, threads=1):
+    """Same sniffing, bytes out: the C parser (moira_amd/fastio.py) takes whole blocks.  `threads`: what a BGZF-blocked
+    gzip file (bgzip, Illumina's writers, this package's own .gz outputs) is inflated on; any other gzip file is one
+    stream on one thread."""
     with io.open(filename, "rb") as fh:
         start = fh.read(3)
     if start.startswith(b"\x42\x5a\x68"):
@@ -381,7 +385,7 @@ def open_input_binary(filename):
         if os.environ.get("MOIRA_ZLIB_INPUT"):
             return _ReadAhead(gzip.open(filename, "rb"))
         from . import fastio as F
-        return _ReadAhead(F.GzipReader(io.open(filename, "rb", buffering=0)))
+        return _ReadAhead(F.GzipReader(io.open(filename, "rb", buffering=0), threads=threads))
     return io.open(filename, "rb", buffering=0)
 
 
@@ -689,13 +693,37 @@ def write_results(index, header, sequence, quals, expected_errors, names_info, o
     return bad(label, nh, (1, 0, 0))
 
 
+BGZF_DATA = 0xff00            # text bytes per BGZF member: whatever deflate makes of it fits the 64 KiB the size field can state
+BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")     # the format's end marker: an empty member
+
+
+def bgzf_compress(data, level=4):
+    """`data` as BGZF members (SAM/BAM specification section 4.1): ordinary gzip members -- gzip, zcat and Python's gzip
+    read the file as usual -- of at most 64 KiB each that state their compressed size in a 'B','C' extra subfield, so a
+    reader that knows the convention (bgzip, htslib, this package's GzipReader) inflates them on several threads."""
+    mv = memoryview(data).cast("B")
+    out = []
+    for pos in range(0, len(mv), BGZF_DATA):
+        piece = mv[pos:pos + BGZF_DATA]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        z = c.compress(piece) + c.flush()
+        if len(z) + 26 > 65536:                       # cannot happen at this piece size (deflate's bound); stored if it did
+            c = zlib.compressobj(0, zlib.DEFLATED, -15)
+            z = c.compress(piece) + c.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(z) + 25))
+        out.append(z)
+        out.append(struct.pack("<II", zlib.crc32(piece), len(piece)))
+    return b"".join(out)
+
+
 class _BlockCompressedWriter:
     """A .gz / .bz2 output written as a sequence of independently compressed blocks (gzip members / bzip2 streams -- both
     formats define the concatenation of valid files as a valid file, and gzip / bz2 / zcat / bzcat read it as one), so
     that the blocks are compressed on several threads (zlib and bz2 release the GIL) while the caller goes on formatting:
     write() cuts its data into 1 MiB blocks, hands them to a pool and writes out, in order, whatever has finished; at
     most `WINDOW` blocks are in flight.  One compressor thread per file is what bounds a run with compressed output
-    otherwise: ~60 MB/s of text per file at gzip level 4."""
+    otherwise: ~60 MB/s of text per file at gzip level 4.  A .gz output is BGZF (bgzf_compress: each 1 MiB block becomes
+    17 members, the file ends with the format's end marker), so it can also be READ on several threads."""
     BLOCK = 1 << 20
     WINDOW = 64
     _pool = None
@@ -718,7 +746,7 @@ class _BlockCompressedWriter:
 
     def _pack(self, block):
         if self.kind == "gz":
-            return gzip.compress(block, compresslevel=4)        # same content, ~4x the speed of level 9
+            return bgzf_compress(block, 4)                      # level 4: same content, ~4x the speed of level 9
         return bz2.compress(block)
 
     def _drain(self, keep):
@@ -756,7 +784,9 @@ class _BlockCompressedWriter:
                 self._submit(self.carry)
                 self.carry = b""
             self._drain(0)
-            if not self.wrote:
+            if self.kind == "gz":
+                self.f.write(BGZF_EOF)                          # (also what makes an empty output a valid archive)
+            elif not self.wrote:
                 self.f.write(self._pack(b""))                   # an empty file is still a valid archive
             self.f.close()
             self.f = None
@@ -859,7 +889,7 @@ def _fast_chunks(args):
         yield from _fast_chunks_fasta_qual(args)
         return
     if not args.paired:
-        fh = open_input_binary(args.forward_fastq)
+        fh = open_input_binary(args.forward_fastq, _text_threads(args))
         try:
             for buf, idx in F.FastqChunks(fh, CHUNK_READS, threads=_text_threads(args)):
                 yield buf, idx, None
@@ -869,7 +899,8 @@ def _fast_chunks(args):
             fh.close()
         return
     from . import contig as CT
-    ffh, rfh = open_input_binary(args.forward_fastq), open_input_binary(args.reverse_fastq)
+    half = max(1, _text_threads(args) // 2)
+    ffh, rfh = open_input_binary(args.forward_fastq, half), open_input_binary(args.reverse_fastq, half)
     try:
         # reading + indexing the two files runs one chunk ahead of contig construction, on a thread of its own
         for fbuf, fidx, rbuf, ridx in _prefetched(iter(F.PairedFastqChunks(ffh, rfh, PAIR_CHUNK_READS, threads=_text_threads(args))), depth=1):
@@ -983,14 +1014,15 @@ def _fast_chunks_fasta_qual(args):
     """fasta + qual input: records rebuilt as header | sequence | quality bytes (offset 0) by
     mio_fasta_qual_index, so that the rest of the path is the FASTQ one."""
     from . import fastio as F
-    files = [open_input_binary(args.forward_fasta), open_input_binary(args.forward_qual)]
+    half = max(1, _text_threads(args) // 2)
+    files = [open_input_binary(args.forward_fasta, half), open_input_binary(args.forward_qual, half)]
     try:
         if not args.paired:
             for buf, idx in F.FastaQualChunks(files[0], files[1], CHUNK_READS):
                 yield buf, idx, None
             return
         from . import contig as CT
-        files += [open_input_binary(args.reverse_fasta), open_input_binary(args.reverse_qual)]
+        files += [open_input_binary(args.reverse_fasta, half), open_input_binary(args.reverse_qual, half)]
         fwd = iter(F.FastaQualChunks(files[0], files[1], PAIR_CHUNK_READS))
         rev = iter(F.FastaQualChunks(files[2], files[3], PAIR_CHUNK_READS))
         while True:

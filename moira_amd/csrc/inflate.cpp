@@ -15,8 +15,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <initializer_list>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 namespace {
 
@@ -560,6 +564,108 @@ out:
     *in_used = in.p - in_buf;
     *out_used = op - out_begin;
     return rc;
+}
+
+// ---- BGZF: gzip members that state their own compressed size ----------------------------------------------------------
+// The blocked gzip of the SAM/BAM specification (section 4.1), which bgzip and Illumina's FASTQ writers produce and which
+// this package's own compressed outputs use: every member is at most 64 KiB, starts with FLG = FEXTRA and carries a
+// 'B','C' subfield whose value is the member's total size - 1.  Members are independent DEFLATE streams, so once their
+// boundaries are known without decoding they inflate on as many threads as there are.
+static int bgzf_block_size(const uint8_t *p, int64_t n)       // > 0: size;  0: header incomplete;  -1: not a BGZF member
+{
+    static const uint8_t magic[4] = {0x1f, 0x8b, 8, 4};          // gzip, deflate, FLG = FEXTRA only
+    for (int k = 0; k < 4 && k < n; k++)
+        if (p[k] != magic[k]) return -1;
+    if (n < 12) return 0;
+    const int64_t xlen = p[10] | (p[11] << 8);
+    if (n < 12 + xlen) return 0;
+    int64_t q = 12;
+    const int64_t xend = 12 + xlen;
+    while (q + 4 <= xend) {
+        const int64_t slen = p[q + 2] | (p[q + 3] << 8);
+        if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= xend) {
+            const int size = (p[q + 4] | (p[q + 5] << 8)) + 1;
+            return size >= (int)(xend + 2 + 8) ? size : -1;     // header + an empty stored/fixed block + trailer at least
+        }
+        q += 4 + slen;
+    }
+    return -1;
+}
+
+int64_t mio_bgzf_scan(const uint8_t *in, int64_t in_len, int64_t max_blocks, int64_t max_out, int64_t *offs, int32_t *sizes,
+                      int64_t *out_offs, int32_t *why)
+{
+    if (!in || in_len < 0 || max_blocks < 0 || !offs || !sizes || !out_offs || !why) return ifail(MIO_E_INVALID, "mio_bgzf_scan: bad arguments");
+    int64_t pos = 0, nb = 0, total = 0;
+    *why = 0;
+    while (nb < max_blocks) {
+        const int size = bgzf_block_size(in + pos, in_len - pos);
+        if (size < 0) { *why = 1; break; }
+        if (size == 0 || pos + size > in_len) { *why = 0; break; }
+        const uint8_t *t = in + pos + size - 4;
+        const int64_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((int64_t)t[3] << 24);
+        if (isize > (1 << 16)) { *why = 1; break; }              // not what the format allows: the serial decoder takes it
+        if (nb > 0 && total + isize > max_out) { *why = 2; break; }
+        offs[nb] = pos; sizes[nb] = size; out_offs[nb] = total;
+        total += isize; pos += size; nb++;
+        if (nb == max_blocks) *why = 2;
+    }
+    out_offs[nb] = total;
+    return nb;
+}
+
+int32_t mio_bgzf_inflate_mt(const uint8_t *in, const int64_t *offs, const int32_t *sizes, const int64_t *out_offs, int64_t n,
+                            uint8_t *out, int32_t threads)
+{
+    if (!in || !offs || !sizes || !out_offs || n < 0 || (!out && n > 0 && out_offs[n] > 0)) return ifail(MIO_E_INVALID, "mio_bgzf_inflate_mt: bad arguments");
+    if (n == 0) return 0;
+    int T = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+    if (T > n) T = (int)n;
+    std::atomic<int64_t> next{0};
+    std::atomic<bool> failed{false};
+    std::mutex mu;
+    int64_t bad_block = -1;
+    char bad_msg[200] = "";
+    auto work = [&]() {
+        mio_inflate *S = new (std::nothrow) mio_inflate();
+        uint8_t dummy[8];
+        for (;;) {
+            const int64_t b = next.fetch_add(4);                  // four blocks (<= 256 KiB of text) per grab
+            if (b >= n || failed.load()) break;
+            for (int64_t k = b; k < n && k < b + 4; k++) {
+                const char *msg = nullptr;
+                if (!S) msg = "out of memory";
+                else {
+                    S->phase = mio_inflate::GZ_HEADER; S->bitbuf = 0; S->bitcnt = 0; S->any_member = false;
+                    S->last_block = false; S->stored_left = 0;
+                    const int64_t want = out_offs[k + 1] - out_offs[k];
+                    int64_t used = 0, made = 0;
+                    const int rc = mio_inflate_gzip(S, in + offs[k], sizes[k], 1, want ? out + out_offs[k] : dummy, 0, want, &used, &made);
+                    if (rc < 0) msg = g_ierr;
+                    else if (rc != 2 || used != sizes[k] || made != want) msg = "block does not match its stated size";
+                }
+                if (msg) {
+                    std::lock_guard<std::mutex> g(mu);
+                    if (bad_block < 0 || k < bad_block) { bad_block = k; snprintf(bad_msg, sizeof(bad_msg), "%s", msg); }
+                    failed.store(true);
+                    break;
+                }
+            }
+        }
+        delete S;
+    };
+    std::vector<std::thread> th;
+    try {
+        for (int t = 1; t < T; t++) th.emplace_back(work);
+    } catch (...) { /* fewer threads: the caller's thread does the rest */ }
+    work();
+    for (auto &t : th) t.join();
+    if (bad_block >= 0) {
+        char m[200];
+        snprintf(m, sizeof(m), "BGZF block %lld: %.150s", (long long)bad_block, bad_msg);
+        return ifail(MIO_E_INVALID, m);
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "mio_inflate_gzip": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p]),
     "mio_crc32": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_int64]),
+    "mio_bgzf_scan": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mio_bgzf_inflate_mt": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "mio_pack": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mio_py2_hash": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
@@ -367,9 +369,15 @@ class GzipReader:
     `raw` is the compressed file opened in binary mode.  Multi-member files and zero padding are read as gzip reads
     them; CRC-32 and length of every member are checked; corrupt or truncated input raises OSError."""
     WINDOW = 32768
+    MAX_BGZF = 1 << 16                                     # members per parallel batch
 
-    def __init__(self, raw, in_block=1 << 23):
+    def __init__(self, raw, in_block=1 << 23, threads=1):
         self.L = load()
+        self.threads = max(1, int(threads))
+        # BGZF members (bgzip, Illumina's writers, this package's own outputs) state their size, so a batch of them
+        # inflates on `threads` threads; the first member that is not BGZF switches to the one-stream decoder for good
+        self.bgzf = self.threads > 1 and in_block >= (1 << 17)
+        self.bgzf_batches = 0
         self.raw = raw
         self.st = self.L.mio_inflate_create()
         if not self.st:
@@ -399,17 +407,65 @@ class GzipReader:
         return True
 
     def read(self, n=1 << 25):
-        """At most n bytes (fewer only at the end of the file); b"" at the end."""
+        """At most n bytes, at least one unless the file has ended (b""): a request is served from what one decoding
+        step produced -- n bytes from the one-stream decoder, the whole members that fit n from a BGZF batch."""
         if n <= 0:
             return b""
-        if len(self.ready) < n and not self.done:
+        if not self.ready and not self.done:
             # the decoder needs room for a whole match (258 bytes) to make progress: small requests are served from a
             # block decoded ahead
-            self.ready += self._decode(max(n - len(self.ready), 1 << 16))
-        out, self.ready = self.ready[:n], self.ready[n:]
+            self.ready = self._decode(max(n, 1 << 16))
+        if len(self.ready) <= n:
+            out, self.ready = self.ready, b""                  # (no copy: the usual case for block-sized requests)
+        else:
+            out, self.ready = self.ready[:n], self.ready[n:]
         return out
 
+    def _decode_bgzf(self, n):
+        """Up to about n bytes from whole BGZF members, or None once the input is not (or no longer) BGZF."""
+        if not hasattr(self, "_bg"):
+            m = self.MAX_BGZF
+            self._bg = (np.empty(m, np.int64), np.empty(m, np.int32), np.empty(m + 1, np.int64), C.c_int32(0))
+        offs, sizes, out_offs, why = self._bg
+        while True:
+            if self.in_pos == self.in_len and not self._more_input():
+                self.done = True                               # ended on a member boundary
+                return b""
+            nb = self.L.mio_bgzf_scan(self.inbuf.ctypes.data + self.in_pos, self.in_len - self.in_pos, len(offs), n,
+                                      offs.ctypes.data, sizes.ctypes.data, out_offs.ctypes.data, C.addressof(why))
+            if nb < 0:
+                raise OSError("gzip input: " + self.L.mio_inflate_error().decode())
+            if nb > 0:
+                break
+            if why.value == 0 and self._more_input():
+                continue                                       # the member at the end of the buffer was incomplete
+            self.bgzf = False                                  # not BGZF, or a truncated tail: the serial decoder says which
+            while self.bgzf_batches:                           # zero padding after a member is ignored, as gzip does
+                view = self.inbuf[self.in_pos:self.in_len]
+                self.in_pos += int(np.argmax(view != 0)) if view.any() else len(view)
+                if self.in_pos < self.in_len:
+                    break
+                if not self._more_input():
+                    self.done = True
+                    return b""
+            return None
+        total = int(out_offs[nb])
+        out = np.empty(max(total, 1), np.uint8)
+        rc = self.L.mio_bgzf_inflate_mt(self.inbuf.ctypes.data + self.in_pos, offs.ctypes.data, sizes.ctypes.data,
+                                        out_offs.ctypes.data, nb, out.ctypes.data, self.threads)
+        if rc < 0:
+            raise OSError("gzip input: " + self.L.mio_inflate_error().decode())
+        self.in_pos += int(offs[nb - 1]) + int(sizes[nb - 1])
+        self.bgzf_batches += 1
+        return out[:total].tobytes()
+
     def _decode(self, n):
+        while self.bgzf:
+            data = self._decode_bgzf(n)
+            if data is None:
+                break
+            if data or self.done:
+                return data                                    # (an empty member, e.g. the end marker, yields nothing: next)
         h = len(self.hist)
         out = np.empty(h + n, np.uint8)
         out[:h] = self.hist

@@ -166,3 +166,136 @@ def test_large_file_and_rate(tmp_path):
     dz = time.perf_counter() - t
     assert ref == data
     print("\ninflate: %.0f MB/s (zlib through gzip.open: %.0f MB/s) on %d MB of FASTQ text" % (len(data) / dt / 1e6, len(data) / dz / 1e6, len(data) >> 20))
+
+
+# ---- BGZF: members that state their size are inflated on several threads -------------------------------------------------
+
+def decode_mt(comp, threads, read_size=1 << 20, in_block=1 << 17):
+    r = F.GzipReader(io.BytesIO(comp), in_block=in_block, threads=threads)
+    out = []
+    while True:
+        b = r.read(read_size)
+        if not b:
+            break
+        out.append(b)
+    batches = r.bgzf_batches
+    r.close()
+    return b"".join(out), batches
+
+
+def test_bgzf_members_are_standard_gzip_and_state_their_size():
+    from moira_amd.cli import BGZF_DATA, BGZF_EOF, bgzf_compress
+    rng = np.random.default_rng(41)
+    text = fastq_text(rng, 3000)
+    z = bgzf_compress(text)
+    assert gzip.decompress(z + BGZF_EOF) == text and gzip.decompress(BGZF_EOF) == b""
+    pos = members = 0
+    while pos < len(z):                                          # walk by the stated sizes alone
+        assert z[pos:pos + 4] == b"\x1f\x8b\x08\x04" and z[pos + 10:pos + 16] == b"\x06\x00BC\x02\x00"
+        size = int.from_bytes(z[pos + 16:pos + 18], "little") + 1
+        assert size <= 65536
+        piece = zlib.decompress(z[pos + 18:pos + size - 8], -15)
+        assert piece == text[members * BGZF_DATA:(members + 1) * BGZF_DATA]
+        assert int.from_bytes(z[pos + size - 4:pos + size], "little") == len(piece)
+        pos += size
+        members += 1
+    assert pos == len(z) and members == -(-len(text) // BGZF_DATA)
+    noise = rng.integers(0, 256, 200_000, dtype=np.uint8).tobytes()       # incompressible data still fits the size field
+    assert gzip.decompress(bgzf_compress(noise)) == noise
+
+
+@pytest.mark.parametrize("threads", [1, 2, 5])
+def test_bgzf_input_on_several_threads(threads):
+    from moira_amd.cli import BGZF_EOF, bgzf_compress
+    rng = np.random.default_rng(42)
+    text = fastq_text(rng, 6000)
+    z = bgzf_compress(text) + BGZF_EOF
+    for read_size in (1 << 20, 70_000, 999):
+        got, batches = decode_mt(z, threads, read_size)
+        assert got == text
+        assert (batches > 0) == (threads > 1)
+    # an input block barely larger than a member: members straddle every refill
+    got, batches = decode_mt(z, threads, 1 << 16, in_block=(1 << 17) + 13)
+    assert got == text
+    # only the end marker / nothing after the last member / zero padding after it
+    assert decode_mt(BGZF_EOF, threads) == (b"", 1 if threads > 1 else 0)
+    assert decode_mt(bgzf_compress(text), threads)[0] == text
+    assert decode_mt(z + b"\0" * 1000, threads)[0] == text
+
+
+def test_bgzf_mixed_with_ordinary_members():
+    """A file may change convention between members (cat of two files): the parallel path hands over to the one-stream
+    decoder at the first member that is not BGZF and the text is the same."""
+    from moira_amd.cli import bgzf_compress
+    rng = np.random.default_rng(43)
+    text = fastq_text(rng, 5000)
+    a, b = len(text) // 3, 2 * len(text) // 3
+    z = bgzf_compress(text[:a]) + gzip.compress(text[a:b]) + bgzf_compress(text[b:])
+    got, batches = decode_mt(z, 4, 50_000)
+    assert got == text and batches >= 1
+    # an extra field that is not the BGZF one, and a BGZF-looking member with a second subfield in front
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = c.compress(text[:5000]) + c.flush()
+    trailer = zlib.crc32(text[:5000]).to_bytes(4, "little") + (5000).to_bytes(4, "little")
+    other = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\x00XY\x02\x00\x07\x07" + raw + trailer
+    assert decode_mt(other, 4) == (text[:5000], 0)
+    two = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x0b\x00XY\x01\x00\x07BC\x02\x00" + (len(raw) + 30).to_bytes(2, "little") + raw + trailer
+    assert decode_mt(two + two, 4) == (text[:5000] * 2, 1)
+
+
+def test_bgzf_damage_is_an_error_not_garbage():
+    from moira_amd.cli import BGZF_EOF, bgzf_compress
+    rng = np.random.default_rng(44)
+    text = fastq_text(rng, 4000)
+    z = bytearray(bgzf_compress(text) + BGZF_EOF)
+    size0 = int.from_bytes(z[16:18], "little") + 1
+    for what in ("data", "crc", "isize", "bsize_short", "bsize_long", "truncated"):
+        bad = bytearray(z)
+        if what == "data":
+            bad[size0 + 200] ^= 0x55                              # inside the second member's deflate data
+        elif what == "crc":
+            bad[size0 - 8] ^= 1
+        elif what == "isize":
+            bad[size0 - 4] ^= 1
+        elif what == "bsize_short":
+            bad[16:18] = (size0 - 1 - 40).to_bytes(2, "little")
+        elif what == "bsize_long":
+            bad[16:18] = (size0 - 1 + 40).to_bytes(2, "little")
+        else:
+            bad = bad[:len(bad) - len(BGZF_EOF) - 11]
+        for threads in (1, 4):
+            try:
+                got, _ = decode_mt(bytes(bad), threads)
+            except OSError:
+                continue
+            # a wrong size FIELD around sound data: a decoder that never needed the field (one stream, or the parallel
+            # path once it has handed over) still yields the text; anything else must have been refused
+            assert what.startswith("bsize") and got == text, "%s (threads %d): decoded %d bytes without an error" % (what, threads, len(got))
+
+
+def test_cli_reads_bgzf_input_like_plain_input(tmp_path, oracle):
+    """The CLI on a BGZF-compressed FASTQ with -p 4 (members inflated on several threads) writes what it writes for the
+    uncompressed file, and its own .gz outputs are BGZF: they decode on the parallel path."""
+    from moira_amd import cli
+    from moira_amd.cli import BGZF_EOF, bgzf_compress
+    from test_cli_golden import oracle_backend, reference_args
+    rng = np.random.default_rng(45)
+    text = fastq_text(rng, 2500)
+    (tmp_path / "r.fastq").write_bytes(text)
+    (tmp_path / "z.fastq.gz").write_bytes(bgzf_compress(text) + BGZF_EOF)
+    outs = {}
+    for label, src, comp in (("plain", "r.fastq", "none"), ("bgzf", "z.fastq.gz", "gz")):
+        pre = str(tmp_path / ("o_" + label))
+        a = reference_args(paired=False, forward_fastq=str(tmp_path / src), output_prefix=pre, collapse=True,
+                           output_compression=comp, processors=4)
+        assert cli.main(a, backend=oracle_backend(oracle), out=open(os.devnull, "w")) == 0
+        outs[label] = {}
+        for f in sorted(os.listdir(tmp_path)):
+            if f.startswith("o_" + label + "."):
+                data = (tmp_path / f).read_bytes()
+                if comp == "gz":
+                    data, batches = decode_mt(data, 4)
+                    assert batches >= 1
+                outs[label][f.split(".", 1)[1].replace(".gz", "")] = data
+    assert outs["plain"].keys() == outs["bgzf"].keys() and len(outs["plain"]) >= 6
+    assert outs["plain"] == outs["bgzf"]

@@ -1,12 +1,13 @@
 #!/bin/bash
 # CPU-only ThreadSanitizer run of the threaded parts of libmoira_io (round 3): the parallel FASTQ indexer
 # (mio_fastq_index_mt), the concurrent preads (mio_pread_mt) and the sharded collapse (mio_collapse_add with 8 threads,
-# several chunks, export).  Pure C++ harness, no Python in the process.
+# several chunks, export) and the BGZF members inflated on 8 threads (mio_bgzf_inflate_mt).  Pure C++ harness, no Python in the process.
 set -e
 cd "$(dirname "$0")/.."
 D=${TMPDIR:-/tmp}/mio_tsan; mkdir -p $D
 cat > $D/main.cpp <<'CPP'
 #include "moira_io.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,10 +65,36 @@ int main()
         mio_collapse_destroy(c);
     }
     if (outs[0] != outs[1]) { printf("collapse mismatch\n"); return 7; }
+    // BGZF members (stored deflate blocks built by hand) inflated on 8 threads
+    {
+        std::string z;
+        const size_t piece = 60000;
+        for (size_t pos = 0; pos < buf.size(); pos += piece) {
+            const size_t len = std::min(piece, buf.size() - pos);
+            const unsigned size = 18 + 5 + (unsigned)len + 8;
+            const unsigned char head[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (unsigned char)((size - 1) & 0xff), (unsigned char)((size - 1) >> 8)};
+            z.append((const char *)head, 18);
+            const unsigned char sb[5] = {1, (unsigned char)(len & 0xff), (unsigned char)(len >> 8), (unsigned char)(~len & 0xff), (unsigned char)((~len >> 8) & 0xff)};
+            z.append((const char *)sb, 5);
+            z.append(buf.data() + pos, len);
+            const uint32_t crc = mio_crc32(0, (const uint8_t *)buf.data() + pos, (int64_t)len);
+            for (uint32_t v : {crc, (uint32_t)len}) for (int k = 0; k < 4; k++) z += (char)((v >> (8 * k)) & 0xff);
+        }
+        const size_t zl = z.size();
+        z.append(8, '\0');                                              // readable slack
+        std::vector<int64_t> offs(4096), oo(4097); std::vector<int32_t> sizes(4096);
+        int32_t why = 0;
+        const int64_t nbk = mio_bgzf_scan((const uint8_t *)z.data(), (int64_t)zl, 4096, (int64_t)1 << 40, offs.data(), sizes.data(), oo.data(), &why);
+        if (nbk <= 0 || oo[(size_t)nbk] != (int64_t)buf.size()) { printf("bgzf scan mismatch\n"); return 8; }
+        std::vector<uint8_t> text(buf.size());
+        if (mio_bgzf_inflate_mt((const uint8_t *)z.data(), offs.data(), sizes.data(), oo.data(), nbk, text.data(), 8)) { printf("bgzf: %s\n", mio_inflate_error()); return 9; }
+        if (memcmp(text.data(), buf.data(), buf.size())) { printf("bgzf text mismatch\n"); return 10; }
+        printf("tsan harness: %lld BGZF members inflated on 8 threads\n", (long long)nbk);
+    }
     printf("tsan harness: index_mt == index (%d records), pread_mt ok, collapse(8 threads) == collapse(1 thread): %zu bytes of names\n", n, outs[0].size());
     return 0;
 }
 CPP
-g++ -O1 -g -fsanitize=thread -std=c++17 -pthread -Iinclude moira_amd/csrc/fastio.cpp $D/main.cpp -o $D/tsan_io
+g++ -O1 -g -fsanitize=thread -std=c++17 -pthread -Iinclude moira_amd/csrc/fastio.cpp moira_amd/csrc/inflate.cpp $D/main.cpp -o $D/tsan_io
 TSAN_OPTIONS=halt_on_error=1 $D/tsan_io
 echo "ThreadSanitizer: no data race reported"
