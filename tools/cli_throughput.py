@@ -132,6 +132,19 @@ if os.environ.get("CLI_GZ"):
     run("fastq.gz in through zlib (MOIRA_ZLIB_INPUT=1), fastq out, no collapse, -p " + P, ["-c", "false", "-o", "fastq", "-p", P],
         {"MOIRA_ZLIB_INPUT": "1"})
     os.environ.pop("MOIRA_ZLIB_INPUT", None)
+    # the same text as BGZF members (what bgzip / Illumina's writers / this CLI's own .gz outputs are): inflated on -p threads
+    from moira_amd.cli import BGZF_EOF, bgzf_compress
+    path = os.path.join(tmp, "small_bgzf.fastq.gz")
+    with open(small, "rb") as f, open(path, "wb") as g:
+        while True:
+            blk = f.read(64 * 0xff00)
+            if not blk:
+                break
+            g.write(bgzf_compress(blk, 1))
+        g.write(BGZF_EOF)
+    run("fastq.gz (BGZF) in, fastq out, no collapse, -p " + P, ["-c", "false", "-o", "fastq", "-p", P])
+    run("fastq.gz (BGZF) in, fastq out, no collapse, -p 1", ["-c", "false", "-o", "fastq"])
+    run("fastq.gz (BGZF) in, fastq.gz (BGZF) out, no collapse, -p " + P, ["-c", "false", "-o", "fastq", "-oc", "gz", "-p", P])
     path, n = _keep, _n
 
 m = min(n, int(os.environ.get("CLI_PAIRS", "200000")))
