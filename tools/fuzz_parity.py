@@ -104,6 +104,31 @@ with Engine(0) as eng:
             ok = ok and np.array_equal(np.isnan(r.ee), np.isnan(ee)) and (rel.size == 0 or rel.max() <= 1e-9)
         else:
             ok = ok and np.array_equal(r.ee, ee, equal_nan=True)
+        if rng.random() < 0.3 and int(q[(q != 255)].max(initial=0)) <= 222:
+            # classified at source (round 3): the same reads as FASTQ text resident in HBM, decoded and classified by one
+            # pass (k_classify_linear), the filter starting at the scan -- same oracle results, and the packed matrix back
+            seq = np.where(q == 0, ord("N"), np.where(q == 255, ord("n"), ord("A"))).astype(np.uint8)
+            amb_q = rng.integers(33, 75, q.shape, dtype=np.uint8)
+            qual = np.where((q == 0) | (q == 255), amb_q, q + 33).astype(np.uint8)
+            pad = np.arange(stride)[None, :] >= lens[:, None]
+            seq[pad] = rng.integers(0, 256, int(pad.sum()), dtype=np.uint8)          # text past the end is never looked at
+            qual[pad] = rng.integers(0, 256, int(pad.sum()), dtype=np.uint8)
+            bufs = [eng.alloc(n * stride).upload(seq), eng.alloc(n * stride).upload(qual), eng.alloc(n * stride),
+                    eng.alloc(n * 4).upload(lens), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n), eng.alloc(4).upload(np.zeros(1, np.int32))]
+            d_seq, d_qual, d_out, d_len, d_ee, d_ns, d_pass, d_err = bufs
+            c = eng.filter_ascii_device(d_seq, d_qual, n, stride, d_out, d_len=None if fixed else d_len,
+                                        fixed_len=int(lens[0]) if fixed else 0, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, d_err=d_err,
+                                        params=eng.params(**kw))
+            wantq = np.where(pad, 0, q).astype(np.uint8)
+            okc = (np.array_equal(d_out.download(np.uint8, n * stride).reshape(n, stride), wantq)
+                   and np.array_equal(d_ee.download(np.float64, n), ee, equal_nan=True)
+                   and np.array_equal(d_ns.download(np.int32, n), ns) and np.array_equal(d_pass.download(np.uint8, n), ps)
+                   and c.n_pass == int(ps.sum()) and int(d_err.download(np.int32, 1)[0]) == 0)
+            for b in bufs:
+                b.free()
+            if not okc:
+                bad += 1
+                print("CLASSIFIED-AT-SOURCE MISMATCH round %d: n=%d stride=%d fixed=%s kind=%d kw=%s" % (it, n, stride, fixed, kind, kw), flush=True)
         if (it + 1) % 100 == 0:
             print("fuzz: %d rounds done, %d mismatching, %.0f s" % (it + 1, bad, time.time() - t0), flush=True)
         if not ok:
