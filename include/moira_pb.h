@@ -49,7 +49,7 @@ extern "C" {
 #define MPB_E_NODEVICE   -2   /* no usable HIP device / bad device id           */
 #define MPB_E_HIP        -3   /* a HIP runtime call failed (message has detail) */
 #define MPB_E_NOMEM      -4   /* device or host allocation failed               */
-#define MPB_E_RANGE      -5   /* a qscore cannot be encoded (Q < 0 or Q > 254)  */
+#define MPB_E_RANGE      -5   /* a qscore cannot be encoded (Q < 0; Q > 254 in a batch entry) */
 
 /* --ambigs modes, ref: moira/moira.py:658-659, :827-828, :911 */
 #define MPB_AMBIG_TREAT_AS_ERRORS 0
@@ -299,6 +299,10 @@ int mpb_filter_host_multi(mpb_ctx *const *ctxs, int32_t n_ctx,
  * ref: moira/bernoullimodule.c:66-114.  Validates alpha in (0,1) (:79-83),
  * clamps Q0->1 (:104-107), counts 'N' and 'n' (:196).  `ee` is the raw
  * percentile (no +Ns, no floor).  Runs the HIP path on a batch of one.
+ * Any non-negative int is a valid score, as in the reference (:92-108): a read with scores above 254 -- which the byte
+ * matrix of the batch entries cannot hold -- gets its own code table for the call ({1-p, p'} of every such score, by the
+ * same expressions, under a byte code the read does not use).  MPB_E_RANGE only for a negative score, or for a read with
+ * more than 254 distinct scores of which some exceed 254.
  */
 int mpb_calculate_errors_PB(mpb_ctx *ctx, const char *contig,
                             const int32_t *contig_quals, int32_t len,

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #define MPB_VERSION_STR "moira_pb 0.3.0 (gfx950)"
@@ -61,6 +62,7 @@ struct mpb_ctx {
     HostSlot slot[MPB_HOST_SLOTS];
     int copy_threads = 1;
     double2 *d_lut = nullptr;
+    double2 *d_lut_private = nullptr;    // one call's table when a read carries qualities above 254 (mpb_calculate_errors_PB)
     // workspace, grown on demand
     int64_t ws_cap = 0;
     MpbWorkspace ws{};
@@ -150,17 +152,22 @@ int mpb_device_count(void)
 //   b  = prob_j_errors(p, 1, 1) = ((1-1+1)/(1.0*1)) * (p/(1-p)) * pow(1 - p, 1)
 // evaluated on the host with libm (this TU is built with -ffp-contract=off).  Bytes 0 ('N')
 // and 255 ('n') are the identity step of the DP: skipping a base == multiplying by {1, 0}.
+static void lut_entry(int q, double2 *e)          // any quality the reference's int can hold (p underflows to 0 near Q = 3240)
+{
+    volatile double p = pow(10, (q / -10.0));
+    volatile double a = pow((1 - p), 1);
+    volatile double r = p / (1 - p);
+    volatile double b1 = ((1 - 1 + 1) / (1.0 * 1)) * r;
+    volatile double b = b1 * a;
+    e->x = a;
+    e->y = b;
+}
+
 static void build_lut(double2 *lut)
 {
     for (int q = 0; q < 256; q++) {
         if (q == 0 || q == 255) { lut[q].x = 1.0; lut[q].y = 0.0; continue; }
-        volatile double p = pow(10, (q / -10.0));
-        volatile double a = pow((1 - p), 1);
-        volatile double r = p / (1 - p);
-        volatile double b1 = ((1 - 1 + 1) / (1.0 * 1)) * r;
-        volatile double b = b1 * a;
-        lut[q].x = a;
-        lut[q].y = b;
+        lut_entry(q, &lut[q]);
     }
 }
 
@@ -234,6 +241,7 @@ int mpb_destroy(mpb_ctx *c)
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     if (c->pin_host) (void)hipHostFree(c->pin_host);
     if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_lut_private) (void)hipFree(c->d_lut_private);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
@@ -1078,12 +1086,53 @@ int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *conti
     if (len > MPB_MAX_LEN) return fail(MPB_E_INVALID, "reads longer than %d bases are not supported", MPB_MAX_LEN);
     const int32_t stride = (int32_t)align_up(len > 0 ? len : 1, 16);
     std::vector<uint8_t> row((size_t)stride);
-    int rc = mpb_pack_read(contig, contig_quals, len, row.data(), stride);
-    if (rc) return rc;
     mpb_filter_params prm;
     prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
     uint8_t pass = 0;
-    return mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
+    bool big = false;
+    for (int32_t i = 0; i < len; i++) {
+        if (contig_quals[i] < 0) return fail(MPB_E_RANGE, "Qualities must have positive values.");
+        big = big || contig_quals[i] > 254;
+    }
+    if (!big) {
+        int rc = mpb_pack_read(contig, contig_quals, len, row.data(), stride);
+        if (rc) return rc;
+        return mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
+    }
+    // A quality above 254 has no byte code, and the reference takes any int (bernoullimodule.c:92-108).  One read holds
+    // few distinct values, so for this call each such value borrows a byte code the read does not use (from 254 down:
+    // the row predictor reads the code as a quality, and up there every code means "practically never wrong") and the
+    // kernels get a private copy of the table with {1-p, p'} of the real value under that code.
+    double2 h[256];
+    build_lut(h);
+    bool used[256] = {};
+    for (int32_t i = 0; i < len; i++)
+        if (contig_quals[i] <= 254) used[contig_quals[i] == 0 ? 1 : contig_quals[i]] = true;
+    std::unordered_map<int32_t, int> code_of;
+    int next = 254;
+    for (int32_t i = 0; i < len; i++) {
+        const int32_t q = contig_quals[i];
+        const char base = contig ? contig[i] : 'A';
+        if (q <= 254) { row[(size_t)i] = pack_one(base, q); continue; }
+        auto it = code_of.find(q);
+        if (it == code_of.end()) {
+            while (next >= 1 && used[next]) next--;
+            if (next < 1) return fail(MPB_E_RANGE, "more than 254 distinct quality values in one read, some above 254");
+            used[next] = true;
+            lut_entry(q, &h[next]);
+            it = code_of.emplace(q, next).first;
+        }
+        row[(size_t)i] = pack_one(base, it->second);
+    }
+    int rc = ensure_workspace(c, 1);
+    if (rc) return rc;
+    if (!c->d_lut_private) HIPCHK(hipMalloc((void **)&c->d_lut_private, sizeof(h)));
+    HIPCHK(hipMemcpyAsync(c->d_lut_private, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                 // h is on this stack
+    c->ws.lut = c->d_lut_private;
+    rc = mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
+    c->ws.lut = c->d_lut;
+    return rc;
 }
 
 int mpb_decode_ascii_device(mpb_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, int64_t n, int64_t row_stride,

@@ -281,8 +281,8 @@ class Engine:
         qi = None
         if contig_quals:
             a = np.asarray(contig_quals)                       # one C loop for the common case: a list of Python ints
-            if a.ndim == 1 and a.dtype.kind in "iub" and (a.dtype.kind == "b" or (a.min() >= -2 ** 31 and a.max() < 2 ** 31)):
-                qi = a.astype(np.int32)
+            if a.ndim == 1 and a.dtype.kind in "ib":
+                qi = a.astype(np.int32)                        # wraps as (int)PyInt_AsLong does (bernoullimodule.c:97)
         if qi is None:                                         # anything else: element by element, as PyInt_AsLong would
             qi = np.empty(len(contig_quals), np.int32)
             for i, v in enumerate(contig_quals):

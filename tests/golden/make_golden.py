@@ -27,6 +27,9 @@ What runs here
   * `--lut` (round 3): the Phred -> probability table and a set of libm probes (pow, exp) are added to kat.json as
     hex-float strings, so that a libm difference between the build container and a GPU box shows up under its own
     test name (last bullet).
+  * `--bigq` (round 3): reads that carry quality scores above 254 (a .qual file or a Python caller can hold them; the
+    byte matrix cannot) through the real extension and the Python twin -> bigq.json (sequence, integer scores, alpha,
+    the reference's (ee, Ns) as hex floats).
 Only data (inputs + the reference's outputs) is written into the repo.
 
 The inputs are stored in the packed-qscore encoding of include/moira_pb.h
@@ -346,6 +349,48 @@ def make_long_fixture(ref, pyref):
     print("long_reads     rows needed: min %d, max %d, > 1024 rows: %d reads" % (need.min(), need.max(), int((need > 1024).sum())))
 
 
+def make_bigq_fixture(ref, pyref):
+    """Quality scores above 254: the reference takes any int (moira/bernoullimodule.c:92-108, moira/moira.py:1561-1634)."""
+    rng = np.random.default_rng(20161008)
+    big = [255, 256, 300, 999, 1000, 3000, 3239, 3240, 3241, 5000, 65535, 2 ** 31 - 1]
+    reads = []
+
+    def add(seq, quals, alpha):
+        quals = [int(v) for v in quals]
+        e, s = ref.calculate_errors_PB(seq, quals, alpha)
+        ep, sp = pyref.calculate_errors_PB(seq.replace("n", "N"), [v if v else 1 for v in quals], alpha)
+        assert sp == s
+        _, _, rows = O.ee_rowwise(seq, quals, alpha)
+        ub = int(rows == 1)                      # the C reference reads accumulated_probs[-1] there: the twin's value is pinned
+        if not ub:
+            assert e == ep, (seq, quals, alpha, e, ep)
+        reads.append({"seq": seq, "quals": quals, "alpha": alpha, "ee": float(ep).hex(), "ns": int(s), "ub": ub})
+
+    for k in range(90):
+        L = int(rng.integers(1, 220))
+        lo, hi = [(2, 42), (1, 8), (25, 42), (1, 255)][k % 4]
+        quals = rng.integers(lo, hi, L).tolist()
+        for pos in rng.integers(0, L, int(rng.integers(1, max(2, L // 3)))):
+            quals[int(pos)] = int(rng.choice(big))
+        seq = ["A"] * L
+        if k % 3 == 0:
+            for pos in rng.integers(0, L, 1 + L // 40):
+                seq[int(pos)] = "N" if rng.random() < 0.7 else "n"
+        if k % 7 == 0:
+            quals[int(rng.integers(0, L))] = 0
+        add("".join(seq), quals, float([0.005, 0.05, 1e-5, 0.3][k % 4]))
+    add("A" * 40, [300] * 40, 0.005)                                            # nothing but big scores
+    add("A" * 300, [255 + 3 * i for i in range(150)] + [7] * 150, 0.005)       # 150 distinct big values
+    add("A" * 500, list(range(1, 201)) + [1000 + i for i in range(54)] + [3] * 246, 0.005)    # 254 distinct values in all
+    add("ANnA", [5000, 5000, 5000, 2], 0.005)
+    add("A", [2 ** 31 - 1], 0.5)
+    out = os.path.join(HERE, "bigq.json")
+    json.dump({"source": "oracle/_ref/bernoulli.so (moira/bernoullimodule.c unmodified) and the Python twin of moira/moira.py:1561-1634; "
+                         "ub = 1: the C reference's value is undefined (bernoullimodule.c:254), the twin's is stored",
+               "reads": reads}, open(out, "w"), indent=0)
+    print("bigq.json: %d reads, %d of them ub" % (len(reads), sum(r["ub"] for r in reads)))
+
+
 def add_lut_to_kat():
     """Phred -> {p, 1-p, p'} exactly as moira/bernoullimodule.c:202,140-145 evaluate them with THIS container's libm,
     plus libm probes of the Poisson tail (moira/moira.py:1671: exp(-Lambda) * Lambda**j / factorial(j)), as hex floats."""
@@ -390,6 +435,12 @@ def main():
     ref = O.reference_module()
     assert ref is not None, "oracle/_ref/bernoulli.so missing: make -C oracle ref"
     pyref, tmp = load_python_reference()
+    if "--bigq" in sys.argv:
+        try:
+            make_bigq_fixture(ref, pyref)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
     if "--long" in sys.argv:
         try:
             make_long_fixture(ref, pyref)

@@ -49,3 +49,11 @@ def lut_fixture():
     lut = {int(q): tuple(float.fromhex(x) for x in v) for q, v in kat["lut"]["q"].items()}
     probes = [(float.fromhex(r[0]), int(r[1]), float.fromhex(r[2]), float.fromhex(r[3])) for r in kat["libm_probes"]["rows"]]
     return lut, probes
+
+
+def bigq_fixture():
+    """[(seq, quals, alpha, ee, ns, ub)]: reads with quality scores above 254 and the real reference's results
+    (make_golden.py --bigq)."""
+    import json
+    d = json.load(open(os.path.join(GOLDEN, "bigq.json")))
+    return [(r["seq"], r["quals"], r["alpha"], float.fromhex(r["ee"]), r["ns"], r["ub"]) for r in d["reads"]]

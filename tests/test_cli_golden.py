@@ -391,3 +391,39 @@ def test_long_reads_run_with_the_poisson_binomial_method_gpu(tmp_path, oracle, l
         n_good += keep
         assert (">r%d\n" % k in good) == keep and (">r%d\t" % k in bad) == (not keep), (k, e, rows)
     assert 0 < n_good < len(recs)
+
+
+def test_quality_above_254_is_scored_through_the_per_read_entry(tmp_path, oracle):
+    """Under poisson_binomial a read whose scores do not fit the byte matrix takes the per-read entry (the reference
+    takes any int, moira/bernoullimodule.c:92-108); the other reads of the chunk stay in the batch.  Here the oracle
+    plays both parts; the GPU twin of this test is tests/test_gpu_bigq.py."""
+    fa, qu = tmp_path / "r.fasta", tmp_path / "r.qual"
+    tops = (40, 300, 41, 5000)
+    with open(fa, "w") as f, open(qu, "w") as g:
+        for k, top in enumerate(tops):
+            f.write(">r%d\n%s\n" % (k, "ACGT" * 10))
+            g.write(">r%d\n%s\n" % (k, " ".join(str(top if i == 7 else 3 if k == 3 else 30) for i in range(40))))
+    calls = []
+    backend = oracle_backend(oracle)
+
+    def per_read(seq, quals, alpha):
+        calls.append(max(quals))
+        e, ns, _ = oracle.ee_rowwise(seq, quals, alpha)
+        return e, ns
+    backend.per_read = per_read
+    out = str(tmp_path / "o")
+    a = reference_args(paired=False, forward_fasta=str(fa), forward_qual=str(qu), output_prefix=out, collapse=False, uncert=0.1)
+    assert cli.main(a, backend=backend, out=open(os.devnull, "w")) == 0
+    assert calls == [300, 5000]
+    good = open(out + ".qc.good.qual").read()
+    bad = open(out + ".qc.bad.qual").read()
+    assert ">r1\n" in good and " 300 " in good and ">r0\n" in good and ">r2\n" in good
+    assert ">r3\t" in bad and " 5000 " in bad                     # Q3 everywhere else: far too many expected errors
+    # --error_calc poisson keeps the limit and says so
+    import io
+    msg = io.StringIO()
+    a = reference_args(paired=False, forward_fasta=str(fa), forward_qual=str(qu), output_prefix=out + "p", collapse=False,
+                       error_calc="poisson", silent=True)
+    backend.methods = ("poisson_binomial", "poisson")
+    assert cli.main(a, backend=backend, out=msg) == 1
+    assert "r1" in msg.getvalue() and "poisson_binomial" in msg.getvalue()

@@ -1,0 +1,104 @@
+"""Quality scores above 254: the byte matrix cannot hold them, the reference takes any int
+(moira/bernoullimodule.c:92-108).  The per-read entry gives such a read its own code table for the call; results must be
+the real reference's (tests/golden/bigq.json, made by make_golden.py --bigq) bit for bit."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+import golden_io as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from moira_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def test_reference_vectors_with_big_scores(eng):
+    from moira_amd.dropin import bernoulli
+    reads = G.bigq_fixture()
+    for seq, quals, alpha, ee, ns, ub in reads:
+        assert eng.calculate_errors_PB(seq, quals, alpha) == (ee, ns), (seq, quals, alpha)
+    for seq, quals, alpha, ee, ns, ub in reads[::7]:
+        assert bernoulli.calculate_errors_PB(seq, quals, alpha) == (ee, ns)
+        assert bernoulli.calculate_errors(seq, quals, alpha) == (ee, ns)
+    # the context's own table is back in place afterwards: the reference's known answer, and the uploaded table itself
+    kat = G.load_kat()["kat1"]
+    assert eng.calculate_errors_PB(kat["seq"], kat["quals"], kat["alpha"]) == (kat["ee"], kat["ns"])
+    lut, _ = G.lut_fixture()
+    a, b = eng.device_lut()
+    assert all(a[q] == lut[q][1] and b[q] == lut[q][2] for q in lut)
+
+
+def test_big_scores_on_every_path_against_the_oracle(eng, oracle):
+    """Random reads: short (one read per wave), long rows, and more than 1024 DP rows (k_wide) -- each with a few scores
+    between 255 and 2^31 - 1, with and without ambiguous bases."""
+    rng = np.random.default_rng(254)
+    big = [255, 299, 1000, 3239, 3240, 70000, 2 ** 31 - 1]
+    cases = [(int(rng.integers(1, 400)), 2, 42) for _ in range(150)] + [(int(rng.integers(1025, 3000)), 20, 42) for _ in range(12)] + \
+            [(1400, 1, 3), (2100, 1, 4), (1600, 1, 2)]
+    most = 0
+    for L, lo, hi in cases:
+        quals = rng.integers(lo, hi, L).tolist()
+        for pos in rng.integers(0, L, 1 + L // 50):
+            quals[int(pos)] = int(rng.choice(big))
+        seq = np.full(L, ord("A"), np.uint8)
+        if rng.random() < 0.4:
+            seq[rng.integers(0, L, 1 + L // 60)] = ord("N")
+            seq[rng.integers(0, L, 1)] = ord("n")
+        seq = seq.tobytes().decode()
+        alpha = float(rng.choice([0.005, 0.05, 1e-4]))
+        e, ns, rows = oracle.ee_rowwise(seq, quals, alpha)
+        assert eng.calculate_errors_PB(seq, quals, alpha) == (e, ns), (L, lo, hi, alpha, rows)
+        most = max(most, rows)
+    assert most > 1024                                       # some case needs more rows than one wave holds
+
+
+def test_too_many_distinct_scores_is_an_error_and_ints_wrap_like_the_c_cast(eng, oracle):
+    with pytest.raises(ValueError, match="distinct quality values"):
+        eng.calculate_errors_PB("A" * 600, list(range(1, 200)) + [1000 + i for i in range(401)], 0.005)
+    # (int)PyInt_AsLong (bernoullimodule.c:97): 2^32 + 30 is 30 after the cast
+    assert eng.calculate_errors_PB("ACGT", [2 ** 32 + 30] * 4, 0.005) == eng.calculate_errors_PB("ACGT", [30] * 4, 0.005)
+    with pytest.raises(ValueError):                          # 2^31 wraps to a negative score
+        eng.calculate_errors_PB("ACGT", [2 ** 31] * 4, 0.005)
+    with pytest.raises(ValueError):                          # the batch entries keep their byte limit
+        eng.pack(["ACGT"], [[30, 255, 30, 30]], 16)
+
+
+def test_cli_scores_a_qual_file_with_big_scores(tmp_path, oracle):
+    from moira_amd import cli
+    from test_cli_golden import reference_args
+    fa, qu = tmp_path / "r.fasta", tmp_path / "r.qual"
+    rng = np.random.default_rng(11)
+    recs = []
+    with open(fa, "w") as f, open(qu, "w") as g:
+        for k in range(60):
+            L = int(rng.integers(30, 200))
+            quals = rng.integers(20, 42, L).tolist()
+            if k % 5 == 1:
+                quals[int(rng.integers(0, L))] = int(rng.choice([255, 300, 4000]))
+            seq = "".join(rng.choice(list("ACGT"), L))
+            recs.append((seq, quals))
+            f.write(">r%d\n%s\n" % (k, seq))
+            g.write(">r%d\n%s\n" % (k, " ".join(map(str, quals))))
+    out = str(tmp_path / "o")
+    a = reference_args(paired=False, forward_fasta=str(fa), forward_qual=str(qu), output_prefix=out, collapse=False, uncert=0.02)
+    assert cli.main(a, out=open(os.devnull, "w")) == 0
+    good = {l[1:].split("\t")[0].strip() for l in open(out + ".qc.good.fasta") if l.startswith(">")}
+    bad = {l[1:].split("\t")[0].strip() for l in open(out + ".qc.bad.fasta") if l.startswith(">")}
+    assert len(good) + len(bad) == 60 and good and bad
+    for k, (seq, quals) in enumerate(recs):
+        e, ns, _ = oracle.ee_rowwise(seq, quals, 0.005)
+        assert (("r%d" % k) in good) == (not (e > 0.02 * len(seq))), k        # moira.py:887 `expected_errors > maxerrors`
+    text = open(out + ".qc.good.qual").read() + open(out + ".qc.bad.qual").read()
+    assert " 300 " in text or " 255 " in text or " 4000 " in text
+    msg = io.StringIO()
+    a = reference_args(paired=False, forward_fasta=str(fa), forward_qual=str(qu), output_prefix=out + "p", collapse=False,
+                       error_calc="poisson", silent=True)
+    assert cli.main(a, out=msg) == 1 and "poisson_binomial" in msg.getvalue()

@@ -178,3 +178,16 @@ def test_live_reference_when_built(oracle):
         ee, ns, rows = oracle.ee_rowwise(seq, quals, 0.005)
         if rows > 1:                       # rows == 1 is the reference's UB case
             assert ref.calculate_errors_PB(seq, quals, 0.005) == (ee, ns)
+
+
+def test_oracle_takes_qualities_above_254_as_the_reference_does(oracle):
+    """The per-read entry points of the oracle work on the reference's own inputs (sequence + ints), so a quality score
+    the byte matrix cannot hold is just another int: pinned by the real extension's results (make_golden.py --bigq)."""
+    reads = G.bigq_fixture()
+    assert len(reads) >= 90 and sum(1 for r in reads if max(r[1]) > 254) == len(reads)
+    for seq, quals, alpha, ee, ns, ub in reads:
+        for fn in (oracle.ee_rowwise, oracle.ee_refshape):
+            e, s, rows = fn(seq, quals, alpha)
+            assert s == ns and (rows == 1) == bool(ub)
+            if not ub or fn is oracle.ee_rowwise:           # the reference-shaped loop nest shares the C reference's UB case
+                assert e == ee, (seq, quals, alpha)
