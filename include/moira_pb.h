@@ -336,6 +336,19 @@ int mpb_filter_poisson_host(mpb_ctx *ctx, const uint8_t *q, int64_t n, int64_t r
                             const int32_t *len, int32_t fixed_len, const mpb_filter_params *params,
                             double *ee, int32_t *ns, uint8_t *pass, mpb_filter_counts *counts);
 
+/*
+ * One read, the signature-level twin of moira.py's
+ *   calculate_errors_poisson(sequence, quals, alpha) -> (expected_errors, Ns)
+ * ref: moira/moira.py:1637-1679.  The function's own rules, not the batch encoding's: any non-negative int is a score
+ * (one outside 1..254 gets a private table entry for the call, as in mpb_calculate_errors_PB), Q0 is p = 1 (the clamp to
+ * Q1 happens in process_data, moira.py:814, before the function is called), only 'N' is skipped and counted.  `ee` is
+ * the raw percentile, NaN where the Python function raises OverflowError.  alpha must be in (0, 1), as the script's own
+ * argument check demands (the bare function also takes 1).
+ */
+int mpb_calculate_errors_poisson(mpb_ctx *ctx, const char *sequence,
+                                 const int32_t *quals, int32_t len,
+                                 double alpha, double *ee, int32_t *ns);
+
 /* ---- synthetic workload (BASELINE.json configs; integer-only generator) ---- */
 /* Fill a device quality matrix with the counter-based synthetic model of
  * include/mpb_synth.h (identical integers on host and device).

@@ -54,17 +54,15 @@ class QualityTooHighError(UnsupportedReadError):
     """Not a reference exception: the packed quality matrix holds one byte per base (0 = 'N', 255 = 'n'), so Phred
     scores above 254 cannot be encoded.  FASTQ cannot produce them (the largest character minus the smallest offset is
     222) and neither can contig construction from FASTQ input (`--consensus_qscore sum` without a cap: 186); only a
-    .qual file with such integers can (the reference takes any int there, moira/bernoullimodule.c:92-108).  Under the
-    poisson_binomial methods such a read is scored exactly through the per-read entry (process_chunk); this error is
-    what --error_calc poisson (and a backend without a per-read entry) still raises."""
+    .qual file with such integers can (the reference takes any int there, moira/bernoullimodule.c:92-108).  Such a read
+    is scored exactly through the per-read entries (process_chunk); this error is what a backend without them raises."""
     def __init__(self, header, quality):
         self.header, self.quality = header, quality
 
     def __str__(self):
-        return ("Sequence %s has a quality score of %d; --error_calc poisson encodes scores up to 254 (an error "
-                "probability of 4e-26). Use --error_calc poisson_binomial (any score), or cap the scores in the .qual file "
-                "(e.g. at 93, the FASTQ maximum) and run again: a capped score changes an error probability that is below "
-                "1e-25 either way." % (self.header, self.quality))
+        return ("Sequence %s has a quality score of %d; this backend encodes scores up to 254 (an error probability of "
+                "4e-26). Cap the scores in the .qual file (e.g. at 93, the FASTQ maximum) and run again: a capped score "
+                "changes an error probability that is below 1e-25 either way." % (self.header, self.quality))
 
 
 class ReadTooLongError(UnsupportedReadError):
@@ -158,9 +156,7 @@ def build_parser():
     p = argparse.ArgumentParser(
         description="Perform quality filtering on a set of sequences.",
         epilog="Limits of this build (a run that meets one stops with a message and leaves no partial output): the "
-               "poisson_binomial methods score reads of up to 16383 bases (--error_calc poisson: any length); "
-               "--error_calc poisson takes quality scores up to 254 (poisson_binomial: any score; FASTQ input never "
-               "has one above 222, a .qual file can).")
+               "poisson_binomial methods score reads of up to 16383 bases (--error_calc poisson: any length).")
     g = p.add_argument_group("General options")
     g.add_argument("-ff", "--forward_fasta", type=str, help="Forward fasta file (can be gzip or bzip2 compressed).")
     g.add_argument("-fq", "--forward_qual", type=str, help="Forward qual file (can be gzip or bzip2 compressed).")
@@ -559,6 +555,7 @@ def make_gpu_backend(device=None):
     backend.engine = eng
     backend.matrix = matrix
     backend.per_read = eng.calculate_errors_PB         # any int quality (a read whose scores do not fit the byte matrix)
+    backend.per_read_poisson = eng.calculate_errors_poisson
     backend.methods = ("poisson_binomial", "poisson")
     return backend
 
@@ -592,17 +589,30 @@ def process_chunk(records, args, backend):
         if args.error_calc in ("poisson_binomial", "poisson_binomial_py", "poisson") and getattr(backend, "methods", None):
             for i, ql in enumerate(quals):                   # the packed matrix holds one byte per base
                 if not isinstance(ql, QualStr) and len(ql) and int(max(ql)) > 254:
-                    if args.error_calc == "poisson" or not getattr(backend, "per_read", None):
+                    if not getattr(backend, "per_read_poisson" if args.error_calc == "poisson" else "per_read", None):
                         raise QualityTooHighError(records[i][0], int(max(ql)))
                     big.append(i)
+        bset = set(big)
+        bq = [[min(int(v), 254) for v in ql] if i in bset else ql for i, ql in enumerate(quals)] if big else quals
+
+        def per_read(fn):
+            # a .qual file may hold any integer and the reference takes it (moira/bernoullimodule.c:92-108,
+            # moira/moira.py:1637-1679): such a read goes through the per-read entry (its own code table for that
+            # call); the batch saw a capped stand-in
+            for i in big:
+                try:
+                    e, ns = fn(seqs[i], [int(v) for v in quals[i]], args.alpha)
+                except OverflowError:                       # the Poisson function's own failure: NaN, as in the batch
+                    e, ns = float("nan"), 0
+                if args.ambigs == "treat_as_errors":                                    # moira.py:826-827
+                    e = e + ns
+                if args.round:                                                          # moira.py:828-829
+                    e = math.floor(e)
+                ee[i] = float(e)
         if args.error_calc in ("poisson_binomial", "poisson_binomial_py"):
             for i, sq in enumerate(seqs):
                 if len(sq) > MAX_PB_LEN:
                     raise ReadTooLongError(records[i][0], len(sq))
-            # a .qual file may hold any integer and the reference takes it (moira/bernoullimodule.c:92-108): such a read
-            # goes through the per-read entry (its own code table for that call); the batch sees a capped stand-in
-            bset = set(big)
-            bq = [[min(int(v), 254) for v in ql] if i in bset else ql for i, ql in enumerate(quals)] if big else quals
             if getattr(args, "fast_discard", False) and not args.collapse and args.pipeline == "mothur" \
                     and "poisson" in getattr(backend, "methods", ()):
                 ee = backend(seqs, bq, args.alpha, args.ambigs, args.round,
@@ -610,15 +620,10 @@ def process_chunk(records, args, backend):
             else:
                 ee = backend(seqs, bq, args.alpha, args.ambigs, args.round)            # includes +Ns / floor
             ee = [float(x) for x in ee]
-            for i in big:
-                e, ns = backend.per_read(seqs[i], [int(v) for v in quals[i]], args.alpha)
-                if args.ambigs == "treat_as_errors":                                    # moira.py:826-827
-                    e = e + ns
-                if args.round:                                                          # moira.py:828-829
-                    e = math.floor(e)
-                ee[i] = float(e)
+            per_read(getattr(backend, "per_read", None))
         elif args.error_calc == "poisson" and "poisson" in getattr(backend, "methods", ()):
-            ee = [float(x) for x in backend(seqs, quals, args.alpha, args.ambigs, args.round, method="poisson")]
+            ee = [float(x) for x in backend(seqs, bq, args.alpha, args.ambigs, args.round, method="poisson")]
+            per_read(getattr(backend, "per_read_poisson", None))
         elif args.error_calc == "poisson":
             raise RuntimeError("this backend has no Poisson method (the HIP library provides it; there is no CPU path)")
         else:

@@ -979,7 +979,7 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
         if (e != hipSuccess) { drain_pipeline(c); return fail(MPB_E_HIP, "host pipeline (H2D): %s", hipGetErrorString(e)); }
         if (poisson) {
             Span t(c, MPB_K_LAMBDA);
-            mpb_launch_lambda(d_q, m, row_stride, len ? d_len : nullptr, fixed_len, c->d_lut, d_ee, d_ns, c->ws.ovf_count, c->stream);
+            mpb_launch_lambda(d_q, m, row_stride, len ? d_len : nullptr, fixed_len, c->ws.lut, d_ee, d_ns, c->ws.ovf_count, c->stream);
             rc = hipGetLastError() == hipSuccess ? MPB_OK : fail(MPB_E_HIP, "k_lambda launch failed");
         } else {
             rc = mpb_filter_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, params, d_ee, d_ns, d_pass, nullptr);
@@ -1074,6 +1074,65 @@ int mpb_host_free(mpb_ctx *c, void *hptr)
     return MPB_OK;
 }
 
+// One read of the per-read entries -> a packed row.  A score the byte codes cannot express borrows a code the read does
+// not use, from 254 down (the row predictor reads codes as scores, and up there every code means "practically never
+// wrong"), and h -- a copy of the context's table -- gets {1-p, p'} of the real score under that code (*priv = true):
+// the reference takes any int (moira/bernoullimodule.c:92-108, moira/moira.py:1637-1679) and one read holds few
+// distinct values.  poisson: the Python function's rules -- 'n' is a base like any other (moira.py:1660), Q0 is p = 1
+// (no clamp inside the function; it too gets a private code), and the second table component is p itself.
+static int pack_one_read(const char *contig, const int32_t *quals, int32_t len, bool poisson, uint8_t *row, int32_t row_bytes,
+                         double2 *h, bool *priv)
+{
+    *priv = false;
+    auto direct = [&](int32_t q) { return poisson ? (q >= 1 && q <= 254) : q <= 254; };
+    bool used[256] = {};
+    for (int32_t i = 0; i < len; i++) {
+        const int32_t q = quals[i];
+        if (q < 0) return fail(MPB_E_RANGE, "Qualities must have positive values.");
+        if (direct(q)) used[q == 0 ? 1 : q] = true; else *priv = true;
+    }
+    if (*priv) build_lut(h);
+    std::unordered_map<int32_t, int> code_of;
+    int next = 254;
+    for (int32_t i = 0; i < len; i++) {
+        const int32_t q = quals[i];
+        char base = contig ? contig[i] : 'A';
+        if (poisson && base == 'n') base = 'A';
+        if (direct(q)) { row[i] = pack_one(base, q); continue; }
+        auto it = code_of.find(q);
+        if (it == code_of.end()) {
+            while (next >= 1 && used[next]) next--;
+            if (next < 1) return fail(MPB_E_RANGE, "more than 254 distinct quality values in one read, some outside 1..254");
+            used[next] = true;
+            lut_entry(q, &h[next]);
+            if (poisson) { volatile double p = pow(10, (q / -10.0)); h[next].y = p; }     // (1 - p is 0 at Q0: p' is not p there)
+            it = code_of.emplace(q, next).first;
+        }
+        row[i] = pack_one(base, it->second);
+    }
+    memset(row + len, 0, (size_t)(row_bytes - len));
+    return MPB_OK;
+}
+
+// The kernels of one call run on a private copy of the table; the context's own is back in place when the call returns.
+struct PrivateTable {
+    mpb_ctx *c;
+    bool on = false;
+    explicit PrivateTable(mpb_ctx *ctx) : c(ctx) {}
+    int install(const double2 *h)
+    {
+        int rc = ensure_workspace(c, 1);
+        if (rc) return rc;
+        if (!c->d_lut_private) HIPCHK(hipMalloc((void **)&c->d_lut_private, 256 * sizeof(double2)));
+        HIPCHK(hipMemcpyAsync(c->d_lut_private, h, 256 * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));             // h lives on the caller's stack
+        c->ws.lut = c->d_lut_private;
+        on = true;
+        return MPB_OK;
+    }
+    ~PrivateTable() { if (on) c->ws.lut = c->d_lut; }
+};
+
 int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *contig_quals, int32_t len,
                             double alpha, double *ee, int32_t *ns)
 {
@@ -1089,50 +1148,13 @@ int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *conti
     mpb_filter_params prm;
     prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
     uint8_t pass = 0;
-    bool big = false;
-    for (int32_t i = 0; i < len; i++) {
-        if (contig_quals[i] < 0) return fail(MPB_E_RANGE, "Qualities must have positive values.");
-        big = big || contig_quals[i] > 254;
-    }
-    if (!big) {
-        int rc = mpb_pack_read(contig, contig_quals, len, row.data(), stride);
-        if (rc) return rc;
-        return mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
-    }
-    // A quality above 254 has no byte code, and the reference takes any int (bernoullimodule.c:92-108).  One read holds
-    // few distinct values, so for this call each such value borrows a byte code the read does not use (from 254 down:
-    // the row predictor reads the code as a quality, and up there every code means "practically never wrong") and the
-    // kernels get a private copy of the table with {1-p, p'} of the real value under that code.
+    bool priv = false;
     double2 h[256];
-    build_lut(h);
-    bool used[256] = {};
-    for (int32_t i = 0; i < len; i++)
-        if (contig_quals[i] <= 254) used[contig_quals[i] == 0 ? 1 : contig_quals[i]] = true;
-    std::unordered_map<int32_t, int> code_of;
-    int next = 254;
-    for (int32_t i = 0; i < len; i++) {
-        const int32_t q = contig_quals[i];
-        const char base = contig ? contig[i] : 'A';
-        if (q <= 254) { row[(size_t)i] = pack_one(base, q); continue; }
-        auto it = code_of.find(q);
-        if (it == code_of.end()) {
-            while (next >= 1 && used[next]) next--;
-            if (next < 1) return fail(MPB_E_RANGE, "more than 254 distinct quality values in one read, some above 254");
-            used[next] = true;
-            lut_entry(q, &h[next]);
-            it = code_of.emplace(q, next).first;
-        }
-        row[(size_t)i] = pack_one(base, it->second);
-    }
-    int rc = ensure_workspace(c, 1);
+    int rc = pack_one_read(contig, contig_quals, len, false, row.data(), stride, h, &priv);
     if (rc) return rc;
-    if (!c->d_lut_private) HIPCHK(hipMalloc((void **)&c->d_lut_private, sizeof(h)));
-    HIPCHK(hipMemcpyAsync(c->d_lut_private, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));                 // h is on this stack
-    c->ws.lut = c->d_lut_private;
-    rc = mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
-    c->ws.lut = c->d_lut;
-    return rc;
+    PrivateTable guard(c);
+    if (priv && (rc = guard.install(h)) != MPB_OK) return rc;
+    return mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
 }
 
 int mpb_decode_ascii_device(mpb_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, int64_t n, int64_t row_stride,
@@ -1165,7 +1187,7 @@ int mpb_poisson_lambda_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(c->ws.ovf_count, 0, sizeof(int32_t), c->stream));
     { Span t(c, MPB_K_LAMBDA);
-      mpb_launch_lambda(d_q, n, row_stride, d_len, fixed_len, c->d_lut, d_lambda, d_ns, c->ws.ovf_count, c->stream); }
+      mpb_launch_lambda(d_q, n, row_stride, d_len, fixed_len, c->ws.lut, d_lambda, d_ns, c->ws.ovf_count, c->stream); }
     HIPCHK(hipGetLastError());
     int32_t bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, c->ws.ovf_count, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
@@ -1304,6 +1326,31 @@ int mpb_filter_poisson_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row
     // the same four-slot pipeline as mpb_filter_host: H2D of chunk k+1 | k_lambda of chunk k | D2H of chunk k-1, and the
     // scalar tail of a chunk runs on the host while the GPU is busy with the chunks after it
     return filter_host_pipeline(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts, 1);
+}
+
+// One read, the twin of moira.py's calculate_errors_poisson(sequence, quals, alpha) -> (expected_errors, Ns)
+// (moira/moira.py:1637-1679): any non-negative int is a score (see pack_one_read), 'n' is a base, Q0 is p = 1.
+// ee is NaN where the Python function raises OverflowError (Lambda ** j or the factorial leave the float range).
+int mpb_calculate_errors_poisson(mpb_ctx *c, const char *sequence, const int32_t *quals, int32_t len, double alpha,
+                                 double *ee, int32_t *ns)
+{
+    CTXCHK(c);
+    if (!ee || !ns) return fail(MPB_E_INVALID, "NULL output");
+    if (!(alpha > 0 && alpha < 1)) return fail(MPB_E_INVALID, "Alpha must be between 0 and 1");
+    if (len < 0 || (len > 0 && !quals)) return fail(MPB_E_INVALID, "bad arguments");
+    if (sequence && (int32_t)strlen(sequence) != len) return fail(MPB_E_INVALID, "sequence and quals must have the same length");
+    const int32_t stride = (int32_t)align_up(len > 0 ? len : 1, 16);
+    std::vector<uint8_t> row((size_t)stride);
+    mpb_filter_params prm;
+    prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
+    uint8_t pass = 0;
+    bool priv = false;
+    double2 h[256];
+    int rc = pack_one_read(sequence, quals, len, true, row.data(), stride, h, &priv);
+    if (rc) return rc;
+    PrivateTable guard(c);
+    if (priv && (rc = guard.install(h)) != MPB_OK) return rc;
+    return mpb_filter_poisson_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
 }
 
 // ---- one host process, several GPUs ("one host thread (or process) + one HIP stream per device") ----

@@ -294,6 +294,24 @@ class Engine:
                                                  C.byref(ee), C.byref(ns)))
         return ee.value, ns.value
 
+    def calculate_errors_poisson(self, sequence, quals, alpha):
+        """Twin of moira.py's calculate_errors_poisson(sequence, quals, alpha) -> (expected_errors, Ns)
+        (moira/moira.py:1637-1679): lambda summed on the GPU in base order, the scalar tail on the host.  Any
+        non-negative int is a score; OverflowError where the Python function raises it."""
+        sequence = str(sequence)
+        qi = np.array([int(v) for v in quals], np.int64).astype(np.int32) if len(quals) else np.empty(0, np.int32)
+        alpha = float(alpha)
+        if len(sequence) != len(qi):
+            raise ValueError("sequence and quals must have the same length")
+        if alpha <= 0 or alpha >= 1:                           # (the bare Python function also takes alpha == 1)
+            raise ValueError("Alpha must be between 0 (not included) and 1.")
+        ee, ns = C.c_double(), C.c_int32()
+        L.check(self.lib.mpb_calculate_errors_poisson(self.ctx, sequence.encode(), qi.ctypes.data, len(qi), alpha,
+                                                      C.byref(ee), C.byref(ns)))
+        if ee.value != ee.value:
+            raise OverflowError("Lambda ** expected_errors or its factorial leaves the float range (moira.py:1671)")
+        return ee.value, ns.value
+
     # ---- synthetic workload -----------------------------------------------------------------------
     def synth_fill(self, d_q, n, stride, fixed_len=0, min_len=0, max_len=0, d_len=None, seed=1, first_read=0):
         ptr = lambda b: (b.ptr if isinstance(b, DeviceBuffer) else b)

@@ -85,6 +85,9 @@ class MultiEngine:
     def calculate_errors_PB(self, contig, contig_quals, alpha):
         return self.engines[0].calculate_errors_PB(contig, contig_quals, alpha)
 
+    def calculate_errors_poisson(self, sequence, quals, alpha):
+        return self.engines[0].calculate_errors_poisson(sequence, quals, alpha)
+
     def _run(self, poisson, q, lens, fixed_len, out, kw):
         import ctypes as C
         from . import _lib as L

@@ -364,7 +364,14 @@ def make_bigq_fixture(ref, pyref):
         ub = int(rows == 1)                      # the C reference reads accumulated_probs[-1] there: the twin's value is pinned
         if not ub:
             assert e == ep, (seq, quals, alpha, e, ep)
-        reads.append({"seq": seq, "quals": quals, "alpha": alpha, "ee": float(ep).hex(), "ns": int(s), "ub": ub})
+        # the Poisson approximation of the same read (moira/moira.py:1637-1679; only 'N' is skipped there)
+        try:
+            pe, pn = pyref.calculate_errors_poisson(seq, quals, alpha)
+            pe = float(pe).hex()
+        except OverflowError:
+            pe, pn = None, seq.count("N")
+        reads.append({"seq": seq, "quals": quals, "alpha": alpha, "ee": float(ep).hex(), "ns": int(s), "ub": ub,
+                      "poisson_ee": pe, "poisson_ns": int(pn)})
 
     for k in range(90):
         L = int(rng.integers(1, 220))
@@ -384,6 +391,8 @@ def make_bigq_fixture(ref, pyref):
     add("A" * 500, list(range(1, 201)) + [1000 + i for i in range(54)] + [3] * 246, 0.005)    # 254 distinct values in all
     add("ANnA", [5000, 5000, 5000, 2], 0.005)
     add("A", [2 ** 31 - 1], 0.5)
+    add("ACGTNACGT", [0, 300, 0, 12, 0, 0, 40, 1000, 7], 0.05)                 # Q0: clamped by the extension, p = 1 for the Poisson function
+    add("A" * 300, [1] * 280 + [400] * 20, 0.005)                               # Lambda ~ 222: the Poisson function overflows
     out = os.path.join(HERE, "bigq.json")
     json.dump({"source": "oracle/_ref/bernoulli.so (moira/bernoullimodule.c unmodified) and the Python twin of moira/moira.py:1561-1634; "
                          "ub = 1: the C reference's value is undefined (bernoullimodule.c:254), the twin's is stored",

@@ -57,3 +57,12 @@ def bigq_fixture():
     import json
     d = json.load(open(os.path.join(GOLDEN, "bigq.json")))
     return [(r["seq"], r["quals"], r["alpha"], float.fromhex(r["ee"]), r["ns"], r["ub"]) for r in d["reads"]]
+
+
+def bigq_poisson_fixture():
+    """[(seq, quals, alpha, ee or None, ns)]: the same reads through the reference's calculate_errors_poisson
+    (None: the function raised OverflowError)."""
+    import json
+    d = json.load(open(os.path.join(GOLDEN, "bigq.json")))
+    return [(r["seq"], r["quals"], r["alpha"], None if r["poisson_ee"] is None else float.fromhex(r["poisson_ee"]), r["poisson_ns"])
+            for r in d["reads"]]

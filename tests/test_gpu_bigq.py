@@ -36,6 +36,41 @@ def test_reference_vectors_with_big_scores(eng):
     assert all(a[q] == lut[q][1] and b[q] == lut[q][2] for q in lut)
 
 
+def test_reference_vectors_with_big_scores_poisson(eng):
+    """The same reads through the reference's calculate_errors_poisson (moira/moira.py:1637-1679): any int is a score,
+    Q0 is p = 1 inside the function, 'n' is a base, OverflowError where Lambda ** j leaves the float range."""
+    from poisson_ref import calculate_errors_poisson
+    reads = G.bigq_poisson_fixture()
+    assert sum(1 for r in reads if r[3] is None) >= 1
+    for seq, quals, alpha, ee, ns in reads:
+        if ee is None:
+            with pytest.raises(OverflowError):
+                eng.calculate_errors_poisson(seq, quals, alpha)
+        else:
+            assert eng.calculate_errors_poisson(seq, quals, alpha) == (ee, ns), (seq, quals, alpha)
+    # ordinary scores take the same entry (no private table): against the restated formula
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        L = int(rng.integers(0, 500))
+        quals = rng.integers(0, 60, L).tolist()
+        seq = "".join(rng.choice(list("ACGTNn"), L, p=[0.24, 0.24, 0.24, 0.24, 0.03, 0.01])) if L else ""
+        alpha = float(rng.choice([0.005, 0.05, 0.3]))
+        try:
+            want = calculate_errors_poisson(seq, quals, alpha)
+        except OverflowError:
+            with pytest.raises(OverflowError):
+                eng.calculate_errors_poisson(seq, quals, alpha)
+            continue
+        assert eng.calculate_errors_poisson(seq, quals, alpha) == want, (seq, quals, alpha)
+    with pytest.raises(ValueError):
+        eng.calculate_errors_poisson("ACGT", [30, -1, 30, 30], 0.005)
+    with pytest.raises(ValueError):
+        eng.calculate_errors_poisson("ACGT", [30, 30, 30], 0.005)
+    # afterwards the batch entry still sums with the context's own table
+    q, lens = eng.pack(["ACGT" * 5], [[20] * 20], 32)
+    assert eng.filter_poisson(q, lens=lens, alpha=0.005, ambigs="ignore", uncert=1.0).ee[0] == calculate_errors_poisson("ACGT" * 5, [20] * 20, 0.005)[0]
+
+
 def test_big_scores_on_every_path_against_the_oracle(eng, oracle):
     """Random reads: short (one read per wave), long rows, and more than 1024 DP rows (k_wide) -- each with a few scores
     between 255 and 2^31 - 1, with and without ambiguous bases."""
@@ -98,7 +133,12 @@ def test_cli_scores_a_qual_file_with_big_scores(tmp_path, oracle):
         assert (("r%d" % k) in good) == (not (e > 0.02 * len(seq))), k        # moira.py:887 `expected_errors > maxerrors`
     text = open(out + ".qc.good.qual").read() + open(out + ".qc.bad.qual").read()
     assert " 300 " in text or " 255 " in text or " 4000 " in text
-    msg = io.StringIO()
+    # --error_calc poisson on the same files: decisions of the reference's formula
+    from poisson_ref import calculate_errors_poisson
     a = reference_args(paired=False, forward_fasta=str(fa), forward_qual=str(qu), output_prefix=out + "p", collapse=False,
-                       error_calc="poisson", silent=True)
-    assert cli.main(a, out=msg) == 1 and "poisson_binomial" in msg.getvalue()
+                       error_calc="poisson", uncert=0.02)
+    assert cli.main(a, out=open(os.devnull, "w")) == 0
+    good = {l[1:].split("\t")[0].strip() for l in open(out + "p.qc.good.fasta") if l.startswith(">")}
+    for k, (seq, quals) in enumerate(recs):
+        e, ns = calculate_errors_poisson(seq, quals, 0.005)
+        assert (("r%d" % k) in good) == (not (e > 0.02 * len(seq))), k

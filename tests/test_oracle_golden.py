@@ -191,3 +191,15 @@ def test_oracle_takes_qualities_above_254_as_the_reference_does(oracle):
             assert s == ns and (rows == 1) == bool(ub)
             if not ub or fn is oracle.ee_rowwise:           # the reference-shaped loop nest shares the C reference's UB case
                 assert e == ee, (seq, quals, alpha)
+
+
+def test_poisson_restatement_on_big_scores():
+    """oracle/poisson_ref.py against the reference function's results on the big-score reads (Q0 = p 1, 'n' a base,
+    OverflowError where the reference raises it)."""
+    from poisson_ref import calculate_errors_poisson
+    for seq, quals, alpha, ee, ns in G.bigq_poisson_fixture():
+        if ee is None:
+            with pytest.raises(OverflowError):
+                calculate_errors_poisson(seq, quals, alpha)
+        else:
+            assert calculate_errors_poisson(seq, quals, alpha) == (ee, ns)
