@@ -429,6 +429,9 @@ class GzipReader:
         offs, sizes, out_offs, why = self._bg
         while True:
             if self.in_pos == self.in_len and not self._more_input():
+                if not self.bgzf_batches:                      # no member at all: the serial decoder's error
+                    self.bgzf = False
+                    return None
                 self.done = True                               # ended on a member boundary
                 return b""
             nb = self.L.mio_bgzf_scan(self.inbuf.ctypes.data + self.in_pos, self.in_len - self.in_pos, len(offs), n,

@@ -221,6 +221,8 @@ def test_bgzf_input_on_several_threads(threads):
     assert decode_mt(BGZF_EOF, threads) == (b"", 1 if threads > 1 else 0)
     assert decode_mt(bgzf_compress(text), threads)[0] == text
     assert decode_mt(z + b"\0" * 1000, threads)[0] == text
+    with pytest.raises(OSError):
+        decode_mt(b"", threads)
 
 
 def test_bgzf_mixed_with_ordinary_members():
