@@ -1179,6 +1179,7 @@ int mpb_poisson_lambda_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t
 {
     CTXCHK(c);
     if (n < 0 || row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "bad matrix shape");
+    if (row_stride > MPB_LAMBDA_MAX_STRIDE) return fail(MPB_E_INVALID, "row_stride %lld exceeds %d", (long long)row_stride, MPB_LAMBDA_MAX_STRIDE);
     if (((uintptr_t)d_q & 15) != 0) return fail(MPB_E_INVALID, "quality matrix must be 16-byte aligned");
     if (!d_len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len does not fit row_stride");
     if (n == 0) return MPB_OK;
@@ -1315,6 +1316,7 @@ int mpb_filter_poisson_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row
     int rc = check_params(params);
     if (rc) return rc;
     if (n < 0 || row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "bad matrix shape");
+    if (row_stride > MPB_LAMBDA_MAX_STRIDE) return fail(MPB_E_INVALID, "row_stride %lld exceeds %d", (long long)row_stride, MPB_LAMBDA_MAX_STRIDE);
     if (n > 0 && (!q || !ee || !ns || !pass)) return fail(MPB_E_INVALID, "NULL host buffer");
     if (!len && (fixed_len < 0 || fixed_len > row_stride)) return fail(MPB_E_INVALID, "fixed_len does not fit row_stride");
     if (len)

@@ -106,6 +106,7 @@ struct MpbWorkspace {
 };
 
 #define MPB_LUT_BYTES   (256 * 16)
+#define MPB_LAMBDA_MAX_STRIDE (1 << 24)     // k_lambda addresses the 64 rows of a wave with 32-bit byte offsets
 
 // Launch wrappers (mpb_kernels.hip).  All asynchronous on `s`.
 void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,

@@ -13,7 +13,7 @@ import numpy as np  # noqa: E402
 from moira_amd.engine import Engine  # noqa: E402
 from moira_amd import _lib as L  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10_000_000
 stride, Lr = 320, 300
 with Engine(0) as eng:
     d_q, d_lam, d_ns = eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4)
@@ -29,6 +29,8 @@ with Engine(0) as eng:
     ms /= cnt
     print("k_lambda: %.3f ms per %d reads = %.3e reads/s = %.2f TB/s of qualities (%.1f%% of the 8 TB/s roof)"
           % (ms, n, n / ms * 1e3, n * stride / ms / 1e9, 100 * n * (Lr + 12) / (ms * 1e-3) / 8e12))
+    if "--device-only" in sys.argv:
+        sys.exit(0)
     lam, ns = d_lam.download(np.float64, n), d_ns.download(np.int32, n)
     ee, ps = np.empty(n), np.empty(n, np.uint8)
     prm = eng.params()
