@@ -138,6 +138,28 @@ def test_crc32_is_zlibs():
     a = rng.integers(0, 256, 5000, dtype=np.uint8)
     c = L.mio_crc32(0, a.ctypes.data, 1234)
     assert L.mio_crc32(c, a.ctypes.data + 1234, 5000 - 1234) == zlib.crc32(a.tobytes())
+    # the carry-less-multiply form folds 64 bytes per step from 128 bytes on: every length around its boundaries, odd
+    # starting offsets, non-zero starting values
+    b = rng.integers(0, 256, 70_000, dtype=np.uint8)
+    raw = b.tobytes()
+    for n in list(range(100, 340)) + [4095, 4096, 4097, 65_535, 65_536, 69_990]:
+        for off in (0, 1, 5):
+            for init in (0, 0xDEADBEEF):
+                assert L.mio_crc32(init, b.ctypes.data + off, n) == zlib.crc32(raw[off:off + n], init), (n, off, init)
+
+
+def test_crc32_table_form_is_the_same():
+    """MOIRA_CRC_TABLES=1 keeps the slice-by-8 form (what a CPU without PCLMULQDQ runs): same values, in a fresh process."""
+    import subprocess
+    import sys
+    code = ("import zlib, numpy as np; from moira_amd import fastio as F; L = F.load(); "
+            "a = np.random.default_rng(5).integers(0, 256, 300000, dtype=np.uint8); "
+            "assert all(L.mio_crc32(0, a.ctypes.data + o, n) == zlib.crc32(a.tobytes()[o:o + n]) for n in (0, 5, 127, 128, 200, 299000) for o in (0, 3)); "
+            "print('ok')")
+    for env_extra in ({"MOIRA_CRC_TABLES": "1"}, {}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
 
 
 def test_large_file_and_rate(tmp_path):
