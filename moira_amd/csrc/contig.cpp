@@ -167,33 +167,49 @@ void nw_diagonal(const int16_t *__restrict d2, const int16_t *__restrict d1, int
 // The whole fill, diagonal by diagonal, in one function per instruction set: a 2 x 250-base pair has 500 diagonals of
 // 125 cells on average, so a call through a pointer per diagonal (re-broadcasting the three scores each time) cost as
 // much as the cells themselves.  base[d] as in nw_align_diag; s2r = seq_2 reversed.
-typedef void (*nw_fill_fn)(int16_t *S, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
-                           int16_t match, int16_t mismatch, int16_t gap);
+// Scores are kept for three diagonals only (R[0..2], indexed by the row i of a cell, rotated): a cell needs its two
+// predecessors' diagonals and nothing else, and the traceback rebuilds the scores along its path from the pointers (see
+// nw_align_diag).  What has to survive is the last column and the last row (the 3' fix-up scans them and the path may run
+// along them): lastcol[i] = S(i, n2), lastrow[j] = S(n1, j), captured as their diagonals are finished.  Storing 2 bytes of
+// score per cell on top of the pointer byte was three quarters of the fill's memory traffic (270 KB per 2 x 300 pair,
+// L2-resident): the fill was bound by it.
+typedef void (*nw_fill_fn)(int16_t *R, int rstride, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
+                           int16_t match, int16_t mismatch, int16_t gap, int16_t *lastcol, int16_t *lastrow);
 
-void nw_fill_generic(int16_t *S, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
-                     int16_t match, int16_t mismatch, int16_t gap)
+// rotate the three diagonal buffers for diagonal d, seed its border cells, and after the diagonal record what belongs
+// to the last column / row
+#define NW_DIAG_BEGIN                                                                                              \
+        int16_t *const cur = R + (size_t)(d % 3) * rstride;                                                       \
+        const int16_t *const d1 = R + (size_t)((d + 2) % 3) * rstride, *const d2 = R + (size_t)((d + 1) % 3) * rstride; \
+        if (d <= n2) cur[0] = 0;                                 /* cell (0, d) */                                 \
+        if (d <= n1) cur[d] = 0;                                 /* cell (d, 0) */
+#define NW_DIAG_END                                                                                                \
+        if (d > n2 && d - n2 <= n1) lastcol[d - n2] = cur[d - n2];          /* cell (d - n2, n2), row >= 1 */       \
+        if (d > n1 && d - n1 <= n2) lastrow[d - n1] = cur[n1];              /* cell (n1, d - n1), column >= 1 */
+
+void nw_fill_generic(int16_t *R, int rstride, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
+                     int16_t match, int16_t mismatch, int16_t gap, int16_t *lastcol, int16_t *lastrow)
 {
     const int D = n1 + n2;
     for (int d = 2; d <= D; d++) {
+        NW_DIAG_BEGIN
         const int ilo = d - n2 > 1 ? d - n2 : 1, ihi = d - 1 < n1 ? d - 1 : n1;
-        if (ilo > ihi) continue;
         // b[i] = s2[(d - i) - 1] = s2r[n2 - d + i]
-        nw_diagonal(S + base[d - 2], S + base[d - 1], S + base[d], P + base[d], A, s2r + (n2 - d), ilo, ihi, match, mismatch, gap);
+        if (ilo <= ihi) nw_diagonal(d2, d1, cur, P + base[d], A, s2r + (n2 - d), ilo, ihi, match, mismatch, gap);
+        NW_DIAG_END
     }
 }
 
 __attribute__((target("avx512f,avx512bw,avx512vl")))
-void nw_fill_avx512(int16_t *S, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
-                    int16_t match, int16_t mismatch, int16_t gap)
+void nw_fill_avx512(int16_t *R, int rstride, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
+                    int16_t match, int16_t mismatch, int16_t gap, int16_t *lastcol, int16_t *lastrow)
 {
     const __m512i vmatch = _mm512_set1_epi16(match), vmis = _mm512_set1_epi16(mismatch), vgap = _mm512_set1_epi16(gap);
     const __m512i one = _mm512_set1_epi16(PTR_UP), two = _mm512_set1_epi16(PTR_LEFT), zero = _mm512_setzero_si512();
     const int D = n1 + n2;
     for (int d = 2; d <= D; d++) {
+        NW_DIAG_BEGIN
         const int ilo = d - n2 > 1 ? d - n2 : 1, ihi = d - 1 < n1 ? d - 1 : n1;
-        if (ilo > ihi) continue;
-        const int16_t *d2 = S + base[d - 2], *d1 = S + base[d - 1];
-        int16_t *cur = S + base[d];
         uint8_t *ptr = P + base[d];
         const char *b = s2r + (n2 - d);
         for (int i = ilo; i <= ihi; i += 32) {
@@ -212,22 +228,21 @@ void nw_fill_avx512(int16_t *S, uint8_t *P, const int64_t *base, const char *A, 
             p = _mm512_mask_blend_epi16(left, p, two);
             _mm256_mask_storeu_epi8(ptr + i, k, _mm512_cvtepi16_epi8(p));
         }
+        NW_DIAG_END
     }
 }
 
 // AVX2: 16 cells per instruction, the remainder of a diagonal cell by cell
 __attribute__((target("avx2")))
-void nw_fill_avx2(int16_t *S, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
-                  int16_t match, int16_t mismatch, int16_t gap)
+void nw_fill_avx2(int16_t *R, int rstride, uint8_t *P, const int64_t *base, const char *A, const char *s2r, int n1, int n2,
+                  int16_t match, int16_t mismatch, int16_t gap, int16_t *lastcol, int16_t *lastrow)
 {
     const __m256i vmatch = _mm256_set1_epi16(match), vmis = _mm256_set1_epi16(mismatch), vgap = _mm256_set1_epi16(gap);
     const __m256i one = _mm256_set1_epi16(PTR_UP), two = _mm256_set1_epi16(PTR_LEFT);
     const int D = n1 + n2;
     for (int d = 2; d <= D; d++) {
+        NW_DIAG_BEGIN
         const int ilo = d - n2 > 1 ? d - n2 : 1, ihi = d - 1 < n1 ? d - 1 : n1;
-        if (ilo > ihi) continue;
-        const int16_t *d2 = S + base[d - 2], *d1 = S + base[d - 1];
-        int16_t *cur = S + base[d];
         uint8_t *ptr = P + base[d];
         const char *b = s2r + (n2 - d);
         int i = ilo;
@@ -255,6 +270,7 @@ void nw_fill_avx2(int16_t *S, uint8_t *P, const int64_t *base, const char *A, co
             cur[i] = lf > mx ? lf : mx;
             ptr[i] = lf > mx ? (uint8_t)PTR_LEFT : (dg >= up ? (uint8_t)PTR_DIAG : (uint8_t)PTR_UP);
         }
+        NW_DIAG_END
     }
 }
 
@@ -275,9 +291,9 @@ nw_fill_fn pick_fill()
 }
 
 struct DiagScratch {
-    std::vector<int16_t> score;
+    std::vector<int16_t> score;     // three diagonals + the last column + the last row
     std::vector<uint8_t> ptr;
-    std::vector<int64_t> base;      // base[d]: index of cell (i, d - i) is base[d] + i
+    std::vector<int64_t> base;      // base[d]: index of cell (i, d - i) in ptr is base[d] + i
     std::vector<char> s2r;
 };
 
@@ -293,29 +309,36 @@ int nw_align_diag(const char *s1, int n1, const char *s2, int n2, int match, int
         sc.base[d] = total - lo;
         total += hi - lo + 1;
     }
-    // Only the first row and column are initialised (scored 0; the column points up, the row left, :64-76): every
-    // other cell is written by the fill before anything reads it, and clearing 3 bytes per cell of a 250 x 250
-    // matrix for every pair cost a third of the alignment.
-    if (sc.score.size() < (size_t)total + 40) { sc.score.resize((size_t)total + 40); sc.ptr.resize((size_t)total + 40); }
-    int16_t *S = sc.score.data();
+    // Only the first row and column of the pointer matrix are initialised (the column points up, the row left, :64-76):
+    // every other cell is written by the fill before anything reads it, and clearing the matrix for every pair cost a
+    // third of the alignment.
+    if (sc.ptr.size() < (size_t)total + 40) sc.ptr.resize((size_t)total + 40);
+    const int rstride = n1 + 72;                         // one diagonal, indexed by row 0..n1 (+ a vector of slack)
+    const size_t need = (size_t)3 * rstride + (size_t)n1 + (size_t)n2 + 80;
+    if (sc.score.size() < need) sc.score.resize(need);
+    int16_t *R = sc.score.data();
+    int16_t *lastcol = R + (size_t)3 * rstride, *lastrow = lastcol + n1 + 8;
     uint8_t *P = sc.ptr.data();
-    for (int i = 0; i <= n1; i++) { S[sc.base[i] + i] = 0; P[sc.base[i] + i] = PTR_UP; }          // cells (i, 0)
-    for (int j = 1; j <= n2; j++) { S[sc.base[j] + 0] = 0; P[sc.base[j] + 0] = PTR_LEFT; }        // cells (0, j)
+    for (int i = 0; i <= n1; i++) { P[sc.base[i] + i] = PTR_UP; lastcol[i] = 0; }                  // cells (i, 0); S(i, n2) until computed
+    for (int j = 1; j <= n2; j++) P[sc.base[j] + 0] = PTR_LEFT;                                   // cells (0, j)
+    for (int j = 0; j <= n2; j++) lastrow[j] = 0;
+    R[0] = 0;                                            // diagonal 0: cell (0, 0)
+    R[rstride] = 0; R[rstride + 1] = 0;                  // diagonal 1: cells (0, 1) and (1, 0)
     sc.s2r.resize((size_t)n2 + 1);
     for (int t = 0; t < n2; t++) sc.s2r[t] = s2[n2 - 1 - t];
     const char *A = s1 - 1;                              // A[i] = s1[i - 1]
     static const nw_fill_fn fill = pick_fill();
-    fill(S, P, sc.base.data(), A, sc.s2r.data(), n1, n2, (int16_t)match, (int16_t)mismatch, (int16_t)gap);
+    fill(R, rstride, P, sc.base.data(), A, sc.s2r.data(), n1, n2, (int16_t)match, (int16_t)mismatch, (int16_t)gap, lastcol, lastrow);
     auto at = [&](int i, int j) { return sc.base[i + j] + i; };
     // 3' overlap fix-up (:155-201): last maximum (>=) of the last column and of the last row
     int best_col_score = -10000, best_col_idx = 0;
     for (int i = 0; i <= n1; i++) {
-        const int c = S[at(i, n2)];
+        const int c = lastcol[i];
         if (c >= best_col_score) { best_col_score = c; best_col_idx = i; }
     }
     int best_row_score = -10000, best_row_idx = 0;
     for (int j = 0; j <= n2; j++) {
-        const int c = S[at(n1, j)];
+        const int c = lastrow[j];
         if (c >= best_row_score) { best_row_score = c; best_row_idx = j; }
     }
     if (best_col_idx == n1 && best_row_idx == n2) {
@@ -325,14 +348,19 @@ int nw_align_diag(const char *s1, int n1, const char *s2, int n2, int match, int
     } else {
         for (int j = n2; j > best_row_idx; j--) P[at(n1, j)] = PTR_LEFT;
     }
-    // traceback (:129-150), filled backwards then reversed
+    // traceback (:129-150), filled backwards then reversed.  The score of the alignment is the sum of the matrix cells on
+    // the path (:136); a cell's value is known where it lies on the border (0), on the last column or row (kept), and
+    // otherwise follows from its successor on the path: the successor's pointer is the fill's own there (the fix-up only
+    // rewrites pointers ON the last column / row, and those lead along it), so S(pred) = S(cell) - what that move scored.
     int i = n1, j = n2, k = 0;
     int32_t score = 0;
+    int32_t tracked = 0;                                 // S(i, j) when the cell is interior
     while (i > 0 || j > 0) {
-        const int64_t c = at(i, j);
-        const uint8_t p = P[c];
-        score += S[c];
+        const uint8_t p = P[at(i, j)];
+        const int32_t here = (i == 0 || j == 0) ? 0 : (j == n2 ? lastcol[i] : (i == n1 ? lastrow[j] : tracked));
+        score += here;
         const bool mv_i = (p == PTR_DIAG || p == PTR_UP), mv_j = (p == PTR_DIAG || p == PTR_LEFT);
+        tracked = here - (p == PTR_DIAG ? (s1[i > 0 ? i - 1 : 0] == s2[j > 0 ? j - 1 : 0] ? match : mismatch) : gap);
         aln1[k] = mv_i ? s1[i - 1] : '-';
         aln2[k] = mv_j ? s2[j - 1] : '-';
         k++;
