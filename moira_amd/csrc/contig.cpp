@@ -245,23 +245,31 @@ void nw_fill_avx2(int16_t *R, int rstride, uint8_t *P, const int64_t *base, cons
         const int ilo = d - n2 > 1 ? d - n2 : 1, ihi = d - 1 < n1 ? d - 1 : n1;
         uint8_t *ptr = P + base[d];
         const char *b = s2r + (n2 - d);
-        int i = ilo;
-        for (; i + 15 <= ihi; i += 16) {
-            const __m128i av = _mm_loadu_si128((const __m128i *)(A + i)), bv = _mm_loadu_si128((const __m128i *)(b + i));
-            const __m256i eq = _mm256_cvtepi8_epi16(_mm_cmpeq_epi8(av, bv));                      // 0xffff where equal
-            const __m256i sub = _mm256_blendv_epi8(vmis, vmatch, eq);
-            const __m256i dg = _mm256_add_epi16(_mm256_loadu_si256((const __m256i *)(d2 + i - 1)), sub);
-            const __m256i up = _mm256_add_epi16(_mm256_loadu_si256((const __m256i *)(d1 + i - 1)), vgap);
-            const __m256i lf = _mm256_add_epi16(_mm256_loadu_si256((const __m256i *)(d1 + i)), vgap);
-            const __m256i mx = _mm256_max_epi16(dg, up);
-            const __m256i left = _mm256_cmpgt_epi16(lf, mx);                                        // lf > mx
-            const __m256i upwins = _mm256_cmpgt_epi16(up, dg);                                      // !(dg >= up)
-            _mm256_storeu_si256((__m256i *)(cur + i), _mm256_max_epi16(lf, mx));
-            __m256i p = _mm256_and_si256(upwins, one);                                              // UP where up > dg, else DIAG (0)
-            p = _mm256_blendv_epi8(p, two, left);
-            const __m256i packed = _mm256_permute4x64_epi64(_mm256_packus_epi16(p, p), 0xd8);       // 16 x u16 -> 16 x u8 (low half)
-            _mm_storeu_si128((__m128i *)(ptr + i), _mm256_castsi256_si128(packed));
+        // 16 cells: 0xffff where the bases are equal; UP where up > diag (else DIAG = 0), LEFT where left beats both; the
+        // 16 pointer words narrowed to bytes through the low half of a pack
+#define NW_AVX2_CELLS(i)                                                                                                \
+        {                                                                                                               \
+            const __m128i av = _mm_loadu_si128((const __m128i *)(A + i)), bv = _mm_loadu_si128((const __m128i *)(b + i));\
+            const __m256i eq = _mm256_cvtepi8_epi16(_mm_cmpeq_epi8(av, bv));                                            \
+            const __m256i sub = _mm256_blendv_epi8(vmis, vmatch, eq);                                                   \
+            const __m256i dg = _mm256_add_epi16(_mm256_loadu_si256((const __m256i *)(d2 + i - 1)), sub);                \
+            const __m256i up = _mm256_add_epi16(_mm256_loadu_si256((const __m256i *)(d1 + i - 1)), vgap);               \
+            const __m256i lf = _mm256_add_epi16(_mm256_loadu_si256((const __m256i *)(d1 + i)), vgap);                   \
+            const __m256i mx = _mm256_max_epi16(dg, up);                                                                \
+            const __m256i left = _mm256_cmpgt_epi16(lf, mx);                                                            \
+            const __m256i upwins = _mm256_cmpgt_epi16(up, dg);                                                          \
+            _mm256_storeu_si256((__m256i *)(cur + i), _mm256_max_epi16(lf, mx));                                        \
+            __m256i p = _mm256_and_si256(upwins, one);                                                                  \
+            p = _mm256_blendv_epi8(p, two, left);                                                                       \
+            const __m256i packed = _mm256_permute4x64_epi64(_mm256_packus_epi16(p, p), 0xd8);                           \
+            _mm_storeu_si128((__m128i *)(ptr + i), _mm256_castsi256_si128(packed));                                     \
         }
+        int i = ilo;
+        for (; i + 15 <= ihi; i += 16) NW_AVX2_CELLS(i)
+        // the rest of the diagonal: one more vector over its LAST 16 cells (cells computed twice get the same values: they
+        // depend on the two finished diagonals only); a diagonal shorter than a vector cell by cell
+        if (i <= ihi && ihi - ilo >= 15) { const int i2 = ihi - 15; NW_AVX2_CELLS(i2) i = ihi + 1; }
+#undef NW_AVX2_CELLS
         for (; i <= ihi; i++) {
             const int16_t dg = (int16_t)(d2[i - 1] + (A[i] == b[i] ? match : mismatch));
             const int16_t up = (int16_t)(d1[i - 1] + gap);
