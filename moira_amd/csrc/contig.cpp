@@ -212,22 +212,49 @@ void nw_fill_avx512(int16_t *R, int rstride, uint8_t *P, const int64_t *base, co
         const int ilo = d - n2 > 1 ? d - n2 : 1, ihi = d - 1 < n1 ? d - 1 : n1;
         uint8_t *ptr = P + base[d];
         const char *b = s2r + (n2 - d);
-        for (int i = ilo; i <= ihi; i += 32) {
-            const int rem = ihi - i + 1;
-            const __mmask32 k = rem >= 32 ? (__mmask32)0xffffffffu : (__mmask32)((1u << rem) - 1u);
-            const __m256i av = _mm256_maskz_loadu_epi8(k, A + i), bv = _mm256_maskz_loadu_epi8(k, b + i);
-            const __mmask32 eq = _mm256_cmpeq_epi8_mask(av, bv);
-            const __m512i dg = _mm512_add_epi16(_mm512_maskz_loadu_epi16(k, d2 + i - 1), _mm512_mask_blend_epi16(eq, vmis, vmatch));
-            const __m512i up = _mm512_add_epi16(_mm512_maskz_loadu_epi16(k, d1 + i - 1), vgap);
-            const __m512i lf = _mm512_add_epi16(_mm512_maskz_loadu_epi16(k, d1 + i), vgap);
-            const __m512i mx = _mm512_max_epi16(dg, up);
-            const __mmask32 left = _mm512_cmpgt_epi16_mask(lf, mx);
-            const __mmask32 diag = _mm512_cmpge_epi16_mask(dg, up);
-            _mm512_mask_storeu_epi16(cur + i, k, _mm512_max_epi16(lf, mx));
-            __m512i p = _mm512_mask_blend_epi16(diag, one, zero);        // DIAG = 0 where diag >= up, else UP
-            p = _mm512_mask_blend_epi16(left, p, two);
-            _mm256_mask_storeu_epi8(ptr + i, k, _mm512_cvtepi16_epi8(p));
+        // whole vectors without masks (a masked 512-bit load / store is the slower instruction), the rest of the diagonal as
+        // one more whole vector over its LAST 32 cells (cells computed twice get the same values: they depend on the two
+        // finished diagonals only); only a diagonal shorter than a vector takes the masked form
+#define NW_AVX512_CELLS(i, LOAD8, LOAD16, STORE16, STORE8)                                                              \
+        {                                                                                                               \
+            const __m256i av = LOAD8(A + (i)), bv = LOAD8(b + (i));                                                     \
+            const __mmask32 eq = _mm256_cmpeq_epi8_mask(av, bv);                                                        \
+            const __m512i dg = _mm512_add_epi16(LOAD16(d2 + (i) - 1), _mm512_mask_blend_epi16(eq, vmis, vmatch));       \
+            const __m512i up = _mm512_add_epi16(LOAD16(d1 + (i) - 1), vgap);                                            \
+            const __m512i lf = _mm512_add_epi16(LOAD16(d1 + (i)), vgap);                                                \
+            const __m512i mx = _mm512_max_epi16(dg, up);                                                                \
+            const __mmask32 left = _mm512_cmpgt_epi16_mask(lf, mx);                                                     \
+            const __mmask32 diag = _mm512_cmpge_epi16_mask(dg, up);                                                     \
+            STORE16(cur + (i), _mm512_max_epi16(lf, mx));                                                               \
+            __m512i p = _mm512_mask_blend_epi16(diag, one, zero);                                                       \
+            p = _mm512_mask_blend_epi16(left, p, two);                                                                  \
+            STORE8(ptr + (i), _mm512_cvtepi16_epi8(p));                                                                 \
         }
+#define NW_L8(ptr_) _mm256_loadu_si256((const __m256i *)(ptr_))
+#define NW_L16(ptr_) _mm512_loadu_si512((const void *)(ptr_))
+#define NW_S16(ptr_, v) _mm512_storeu_si512((void *)(ptr_), v)
+#define NW_S8(ptr_, v) _mm256_storeu_si256((__m256i *)(ptr_), v)
+#define NW_ML8(ptr_) _mm256_maskz_loadu_epi8(k, ptr_)
+#define NW_ML16(ptr_) _mm512_maskz_loadu_epi16(k, ptr_)
+#define NW_MS16(ptr_, v) _mm512_mask_storeu_epi16(ptr_, k, v)
+#define NW_MS8(ptr_, v) _mm256_mask_storeu_epi8(ptr_, k, v)
+        if (ihi - ilo >= 31) {
+            int i = ilo;
+            for (; i + 31 <= ihi; i += 32) NW_AVX512_CELLS(i, NW_L8, NW_L16, NW_S16, NW_S8)
+            if (i <= ihi) { const int i2 = ihi - 31; NW_AVX512_CELLS(i2, NW_L8, NW_L16, NW_S16, NW_S8) }
+        } else if (ilo <= ihi) {
+            const __mmask32 k = (__mmask32)((1ull << (ihi - ilo + 1)) - 1ull);
+            NW_AVX512_CELLS(ilo, NW_ML8, NW_ML16, NW_MS16, NW_MS8)
+        }
+#undef NW_AVX512_CELLS
+#undef NW_L8
+#undef NW_L16
+#undef NW_S16
+#undef NW_S8
+#undef NW_ML8
+#undef NW_ML16
+#undef NW_MS16
+#undef NW_MS8
         NW_DIAG_END
     }
 }
