@@ -66,3 +66,104 @@ def bigq_poisson_fixture():
     d = json.load(open(os.path.join(GOLDEN, "bigq.json")))
     return [(r["seq"], r["quals"], r["alpha"], None if r["poisson_ee"] is None else float.fromhex(r["poisson_ee"]), r["poisson_ns"])
             for r in d["reads"]]
+
+
+# ---------------------------------------------------------------------------------------------
+# flag matrix (round 4): inputs derived from the reference's test1 / test2.fastq, the reference's outputs for them
+# ---------------------------------------------------------------------------------------------
+FLAG_DIR = os.path.join(GOLDEN, "flag_matrix")
+
+
+def _lcg(state):
+    """One step of a 64-bit linear congruential generator (written out so that the derived input never depends on a
+    library's random stream): returns (new state, 31 random bits)."""
+    state = (state * 6364136223846793005 + 1442695040888963407) & ((1 << 64) - 1)
+    return state, state >> 33
+
+
+def read_fastq_records(path):
+    """[(header line, sequence, plus line, quality line)] of a plain / .gz / .bz2 FASTQ file."""
+    import bz2
+    import gzip
+    opener = gzip.open if path.endswith(".gz") else bz2.open if path.endswith(".bz2") else open
+    with opener(path, "rt") as f:
+        lines = [l.rstrip("\n") for l in f]
+    return [tuple(lines[i:i + 4]) for i in range(0, len(lines) - 3, 4)]
+
+
+def derive_flag_inputs(rec1, rec2):
+    """The flag matrix's input pair: the reference's test1 / test2 records with what the shipped files lack --
+    ambiguous bases in both cases ('N' and 'n'), Q0 characters, short reads (so that --truncate discards and
+    --min_overlap bites), header text after a blank / tab and ':' in names, and late duplicates of early reads with
+    better qualities (so that a collapse group changes its representative).  Deterministic, index-driven."""
+    out1, out2 = [], []
+    st = 20161009
+    n = min(len(rec1), len(rec2))
+    for i in range(n):
+        h1, s1, p1, q1 = rec1[i]
+        h2, s2, p2, q2 = rec2[i]
+        s1, q1, s2, q2 = list(s1), list(q1), list(s2), list(q2)
+        if i % 7 == 3:
+            st, k = _lcg(st)
+            for _ in range(1 + k % 3):
+                st, pos = _lcg(st)
+                s1[pos % len(s1)] = "N"
+        if i % 11 == 5:
+            st, k = _lcg(st)
+            for _ in range(1 + k % 2):
+                st, pos = _lcg(st)
+                s1[pos % len(s1)] = "n"
+        if i % 9 == 4:
+            st, k = _lcg(st)
+            for _ in range(1 + k % 3):
+                st, pos = _lcg(st)
+                s2[pos % len(s2)] = "N"
+        if i % 17 == 2:
+            for _ in range(3):
+                st, pos = _lcg(st)
+                q1[pos % len(q1)] = "!"
+        if i % 13 == 6:
+            st, k = _lcg(st)
+            cut = 100 + k % 100
+            s1, q1 = s1[:cut], q1[:cut]
+        if i % 19 == 8:
+            st, k = _lcg(st)
+            cut = 60 + k % 91
+            s2, q2 = s2[:cut], q2[:cut]
+        if i % 23 == 1:
+            h1, h2 = h1 + " 1:N:0:7\tlane x", h2 + "\t2:N:0:7"
+        if i % 29 == 9:
+            h1 = h2 = "@run:7:" + h1[1:]
+        out1.append((h1, "".join(s1), p1, "".join(q1)))
+        out2.append((h2, "".join(s2), p2, "".join(q2)))
+    for k in range(40):                         # late duplicates: same bases, better (even k) or worse (odd k) qualities
+        i = (k * 37) % n
+        h1, s1, p1, q1 = out1[i]
+        h2, s2, p2, q2 = out2[i]
+        bump = (lambda c: chr(min(ord(c) + 3, 73))) if k % 2 == 0 else (lambda c: chr(max(ord(c) - 4, 35)))
+        out1.append(("@dup%d" % k, s1, "+", "".join(bump(c) for c in q1)))
+        out2.append(("@dup%d" % k, s2, "+", "".join(bump(c) for c in q2)))
+    return out1, out2
+
+
+def write_fastq(path, records):
+    with open(path, "w") as f:
+        for r in records:
+            f.write("%s\n%s\n%s\n%s\n" % r)
+
+
+def flag_manifest():
+    return json.load(open(os.path.join(FLAG_DIR, "manifest.json")))
+
+
+def flag_outputs():
+    """{case: {file stem: bytes}} from the committed archive of the reference's outputs."""
+    import io
+    import tarfile
+    out = {}
+    with tarfile.open(os.path.join(FLAG_DIR, "outputs.tar.xz"), "r:xz") as tf:
+        for m in tf.getmembers():
+            if m.isfile():
+                case, stem = m.name.split("/", 1)
+                out.setdefault(case, {})[stem] = tf.extractfile(m).read()
+    return out
