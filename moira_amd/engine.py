@@ -36,10 +36,11 @@ class DeviceBuffer:
         L.check(self.engine.lib.mpb_memcpy_h2d(self.engine.ctx, self.ptr, arr.ctypes.data, arr.nbytes))
         return self
 
-    def download(self, dtype, count):
+    def download(self, dtype, count, offset=0):
+        """`count` items of `dtype` starting `offset` BYTES into the allocation."""
         out = np.empty(count, dtype)
-        assert out.nbytes <= self.nbytes
-        L.check(self.engine.lib.mpb_memcpy_d2h(self.engine.ctx, out.ctypes.data, self.ptr, out.nbytes))
+        assert offset >= 0 and offset + out.nbytes <= self.nbytes
+        L.check(self.engine.lib.mpb_memcpy_d2h(self.engine.ctx, out.ctypes.data, self.ptr + int(offset), out.nbytes))
         return out
 
     def free(self):

@@ -25,3 +25,19 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+PARITY_LINES = []          # "[every-read parity] ..." lines of the full-size GPU tests, shown in the run's summary
+
+
+def note_parity(line):
+    PARITY_LINES.append(line)
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "every_read_parity.txt"), "a") as f:
+            f.write(line + "\n")
+
+
+def pytest_terminal_summary(terminalreporter):
+    for line in PARITY_LINES:
+        terminalreporter.write_line(line)

@@ -244,12 +244,36 @@ def test_device_synth_matches_host_and_device_resident_filter(eng, oracle):
         b.free()
 
 
+def compare_every_read(eng, oracle, d_q, n, stride, ee1, ns1, ps1, fixed_len=None, lens=None, step=4_000_000, label=""):
+    """Bit-for-bit comparison of ALL n reads of a resident batch with the oracle (no sampling).  The
+    oracle reads the very bytes the GPU filtered: the matrix comes back from HBM a few million rows at a time (that the
+    device generator writes what the host generator writes is checked on its own, by test_device_generator_* and by the
+    host-regenerated windows of the callers).  Prints the compared-read count."""
+    import time
+    threads = oracle.lib().pbo_max_threads()
+    t0, done = time.time(), 0
+    for start in range(0, n, step):
+        m = min(step, n - start)
+        hq = d_q.download(np.uint8, m * stride, offset=start * stride).reshape(m, stride)
+        if lens is None:
+            ee, ns, ps, _ = oracle.filter_batch(hq, fixed_len=fixed_len, threads=threads)
+        else:
+            ee, ns, ps, _ = oracle.filter_batch(hq, lens=lens[start:start + m], threads=threads)
+        sl = slice(start, start + m)
+        assert same(ee1[sl], ee), (label, start)
+        assert np.array_equal(ns1[sl], ns) and np.array_equal(ps1[sl], ps), (label, start)
+        done += m
+    from conftest import note_parity
+    note_parity("[every-read parity] %s: %d of %d reads compared bit for bit with the oracle (%d threads, %.1f s)"
+                % (label, done, n, threads, time.time() - t0))
+    return done
+
+
 def test_config2_full_size(eng, oracle):
-    """BASELINE config 2: 10M x 300 bp resident in HBM.  Size-independent properties (determinism,
-    pass count == sum of flags == threshold test on ee, no NaN) and -- because the oracle's fast
-    shape does ~1e5 reads/s per core -- a bit-for-bit comparison of EVERY read when the host has
-    the cores for it (the GPU box has 128), of 300 random 64-read windows otherwise.  Inputs are
-    regenerated on the host from the counter-based generator, so nothing is copied back."""
+    """BASELINE config 2: 10M x 300 bp resident in HBM.  Size-independent properties (determinism, pass count == sum
+    of flags == threshold test on ee, no NaN) AND a bit-for-bit comparison of every one of the 10 M reads with the
+    oracle (2 s of oracle on the 16 cores a GPU box grants), plus host-regenerated windows (the counter-based
+    generator on the host writes what the device wrote)."""
     n, stride, L, seed = 10_000_000, 320, 300, 2
     d_q, d_ee, d_ns, d_pass = eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
     eng.synth_fill(d_q, n, stride, fixed_len=L, seed=seed)
@@ -262,22 +286,32 @@ def test_config2_full_size(eng, oracle):
     assert not np.isnan(ee1).any()
     assert np.array_equal(ps1.astype(bool), ee1 <= L * 0.01)
     ns1 = d_ns.download(np.int32, n)
-    threads = oracle.lib().pbo_max_threads()
-    if threads >= 32:
-        step = 2_000_000
-        for start in range(0, n, step):
-            hq, _ = oracle.synth_fill(step, stride, fixed_len=L, seed=seed, first_read=start)
-            ee, ns, ps, _ = oracle.filter_batch(hq, fixed_len=L, threads=threads)
-            sl = slice(start, start + step)
-            assert same(ee1[sl], ee) and np.array_equal(ns1[sl], ns) and np.array_equal(ps1[sl], ps)
-    else:
-        rng = np.random.default_rng(99)
-        for start in rng.integers(0, n - 64, 300):
-            hq, _ = oracle.synth_fill(64, stride, fixed_len=L, seed=seed, first_read=int(start))
-            ee, ns, ps, _ = oracle.filter_batch(hq, fixed_len=L)
-            sl = slice(int(start), int(start) + 64)
-            assert same(ee1[sl], ee) and np.array_equal(ns1[sl], ns) and np.array_equal(ps1[sl], ps)
+    assert compare_every_read(eng, oracle, d_q, n, stride, ee1, ns1, ps1, fixed_len=L, label="config 2") == n
+    rng = np.random.default_rng(99)
+    for start in rng.integers(0, n - 64, 100):
+        hq, _ = oracle.synth_fill(64, stride, fixed_len=L, seed=seed, first_read=int(start))
+        assert np.array_equal(d_q.download(np.uint8, 64 * stride, offset=int(start) * stride).reshape(64, stride), hq)
     for b in (d_q, d_ee, d_ns, d_pass):
+        b.free()
+
+
+def test_ragged_config5_full_size(eng, oracle):
+    """BASELINE config 5 at bench.py's size: 5 M reads of 50-600 bases in one stride-608 matrix (the batch of
+    extras.ragged_config5), every read compared with the oracle."""
+    n, stride, seed = 5_000_000, 608, 5
+    d_q, d_len = eng.alloc(n * stride), eng.alloc(n * 4)
+    d_ee, d_ns, d_pass = eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
+    eng.synth_fill(d_q, n, stride, min_len=50, max_len=600, d_len=d_len, seed=seed)
+    c = eng.filter_device(d_q, n, stride, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+    ee1, ns1, ps1 = d_ee.download(np.float64, n), d_ns.download(np.int32, n), d_pass.download(np.uint8, n)
+    lens = d_len.download(np.int32, n)
+    assert lens.min() == 50 and lens.max() == 600 and c.n_pass == int(ps1.sum())
+    assert np.array_equal(ps1.astype(bool), ee1 <= lens * 0.01)
+    assert compare_every_read(eng, oracle, d_q, n, stride, ee1, ns1, ps1, lens=lens, step=2_000_000, label="config 5") == n
+    hq, hl = oracle.synth_fill(4096, stride, min_len=50, max_len=600, seed=seed, first_read=n - 4096)
+    assert np.array_equal(lens[n - 4096:], hl)
+    assert np.array_equal(d_q.download(np.uint8, 4096 * stride, offset=(n - 4096) * stride).reshape(4096, stride), hq)
+    for b in (d_q, d_len, d_ee, d_ns, d_pass):
         b.free()
 
 
