@@ -308,6 +308,38 @@ int mpb_calculate_errors_PB(mpb_ctx *ctx, const char *contig,
                             const int32_t *contig_quals, int32_t len,
                             double alpha, double *ee, int32_t *ns);
 
+/* ---- per-read calls from many worker processes: the broker -------------------------------------- */
+/*
+ * Reference shape: moira/moira.py:398-399,431-454 -- `Pool(args.processors)` worker processes, each calling
+ * bernoulli.calculate_errors_PB(contig, contig_quals, alpha) once per read (moira/moira.py:817) and blocking for the
+ * answer.  One GPU context per worker makes those one-read launches time-share the card.  Instead ONE process -- the
+ * broker -- owns the GPU; the workers never touch it: mpb_broker_call() packs the read (host only, the packer of
+ * mpb_calculate_errors_PB) into the caller's slot of a shared-memory segment and waits, the broker gathers whatever is
+ * pending into one launch of the one-read-per-wave kernel (several such micro-batches in flight) and hands the results
+ * back through the slots.  Results are those of mpb_calculate_errors_PB bit for bit, scores above 254 included.
+ *
+ *   mpb_broker_serve   runs the broker loop on `ctx` in the calling thread until mpb_broker_shutdown(name), or until no
+ *                      live process has been attached and nothing has been asked for idle_exit_ms milliseconds
+ *                      (0: never).  Creates the segment "/moira_pb_<name>" (letters, digits, '_', '-', '.'), n_slots
+ *                      (1..256) slots = the most worker processes it serves at once; replaces a segment a dead broker
+ *                      left behind; MPB_E_INVALID when a live broker of that name exists.  Blocking.
+ *   mpb_broker_attach  no ctx, no HIP call: maps the segment (waiting up to wait_ms for a broker that is still starting)
+ *                      and claims a slot for this process.  An attachment does not survive fork(): the child attaches
+ *                      itself (mpb_broker_call refuses an attachment made by another pid).
+ *   mpb_broker_call    the per-read entry, arguments and errors of mpb_calculate_errors_PB.  MPB_E_HIP when the broker
+ *                      stops or dies while the read is pending (the caller may start a new one and attach again).
+ *   mpb_broker_stats   reads served / micro-batches launched / reads run alone (row budget missed, or scores above
+ *                      254), the broker's pid (0: not serving) and the number of attached processes; any may be NULL.
+ */
+typedef struct mpb_broker_client mpb_broker_client;
+int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t idle_exit_ms);
+int mpb_broker_attach(const char *name, int32_t wait_ms, mpb_broker_client **client_out);
+int mpb_broker_call(mpb_broker_client *client, const char *contig, const int32_t *contig_quals, int32_t len,
+                    double alpha, double *ee, int32_t *ns);
+int mpb_broker_detach(mpb_broker_client *client);
+int mpb_broker_shutdown(const char *name);
+int mpb_broker_stats(const char *name, int64_t *served, int64_t *batches, int64_t *solo, int32_t *pid, int32_t *attached);
+
 /* ---- --error_calc poisson -------------------------------------- */
 /*
  * Poisson approximation, ref: moira/moira.py:1637-1679 (calculate_errors_poisson).

@@ -18,8 +18,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmoira_pb.so")
-SOURCES = [os.path.join(CSRC, "mpb_kernels.hip"), os.path.join(CSRC, "mpb_api.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "mpb_internal.h"), os.path.join(CSRC, "libmoira_pb.map"),
+SOURCES = [os.path.join(CSRC, "mpb_kernels.hip"), os.path.join(CSRC, "mpb_api.cpp"), os.path.join(CSRC, "mpb_broker.cpp")]
+DEPS = SOURCES + [os.path.join(CSRC, "mpb_internal.h"), os.path.join(CSRC, "mpb_host_internal.h"),
+                  os.path.join(CSRC, "libmoira_pb.map"),
                   os.path.join(ROOT, "include", "moira_pb.h"),
                   os.path.join(ROOT, "include", "mpb_synth.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

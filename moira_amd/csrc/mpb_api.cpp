@@ -7,6 +7,7 @@
 
 #include "../../include/moira_pb.h"
 #include "mpb_internal.h"
+#include "mpb_host_internal.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -1080,8 +1081,8 @@ int mpb_host_free(mpb_ctx *c, void *hptr)
 // the reference takes any int (moira/bernoullimodule.c:92-108, moira/moira.py:1637-1679) and one read holds few
 // distinct values.  poisson: the Python function's rules -- 'n' is a base like any other (moira.py:1660), Q0 is p = 1
 // (no clamp inside the function; it too gets a private code), and the second table component is p itself.
-static int pack_one_read(const char *contig, const int32_t *quals, int32_t len, bool poisson, uint8_t *row, int32_t row_bytes,
-                         double2 *h, bool *priv)
+int mpbi_pack_one_read(const char *contig, const int32_t *quals, int32_t len, bool poisson, uint8_t *row, int32_t row_bytes,
+                       double2 *h, bool *priv)
 {
     *priv = false;
     auto direct = [&](int32_t q) { return poisson ? (q >= 1 && q <= 254) : q <= 254; };
@@ -1133,29 +1134,71 @@ struct PrivateTable {
     ~PrivateTable() { if (on) c->ws.lut = c->d_lut; }
 };
 
-int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *contig_quals, int32_t len,
-                            double alpha, double *ee, int32_t *ns)
+// argument rules of the per-read entry (moira/bernoullimodule.c:79-90), shared with the broker's client side
+int mpbi_check_one_read(const char *contig, const int32_t *contig_quals, int32_t len, double alpha, const void *ee, const void *ns)
 {
-    CTXCHK(c);
     if (!ee || !ns) return fail(MPB_E_INVALID, "NULL output");
     if (!(alpha > 0 && alpha < 1)) return fail(MPB_E_INVALID, "Alpha must be between 0 and 1");   // bernoullimodule.c:79-83
     if (len < 0 || (len > 0 && !contig_quals)) return fail(MPB_E_INVALID, "bad arguments");
     if (contig && (int32_t)strlen(contig) != len)                                               // bernoullimodule.c:85-90
         return fail(MPB_E_INVALID, "contig and contig_quals must have the same length");
     if (len > MPB_MAX_LEN) return fail(MPB_E_INVALID, "reads longer than %d bases are not supported", MPB_MAX_LEN);
-    const int32_t stride = (int32_t)align_up(len > 0 ? len : 1, 16);
-    std::vector<uint8_t> row((size_t)stride);
+    return MPB_OK;
+}
+
+// one packed row (and, when the read carries scores above 254, its private table h) -> (ee, Ns): the GPU half of the
+// per-read entry.  The broker calls it for the reads it cannot put into a micro-batch.
+int mpbi_run_packed_read(mpb_ctx *c, const uint8_t *row, int32_t len, int32_t stride, const double2 *h, double alpha,
+                         double *ee, int32_t *ns)
+{
     mpb_filter_params prm;
     prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
     uint8_t pass = 0;
+    PrivateTable guard(c);
+    int rc;
+    if (h && (rc = guard.install(h)) != MPB_OK) return rc;
+    return mpb_filter_host(c, row, 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
+}
+
+int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *contig_quals, int32_t len,
+                            double alpha, double *ee, int32_t *ns)
+{
+    CTXCHK(c);
+    int rc = mpbi_check_one_read(contig, contig_quals, len, alpha, ee, ns);
+    if (rc) return rc;
+    const int32_t stride = (int32_t)align_up(len > 0 ? len : 1, 16);
+    std::vector<uint8_t> row((size_t)stride);
     bool priv = false;
     double2 h[256];
-    int rc = pack_one_read(contig, contig_quals, len, false, row.data(), stride, h, &priv);
-    if (rc) return rc;
-    PrivateTable guard(c);
-    if (priv && (rc = guard.install(h)) != MPB_OK) return rc;
-    return mpb_filter_host(c, row.data(), 1, stride, nullptr, len, &prm, ee, ns, &pass, nullptr);
+    if ((rc = mpbi_pack_one_read(contig, contig_quals, len, false, row.data(), stride, h, &priv))) return rc;
+    return mpbi_run_packed_read(c, row.data(), len, stride, priv ? h : nullptr, alpha, ee, ns);
 }
+
+// One micro-batch of the broker: m packed rows that already lie in device memory -> one k_small launch on stream s
+// (one read per wave), results into device arrays.  Nothing here synchronises; a read that misses its row budget comes
+// back with pass == 2 and the broker re-runs it alone.  cls / ident are the launch's own scratch (m bytes / m int32),
+// so that several micro-batches can be in flight on different streams.
+int mpbi_small_async(mpb_ctx *c, const uint8_t *d_q, int64_t m, int64_t stride, const int32_t *d_len, double alpha,
+                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *d_cls, int32_t *d_ident, hipStream_t s)
+{
+    mpb_filter_params prm;
+    prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
+    const int32_t max_len = (int32_t)(stride < MPB_MAX_LEN ? stride : MPB_MAX_LEN);
+    const MpbDevParams dp = make_dev_params(&prm, 0, max_len);
+    int rc = ensure_workspace(c, m);               // (the broker sizes it once, before anything is in flight)
+    if (rc) return rc;
+    MpbWorkspace ws = c->ws;                       // only lut / cls / perm are read by the launch
+    ws.lut = c->d_lut;
+    ws.cls = d_cls;
+    ws.perm = d_ident;
+    mpb_launch_small(d_q, m, stride, d_len, dp, ws, d_ns, d_ee, d_pass, s);
+    HIPCHK(hipGetLastError());
+    return MPB_OK;
+}
+
+int mpbi_ctx_device(const mpb_ctx *c) { return c ? c->device : -1; }
+
+int mpbi_fail(int code, const char *msg) { return fail(code, "%s", msg); }
 
 int mpb_decode_ascii_device(mpb_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, int64_t n, int64_t row_stride,
                             const int32_t *d_len, int32_t fixed_len, int32_t fastq_offset, uint8_t *d_out, int32_t *d_err)
@@ -1348,7 +1391,7 @@ int mpb_calculate_errors_poisson(mpb_ctx *c, const char *sequence, const int32_t
     uint8_t pass = 0;
     bool priv = false;
     double2 h[256];
-    int rc = pack_one_read(sequence, quals, len, true, row.data(), stride, h, &priv);
+    int rc = mpbi_pack_one_read(sequence, quals, len, true, row.data(), stride, h, &priv);
     if (rc) return rc;
     PrivateTable guard(c);
     if (priv && (rc = guard.install(h)) != MPB_OK) return rc;

@@ -1,0 +1,568 @@
+// mpb_broker.cpp -- one GPU-owning process serves the per-read calls of many worker processes.
+//
+// Reference shape served: moira/moira.py:398-399,431-454 -- `Pool(args.processors)` worker processes, each calling
+// bernoulli.calculate_errors_PB(contig, quals, alpha) once per read (moira/moira.py:817) and blocking for the answer.
+// If every worker opens its own GPU context those one-read launches time-share the card (2.4 x 10^4 calls/s in all,
+// whatever P is: profiles/r03_per_read_concurrency.txt).  Here the workers never touch the GPU: a call packs its read into
+// a slot of a shared-memory segment and waits; the broker process gathers whatever is pending -- at most one read per
+// worker, they block -- into ONE launch of the one-read-per-wave kernel (k_small), several such micro-batches in flight on
+// streams of their own, and hands the results back through the slots.
+//
+// Segment (POSIX shared memory, name "/moira_pb_<name>"): a header and n_slots slots of fixed size.  A client owns one
+// slot for as long as it is attached (claimed by a compare-and-swap of its pid); a slot whose owner has died is reclaimed
+// by the broker.  Slot state machine (one 32-bit word, also the futex the client sleeps on):
+//     IDLE -> (client packs the read) SUBMITTED -> (broker) RUNNING -> DONE -> (client copies the result) IDLE
+// Waiting is spin-then-futex on both sides, so that in steady state nobody makes a system call.
+//
+// Results are those of mpb_calculate_errors_PB bit for bit: same packer (client side, host only), same kernel, same
+// fallbacks (a read that misses its predicted row budget, or carries scores above 254, is run alone by the broker through
+// the ordinary per-read path).
+
+#include "../../include/moira_pb.h"
+#include "mpb_internal.h"
+#include "mpb_host_internal.h"
+
+#include <atomic>
+#include <cerrno>
+#include <cmath>
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fcntl.h>
+#include <linux/futex.h>
+#include <new>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t BRK_MAGIC = 0x4d504252u;        // "MPBR"
+constexpr uint32_t BRK_VERSION = 1;
+constexpr int BRK_LANES = 4;                        // micro-batches in flight
+constexpr int BRK_MAX_SLOTS = 256;
+
+enum : uint32_t { ST_IDLE = 0, ST_SUBMITTED = 1, ST_RUNNING = 2, ST_DONE = 3 };
+enum : int32_t { BS_STARTING = 0, BS_SERVING = 1, BS_EXITING = 2 };
+
+struct alignas(64) BrkHeader {
+    uint32_t magic, version;
+    int32_t n_slots, slot_bytes;
+    std::atomic<int32_t> state;
+    std::atomic<int32_t> pid;
+    std::atomic<int32_t> device;
+    std::atomic<int32_t> stop;                      // set by mpb_broker_shutdown
+    alignas(64) std::atomic<uint32_t> submit_seq;   // futex word: bumped by every submit
+    std::atomic<int32_t> sleeping;                  // the broker is (about to be) asleep on submit_seq
+    alignas(64) std::atomic<int64_t> served;
+    std::atomic<int64_t> batches, solo;
+    std::atomic<int64_t> heartbeat_ms;
+};
+
+struct alignas(64) BrkSlot {
+    std::atomic<int32_t> owner;                     // pid of the attached client, 0 = free
+    std::atomic<uint32_t> state;                    // ST_*, futex word of the client
+    std::atomic<int32_t> waiting;                   // the client sleeps on `state`
+    int32_t len, priv, rc, ns;
+    double alpha, ee;
+    char err[160];
+    // then: uint8_t row[MPB_MAX_STRIDE]; double2 lut[256] (only read when priv != 0)
+};
+
+constexpr size_t SLOT_ROW_OFF = (sizeof(BrkSlot) + 63) & ~(size_t)63;
+constexpr size_t SLOT_LUT_OFF = SLOT_ROW_OFF + MPB_MAX_STRIDE;
+constexpr size_t SLOT_BYTES = SLOT_LUT_OFF + 256 * sizeof(double2);
+
+inline long futex(void *addr, int op, uint32_t val, const timespec *ts)
+{
+    return syscall(SYS_futex, addr, op, val, ts, nullptr, 0);
+}
+inline void futex_wait(void *addr, uint32_t val, int ms)
+{
+    timespec ts{ms / 1000, (long)(ms % 1000) * 1000000L};
+    futex(addr, FUTEX_WAIT, val, &ts);
+}
+inline void futex_wake(void *addr, int n) { futex(addr, FUTEX_WAKE, (uint32_t)n, nullptr); }
+
+inline int64_t now_ms()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000 + ts.tv_nsec / 1000000;
+}
+inline int64_t now_us()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000 + ts.tv_nsec / 1000;
+}
+inline void cpu_relax() { __builtin_ia32_pause(); }
+
+inline bool pid_alive(int pid) { return pid > 0 && (kill(pid, 0) == 0 || errno == EPERM); }
+
+int shm_path(const char *name, char *out, size_t cap)
+{
+    if (!name || !*name || strlen(name) > 100) return mpbi_fail(MPB_E_INVALID, "broker name must be 1..100 characters");
+    for (const char *p = name; *p; p++)
+        if (!((*p >= 'a' && *p <= 'z') || (*p >= 'A' && *p <= 'Z') || (*p >= '0' && *p <= '9') || *p == '_' || *p == '-' || *p == '.'))
+            return mpbi_fail(MPB_E_INVALID, "broker name may hold letters, digits, '_', '-' and '.' only");
+    snprintf(out, cap, "/moira_pb_%s", name);
+    return MPB_OK;
+}
+
+struct Mapping {
+    void *base = nullptr;
+    size_t bytes = 0;
+    BrkHeader *hdr() const { return (BrkHeader *)base; }
+    BrkSlot *slot(int i) const { return (BrkSlot *)((char *)base + sizeof(BrkHeader) + (size_t)i * SLOT_BYTES); }
+    static uint8_t *row(BrkSlot *s) { return (uint8_t *)s + SLOT_ROW_OFF; }
+    static double2 *lut(BrkSlot *s) { return (double2 *)((char *)s + SLOT_LUT_OFF); }
+    void unmap() { if (base) munmap(base, bytes); base = nullptr; bytes = 0; }
+};
+
+int map_existing(const char *name, Mapping *m)
+{
+    char path[128];
+    int rc = shm_path(name, path, sizeof(path));
+    if (rc) return rc;
+    const int fd = shm_open(path, O_RDWR, 0600);
+    if (fd < 0) return mpbi_fail(MPB_E_INVALID, "no broker segment of this name");
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(BrkHeader)) { close(fd); return mpbi_fail(MPB_E_INVALID, "broker segment is not initialised yet"); }
+    void *p = mmap(nullptr, (size_t)st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return mpbi_fail(MPB_E_NOMEM, "mmap of the broker segment failed");
+    m->base = p;
+    m->bytes = (size_t)st.st_size;
+    const BrkHeader *h = m->hdr();
+    if (h->magic != BRK_MAGIC || h->version != BRK_VERSION || h->slot_bytes != (int32_t)SLOT_BYTES ||
+        m->bytes < sizeof(BrkHeader) + (size_t)h->n_slots * SLOT_BYTES) {
+        m->unmap();
+        return mpbi_fail(MPB_E_INVALID, "broker segment has another layout (another library version?)");
+    }
+    return MPB_OK;
+}
+
+// ---- broker side -------------------------------------------------------------------------------------------------
+
+#define BHIP(expr)                                                                         \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            char b_[256];                                                                  \
+            snprintf(b_, sizeof(b_), "%s failed: %s", #expr, hipGetErrorString(e_));       \
+            return mpbi_fail(e_ == hipErrorOutOfMemory ? MPB_E_NOMEM : MPB_E_HIP, b_);     \
+        }                                                                                  \
+    } while (0)
+
+// one micro-batch in flight: pinned input block (len | q), device block, pinned output block (ee | ns | pass)
+struct Lane {
+    hipStream_t stream = nullptr;
+    char *pin_in = nullptr, *pin_out = nullptr, *dev = nullptr;
+    size_t in_cap = 0, out_cap = 0, dev_cap = 0;
+    bool busy = false;
+    int m = 0;
+    int64_t stride = 0;
+    int slots[BRK_MAX_SLOTS];
+};
+
+struct Broker {
+    mpb_ctx *ctx;
+    Mapping map;
+    int n_slots;
+    Lane lane[BRK_LANES];
+    size_t off_q, off_ee, off_ns, off_pass, off_cls, off_ident;       // offsets inside a lane's blocks (n_slots reads)
+
+    int init_lanes()
+    {
+        const size_t ns = (size_t)n_slots;
+        off_q = (ns * 4 + 255) & ~(size_t)255;                        // input block: len[n_slots] | q[m x stride]
+        const size_t in_cap = off_q + ns * (size_t)MPB_MAX_STRIDE;
+        off_ee = 0;                                                   // output block: ee | ns | pass
+        off_ns = ns * 8;
+        off_pass = off_ns + ns * 4;
+        const size_t out_cap = (off_pass + ns + 255) & ~(size_t)255;
+        off_cls = in_cap + out_cap;                                   // device block: input | output | cls | ident
+        off_ident = (off_cls + ns + 255) & ~(size_t)255;
+        const size_t dev_cap = off_ident + ns * 4;
+        for (Lane &l : lane) {
+            BHIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+            BHIP(hipHostMalloc((void **)&l.pin_in, in_cap, hipHostMallocDefault));
+            BHIP(hipHostMalloc((void **)&l.pin_out, out_cap, hipHostMallocDefault));
+            BHIP(hipMalloc((void **)&l.dev, dev_cap));
+            l.in_cap = in_cap; l.out_cap = out_cap; l.dev_cap = dev_cap;
+        }
+        return MPB_OK;
+    }
+
+    void free_lanes()
+    {
+        for (Lane &l : lane) {
+            if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+            if (l.pin_in) (void)hipHostFree(l.pin_in);
+            if (l.pin_out) (void)hipHostFree(l.pin_out);
+            if (l.dev) (void)hipFree(l.dev);
+            l = Lane();
+        }
+    }
+
+    void finish(int si, int rc, double ee, int32_t ns, const char *err)
+    {
+        BrkSlot *s = map.slot(si);
+        s->rc = rc; s->ee = ee; s->ns = ns;
+        if (err) { strncpy(s->err, err, sizeof(s->err) - 1); s->err[sizeof(s->err) - 1] = 0; } else s->err[0] = 0;
+        s->state.store(ST_DONE, std::memory_order_seq_cst);
+        if (s->waiting.load(std::memory_order_seq_cst)) futex_wake(&s->state, 1);
+        map.hdr()->served.fetch_add(1, std::memory_order_relaxed);
+    }
+
+    // a read the micro-batch cannot take (private table), or that came back with pass == 2: alone, synchronously
+    void run_solo(int si)
+    {
+        BrkSlot *s = map.slot(si);
+        double ee = 0;
+        int32_t ns = 0;
+        const int32_t stride = (int32_t)(((s->len > 0 ? s->len : 1) + 15) & ~15);
+        const int rc = mpbi_run_packed_read(ctx, Mapping::row(s), s->len, stride, s->priv ? Mapping::lut(s) : nullptr, s->alpha, &ee, &ns);
+        map.hdr()->solo.fetch_add(1, std::memory_order_relaxed);
+        finish(si, rc, ee, ns, rc ? mpb_last_error() : nullptr);
+    }
+
+    int launch(Lane &l, const int *cand, int m, double alpha)
+    {
+        int32_t maxlen = 1;
+        for (int k = 0; k < m; k++) maxlen = std::max(maxlen, map.slot(cand[k])->len);
+        const int64_t stride = (maxlen + 15) & ~15;
+        int32_t *h_len = (int32_t *)l.pin_in;
+        uint8_t *h_q = (uint8_t *)l.pin_in + off_q;
+        for (int k = 0; k < m; k++) {
+            BrkSlot *s = map.slot(cand[k]);
+            h_len[k] = s->len;
+            memcpy(h_q + (size_t)k * stride, Mapping::row(s), (size_t)((s->len + 15) & ~15));     // bytes past len are never looked at
+            l.slots[k] = cand[k];
+        }
+        l.m = m; l.stride = stride;
+        char *d = l.dev;
+        const size_t in_bytes = off_q + (size_t)m * stride;
+        BHIP(hipMemcpyAsync(d, l.pin_in, in_bytes, hipMemcpyHostToDevice, l.stream));
+        char *d_out = d + l.in_cap;
+        int rc = mpbi_small_async(ctx, (const uint8_t *)d + off_q, m, stride, (const int32_t *)d, alpha, (double *)(d_out + off_ee),
+                                  (int32_t *)(d_out + off_ns), (uint8_t *)(d_out + off_pass), (uint8_t *)d + off_cls,
+                                  (int32_t *)(d + off_ident), l.stream);
+        if (rc) return rc;
+        BHIP(hipMemcpyAsync(l.pin_out, d_out, off_pass + (size_t)n_slots, hipMemcpyDeviceToHost, l.stream));
+        l.busy = true;
+        map.hdr()->batches.fetch_add(1, std::memory_order_relaxed);
+        return MPB_OK;
+    }
+
+    void retire(Lane &l)
+    {
+        const double *ee = (const double *)(l.pin_out + off_ee);
+        const int32_t *ns = (const int32_t *)(l.pin_out + off_ns);
+        const uint8_t *pass = (const uint8_t *)(l.pin_out + off_pass);
+        l.busy = false;
+        for (int k = 0; k < l.m; k++) {
+            if (pass[k] == 2) run_solo(l.slots[k]);            // row budget missed (or more than 1024 rows): the ordinary per-read path
+            else finish(l.slots[k], MPB_OK, ee[k], ns[k], nullptr);
+        }
+    }
+
+    void fail_lane(Lane &l, int rc)
+    {
+        l.busy = false;
+        for (int k = 0; k < l.m; k++) finish(l.slots[k], rc, 0, 0, mpb_last_error());
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t idle_exit_ms)
+{
+    if (!ctx) return mpbi_fail(MPB_E_INVALID, "ctx is NULL");
+    if (n_slots < 1 || n_slots > BRK_MAX_SLOTS) return mpbi_fail(MPB_E_INVALID, "n_slots must be 1..256");
+    char path[128];
+    int rc = shm_path(name, path, sizeof(path));
+    if (rc) return rc;
+    BHIP(hipSetDevice(mpbi_ctx_device(ctx)));
+    // a segment left behind by a broker that died is replaced; a live one is an error
+    {
+        Mapping old;
+        if (map_existing(name, &old) == MPB_OK) {
+            const int opid = old.hdr()->pid.load();
+            const bool live = old.hdr()->state.load() != BS_EXITING && pid_alive(opid) && opid != (int)getpid();
+            old.unmap();
+            if (live) return mpbi_fail(MPB_E_INVALID, "a broker of this name is already serving");
+        }
+        shm_unlink(path);
+    }
+    const int fd = shm_open(path, O_RDWR | O_CREAT | O_EXCL, 0600);
+    if (fd < 0) return mpbi_fail(MPB_E_INVALID, "cannot create the broker segment (another broker starting?)");
+    const size_t bytes = sizeof(BrkHeader) + (size_t)n_slots * SLOT_BYTES;
+    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(path); return mpbi_fail(MPB_E_NOMEM, "cannot size the broker segment"); }
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { shm_unlink(path); return mpbi_fail(MPB_E_NOMEM, "mmap of the broker segment failed"); }
+    Broker b;
+    b.ctx = ctx;
+    b.map.base = p;
+    b.map.bytes = bytes;
+    b.n_slots = n_slots;
+    BrkHeader *h = new (p) BrkHeader();             // ftruncate zero-filled the pages: every slot is free and idle
+    h->n_slots = n_slots;
+    h->slot_bytes = (int32_t)SLOT_BYTES;
+    h->pid.store((int32_t)getpid());
+    h->device.store(mpbi_ctx_device(ctx));
+    h->heartbeat_ms.store(now_ms());
+    h->version = BRK_VERSION;
+    rc = b.init_lanes();
+    if (rc == MPB_OK) {
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        h->magic = BRK_MAGIC;                        // clients accept the segment from here on
+        h->state.store(BS_SERVING);
+    }
+    int64_t last_work = now_ms(), last_house = last_work;
+    int cand[BRK_MAX_SLOTS];
+    while (rc == MPB_OK && !h->stop.load(std::memory_order_relaxed)) {
+        bool progress = false;
+        bool any_busy = false;
+        // 1. retire the micro-batches that have finished
+        for (Lane &l : b.lane) {
+            if (!l.busy) continue;
+            const hipError_t q = hipStreamQuery(l.stream);
+            if (q == hipSuccess) { b.retire(l); progress = true; }
+            else if (q != hipErrorNotReady) {
+                mpbi_fail(MPB_E_HIP, hipGetErrorString(q));
+                b.fail_lane(l, MPB_E_HIP);
+                rc = MPB_E_HIP;                      // the context is gone: stop serving (clients see BS_EXITING)
+                break;
+            } else any_busy = true;
+        }
+        if (rc) break;
+        // 2. whatever has been submitted goes into the next free lane
+        Lane *free_lane = nullptr;
+        for (Lane &l : b.lane) if (!l.busy) { free_lane = &l; break; }
+        if (free_lane) {
+            int m = 0;
+            double alpha = 0;
+            for (int i = 0; i < n_slots; i++) {
+                BrkSlot *s = b.map.slot(i);
+                if (s->state.load(std::memory_order_acquire) != ST_SUBMITTED) continue;
+                if (s->priv) {                       // its own code table: cannot share a launch
+                    s->state.store(ST_RUNNING, std::memory_order_relaxed);
+                    b.run_solo(i);
+                    progress = true;
+                    continue;
+                }
+                if (m == 0) alpha = s->alpha;
+                else if (s->alpha != alpha) continue;              // another alpha: the next micro-batch
+                s->state.store(ST_RUNNING, std::memory_order_relaxed);
+                cand[m++] = i;
+            }
+            if (m) {
+                const int lrc = b.launch(*free_lane, cand, m, alpha);
+                if (lrc) {
+                    for (int k = 0; k < m; k++) b.finish(cand[k], lrc, 0, 0, mpb_last_error());
+                    if (lrc == MPB_E_HIP) { rc = lrc; break; }
+                }
+                progress = true;
+                any_busy = true;
+            }
+        }
+        const int64_t t = now_ms();
+        if (progress) { last_work = t; continue; }
+        // 3. nothing to do right now
+        if (any_busy) { cpu_relax(); continue; }
+        if (t - last_house >= 20) {
+            last_house = t;
+            h->heartbeat_ms.store(t, std::memory_order_relaxed);
+            bool attached = false;
+            for (int i = 0; i < n_slots; i++) {     // a slot whose owner has died goes back to the pool
+                BrkSlot *s = b.map.slot(i);
+                const int o = s->owner.load(std::memory_order_relaxed);
+                if (!o) continue;
+                if (pid_alive(o)) { attached = true; continue; }
+                s->state.store(ST_IDLE);
+                s->waiting.store(0);
+                s->owner.store(0);
+            }
+            if (attached) last_work = t;             // attached clients keep the broker alive even when they are quiet
+            if (idle_exit_ms > 0 && t - last_work > idle_exit_ms) break;
+        }
+        // spin for a little while (a worker is usually back within tens of microseconds), then sleep on the submit word
+        const uint32_t seq = h->submit_seq.load(std::memory_order_acquire);
+        const int64_t spin_until = now_us() + 100;
+        bool woke = false;
+        while (now_us() < spin_until) {
+            if (h->submit_seq.load(std::memory_order_acquire) != seq) { woke = true; break; }
+            cpu_relax();
+        }
+        if (woke) continue;
+        h->sleeping.store(1, std::memory_order_seq_cst);
+        bool pending = false;
+        for (int i = 0; i < n_slots && !pending; i++) pending = b.map.slot(i)->state.load(std::memory_order_seq_cst) == ST_SUBMITTED;
+        if (!pending && !h->stop.load()) futex_wait(&h->submit_seq, seq, 20);
+        h->sleeping.store(0, std::memory_order_seq_cst);
+    }
+    // leave: nobody may wait for an answer that will not come
+    h->state.store(BS_EXITING);
+    for (Lane &l : b.lane) if (l.busy) { if (hipStreamSynchronize(l.stream) == hipSuccess) b.retire(l); else b.fail_lane(l, MPB_E_HIP); }
+    for (int i = 0; i < n_slots; i++) {
+        BrkSlot *s = b.map.slot(i);
+        const uint32_t st = s->state.load();
+        if (st == ST_SUBMITTED || st == ST_RUNNING) { mpbi_fail(MPB_E_HIP, "the broker is shutting down"); b.finish(i, MPB_E_HIP, 0, 0, mpb_last_error()); }
+    }
+    b.free_lanes();
+    shm_unlink(path);
+    b.map.unmap();
+    return rc;
+}
+
+struct mpb_broker_client {
+    Mapping map;
+    int slot = -1;
+    int32_t pid = 0;
+};
+
+int mpb_broker_attach(const char *name, int32_t wait_ms, mpb_broker_client **out)
+{
+    if (!out) return mpbi_fail(MPB_E_INVALID, "NULL output");
+    *out = nullptr;
+    const int64_t deadline = now_ms() + (wait_ms > 0 ? wait_ms : 0);
+    Mapping m;
+    for (;;) {
+        int rc = map_existing(name, &m);
+        if (rc == MPB_OK) {
+            BrkHeader *h = m.hdr();
+            const int st = h->state.load();
+            if (st == BS_SERVING && pid_alive(h->pid.load())) break;
+            m.unmap();
+            if (st == BS_SERVING) { mpbi_fail(MPB_E_INVALID, "the broker process of this segment is gone"); }
+            else mpbi_fail(MPB_E_INVALID, "the broker is not serving");
+        }
+        if (now_ms() >= deadline) return MPB_E_INVALID;
+        usleep(2000);
+    }
+    const int32_t me = (int32_t)getpid();
+    int got = -1;
+    for (int i = 0; i < m.hdr()->n_slots && got < 0; i++) {
+        int32_t expect = 0;
+        if (m.slot(i)->owner.compare_exchange_strong(expect, me)) got = i;
+    }
+    if (got < 0) { m.unmap(); return mpbi_fail(MPB_E_NOMEM, "every slot of the broker is taken (more worker processes than slots)"); }
+    BrkSlot *s = m.slot(got);
+    s->waiting.store(0);
+    s->state.store(ST_IDLE);
+    mpb_broker_client *cl = new (std::nothrow) mpb_broker_client();
+    if (!cl) { s->owner.store(0); m.unmap(); return mpbi_fail(MPB_E_NOMEM, "out of memory"); }
+    cl->map = m;
+    cl->slot = got;
+    cl->pid = me;
+    *out = cl;
+    return MPB_OK;
+}
+
+int mpb_broker_call(mpb_broker_client *cl, const char *contig, const int32_t *contig_quals, int32_t len, double alpha,
+                    double *ee, int32_t *ns)
+{
+    if (!cl || !cl->map.base) return mpbi_fail(MPB_E_INVALID, "not attached to a broker");
+    if (cl->pid != (int32_t)getpid()) return mpbi_fail(MPB_E_INVALID, "this attachment belongs to another process (forked after attaching): attach again");
+    int rc = mpbi_check_one_read(contig, contig_quals, len, alpha, ee, ns);
+    if (rc) return rc;
+    BrkHeader *h = cl->map.hdr();
+    BrkSlot *s = cl->map.slot(cl->slot);
+    if (h->state.load(std::memory_order_acquire) != BS_SERVING) return mpbi_fail(MPB_E_HIP, "the broker has stopped serving");
+    bool priv = false;
+    const int32_t stride = (int32_t)(((len > 0 ? len : 1) + 15) & ~15);
+    if ((rc = mpbi_pack_one_read(contig, contig_quals, len, false, Mapping::row(s), stride, Mapping::lut(s), &priv))) return rc;
+    s->len = len;
+    s->alpha = alpha;
+    s->priv = priv ? 1 : 0;
+    s->state.store(ST_SUBMITTED, std::memory_order_seq_cst);
+    h->submit_seq.fetch_add(1, std::memory_order_seq_cst);
+    if (h->sleeping.load(std::memory_order_seq_cst)) futex_wake(&h->submit_seq, 1);
+    // wait: spin first (the answer is usually tens of microseconds away), then sleep on the slot's state word
+    const int64_t spin_until = now_us() + 300;
+    int spins = 0;
+    for (;;) {
+        if (s->state.load(std::memory_order_acquire) == ST_DONE) break;
+        cpu_relax();
+        if ((++spins & 63) == 0 && now_us() >= spin_until) {
+            int64_t waited_ms = 0;
+            for (;;) {
+                s->waiting.store(1, std::memory_order_seq_cst);
+                const uint32_t st = s->state.load(std::memory_order_seq_cst);
+                if (st == ST_DONE) { s->waiting.store(0); break; }
+                futex_wait(&s->state, st, 50);
+                s->waiting.store(0, std::memory_order_seq_cst);
+                if (s->state.load(std::memory_order_acquire) == ST_DONE) break;
+                waited_ms += 50;
+                if (h->state.load() != BS_SERVING || (waited_ms >= 1000 && !pid_alive(h->pid.load()))) {
+                    if (s->state.load() == ST_DONE) break;
+                    s->state.store(ST_IDLE);
+                    return mpbi_fail(MPB_E_HIP, "the broker went away while a read was pending");
+                }
+            }
+            break;
+        }
+    }
+    rc = s->rc;
+    if (rc == MPB_OK) { *ee = s->ee; *ns = s->ns; }
+    else mpbi_fail(rc, s->err);
+    s->state.store(ST_IDLE, std::memory_order_release);
+    return rc;
+}
+
+int mpb_broker_detach(mpb_broker_client *cl)
+{
+    if (!cl) return MPB_OK;
+    if (cl->map.base) {
+        if (cl->pid == (int32_t)getpid()) {
+            BrkSlot *s = cl->map.slot(cl->slot);
+            s->state.store(ST_IDLE);
+            s->owner.store(0);
+        }
+        cl->map.unmap();
+    }
+    delete cl;
+    return MPB_OK;
+}
+
+int mpb_broker_shutdown(const char *name)
+{
+    Mapping m;
+    int rc = map_existing(name, &m);
+    if (rc) return rc;
+    m.hdr()->stop.store(1);
+    m.hdr()->submit_seq.fetch_add(1);
+    futex_wake(&m.hdr()->submit_seq, 1);
+    m.unmap();
+    return MPB_OK;
+}
+
+int mpb_broker_stats(const char *name, int64_t *served, int64_t *batches, int64_t *solo, int32_t *pid, int32_t *attached)
+{
+    Mapping m;
+    int rc = map_existing(name, &m);
+    if (rc) return rc;
+    const BrkHeader *h = m.hdr();
+    if (served) *served = h->served.load();
+    if (batches) *batches = h->batches.load();
+    if (solo) *solo = h->solo.load();
+    if (pid) *pid = (h->state.load() == BS_SERVING && pid_alive(h->pid.load())) ? h->pid.load() : 0;
+    if (attached) {
+        int a = 0;
+        for (int i = 0; i < h->n_slots; i++) a += m.slot(i)->owner.load() != 0;
+        *attached = a;
+    }
+    m.unmap();
+    return MPB_OK;
+}
+
+}  // extern "C"

@@ -9,6 +9,12 @@ Same signature, same exceptions (moira/bernoullimodule.c:74-90); computed on the
 libmoira_pb.so.  `calculate_errors` is the alias BASELINE.json's north_star names.
 A per-read call pays a kernel launch; throughput comes from the batch API
 (moira_amd.engine.Engine.filter), which is what replaces moira's per-read Pool dispatch.
+
+Under an unchanged `moira.py --processors P` the callers are the P worker processes of a multiprocessing.Pool
+(moira/moira.py:398-399,431-454).  Those do not open P GPU contexts (which would time-share the card): a process that
+was started by multiprocessing attaches to ONE GPU-owning broker process (moira_amd/broker.py; started on demand as a
+fresh child before this process has touched the GPU), which micro-batches whatever the workers have pending into one
+launch.  MOIRA_PB_BROKER=1 / 0 forces / forbids the broker; MOIRA_PB_DEVICE picks the GPU (default 0).
 """
 import os
 import sys
@@ -23,10 +29,37 @@ __doc__ = ("This module provides an interface for calculating the expected error
            "using a sum of Bernoulli random variables.")
 
 
+_entry = {"pid": None, "fn": None}
+
+
+def _choose():
+    """The per-read entry of THIS process: the broker for a multiprocessing worker, a context of its own otherwise."""
+    import multiprocessing
+    mode = os.environ.get("MOIRA_PB_BROKER", "auto").lower()
+    use_broker = mode in ("1", "on", "yes", "true") or (mode == "auto" and multiprocessing.parent_process() is not None)
+    if not use_broker:
+        return _default_engine().calculate_errors_PB
+    from moira_amd import broker as _broker
+    device = int(os.environ.get("MOIRA_PB_DEVICE", "0"))
+    state = {"cl": _broker.client(device)}
+
+    def call(contig, contig_quals, alpha):
+        try:
+            return state["cl"].calculate_errors_PB(contig, contig_quals, alpha)
+        except _broker.BrokerGone:                     # the broker died or left: start / find another one, once
+            state["cl"].close()
+            state["cl"] = _broker.client(device)
+            return state["cl"].calculate_errors_PB(contig, contig_quals, alpha)
+    return call
+
+
 def calculate_errors_PB(contig, contig_quals, alpha):
     """This function returns the expected errors of a given sequence with a given confidence value
     using a sum of Bernoulli random variables."""
-    return _default_engine().calculate_errors_PB(contig, contig_quals, alpha)
+    pid = os.getpid()
+    if _entry["pid"] != pid:                           # first call in this process (a forked worker decides for itself)
+        _entry["fn"], _entry["pid"] = _choose(), pid
+    return _entry["fn"](contig, contig_quals, alpha)
 
 
 calculate_errors = calculate_errors_PB

@@ -270,28 +270,10 @@ class Engine:
     def calculate_errors_PB(self, contig, contig_quals, alpha):
         """Exact twin of bernoulli.calculate_errors_PB -> (expected_errors, Ns).
         ref: moira/bernoullimodule.c:66-114 (argument and error behaviour)."""
-        if not isinstance(contig, str):
-            raise TypeError("argument 1 must be str, not %s" % type(contig).__name__)
-        if not isinstance(contig_quals, list):
-            raise TypeError("argument 2 must be list, not %s" % type(contig_quals).__name__)
-        alpha = float(alpha)                                   # "d" format: TypeError if not a number
-        if alpha <= 0 or alpha >= 1:
-            raise ValueError("Alpha must be between 0 and 1")
-        if len(contig_quals) != len(contig):
-            raise ValueError("contig and contig_quals must have the same length")
-        qi = None
-        if contig_quals:
-            a = np.asarray(contig_quals)                       # one C loop for the common case: a list of Python ints
-            if a.ndim == 1 and a.dtype.kind in "ib":
-                qi = a.astype(np.int32)                        # wraps as (int)PyInt_AsLong does (bernoullimodule.c:97)
-        if qi is None:                                         # anything else: element by element, as PyInt_AsLong would
-            qi = np.empty(len(contig_quals), np.int32)
-            for i, v in enumerate(contig_quals):
-                if not isinstance(v, int):
-                    raise TypeError("an integer is required")
-                qi[i] = v
+        from .broker import marshal_read               # the argument rules, shared with the broker entry
+        seq, qi, alpha = marshal_read(contig, contig_quals, alpha)
         ee, ns = C.c_double(), C.c_int32()
-        L.check(self.lib.mpb_calculate_errors_PB(self.ctx, contig.encode(), qi.ctypes.data, len(qi), alpha,
+        L.check(self.lib.mpb_calculate_errors_PB(self.ctx, seq, qi.ctypes.data, len(qi), alpha,
                                                  C.byref(ee), C.byref(ns)))
         return ee.value, ns.value
 

@@ -1,0 +1,86 @@
+// broker_stub.cpp -- TEST INFRASTRUCTURE, never shipped: lets the broker's inter-process protocol
+// (moira_amd/csrc/mpb_broker.cpp: shared-memory slots, futex hand-over, micro-batch lanes, dead-owner reclaim,
+// shutdown) run WITHOUT a GPU.  The product source file is compiled unchanged; this file supplies
+//   * the dozen HIP runtime entry points it calls, as host-memory operations that complete at once, and
+//   * the mpbi_* hooks of mpb_api.cpp, with the ORACLE (oracle/pb_oracle.c) doing the arithmetic,
+// and the test library is linked from the two.  A read whose length is a multiple of 7 is reported "row budget missed"
+// (pass == 2) by the stub's micro-batch, so that the broker's run-alone fallback is exercised as well.
+// What this does NOT test: the kernels (tests/test_gpu_broker.py does, on the GPU).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "../../include/moira_pb.h"
+
+extern "C" {
+typedef struct pbo_params { double alpha, uncert, maxerrors; int32_t ambig_mode; uint32_t flags; } pbo_params;
+int pbo_filter_batch(const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len, int32_t fixed_len,
+                     const pbo_params *prm, int shape, int threads, double *ee, int32_t *ns, uint8_t *pass, int32_t *rows);
+int pbo_pack_read(const char *seq, const int32_t *quals, int32_t len, uint8_t *row_out, int32_t row_bytes);
+
+static thread_local char g_err[512] = "";
+const char *mpb_last_error(void) { return g_err; }
+int mpbi_fail(int code, const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
+int mpbi_ctx_device(const mpb_ctx *) { return 0; }
+
+int mpbi_check_one_read(const char *contig, const int32_t *q, int32_t len, double alpha, const void *ee, const void *ns)
+{
+    if (!ee || !ns) return mpbi_fail(MPB_E_INVALID, "NULL output");
+    if (!(alpha > 0 && alpha < 1)) return mpbi_fail(MPB_E_INVALID, "Alpha must be between 0 and 1");
+    if (contig && (int32_t)strlen(contig) != len) return mpbi_fail(MPB_E_INVALID, "contig and contig_quals must have the same length");
+    if (len > 16383) return mpbi_fail(MPB_E_INVALID, "reads longer than 16383 bases are not supported");
+    return MPB_OK;
+}
+
+int mpbi_pack_one_read(const char *contig, const int32_t *quals, int32_t len, bool, uint8_t *row, int32_t row_bytes, double2 *, bool *priv)
+{
+    *priv = false;
+    for (int32_t i = 0; i < len; i++) {
+        if (quals[i] < 0) return mpbi_fail(MPB_E_RANGE, "Qualities must have positive values.");
+        if (quals[i] > 254) *priv = true;            // the stub has no private tables: it only carries the flag to the broker
+    }
+    if (*priv) {                                     // clamp so that the oracle can score it (the flag routes it to run_solo)
+        int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(len ? len : 1));
+        for (int32_t i = 0; i < len; i++) tmp[i] = quals[i] > 254 ? 254 : quals[i];
+        const int rc = pbo_pack_read(contig, tmp, len, row, row_bytes);
+        free(tmp);
+        return rc ? mpbi_fail(MPB_E_RANGE, "pack failed") : MPB_OK;
+    }
+    return pbo_pack_read(contig, quals, len, row, row_bytes) ? mpbi_fail(MPB_E_RANGE, "pack failed") : MPB_OK;
+}
+
+static int oracle_rows(const uint8_t *q, int64_t m, int64_t stride, const int32_t *len, double alpha, double *ee, int32_t *ns, uint8_t *pass)
+{
+    pbo_params p{alpha, 1.0, NAN, 1 /* ignore */, 0};
+    return pbo_filter_batch(q, m, stride, len, 0, &p, 0, 1, ee, ns, pass, nullptr) ? mpbi_fail(MPB_E_INVALID, "oracle failed") : MPB_OK;
+}
+
+int mpbi_run_packed_read(mpb_ctx *, const uint8_t *row, int32_t len, int32_t stride, const double2 *, double alpha, double *ee, int32_t *ns)
+{
+    uint8_t pass;
+    return oracle_rows(row, 1, stride, &len, alpha, ee, ns, &pass);
+}
+
+int mpbi_small_async(mpb_ctx *, const uint8_t *d_q, int64_t m, int64_t stride, const int32_t *d_len, double alpha,
+                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *, int32_t *, hipStream_t)
+{
+    int rc = oracle_rows(d_q, m, stride, d_len, alpha, d_ee, d_ns, d_pass);
+    for (int64_t i = 0; i < m && !rc; i++)
+        if (d_len[i] % 7 == 0) { d_pass[i] = 2; d_ee[i] = -12345.0; }    // "row budget missed": the broker must re-run it alone
+    return rc;
+}
+
+// ---- the HIP entry points mpb_broker.cpp calls, on host memory ----
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned int) { *p = malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+const char *hipGetErrorString(hipError_t) { return "stub"; }
+}

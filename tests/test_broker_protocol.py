@@ -1,0 +1,236 @@
+"""The broker's inter-process protocol on the CPU (no GPU here): moira_amd/csrc/mpb_broker.cpp compiled UNCHANGED and
+linked against tests/helpers/broker_stub.cpp, which stands in for the HIP runtime (host memory, immediate completion)
+and lets the oracle do the arithmetic.  What is tested: shared-memory slots, the spin / futex hand-over in both
+directions, micro-batches over several lanes, the run-alone fallback, mixed alphas, slot reclaim after a client dies,
+shutdown with clients attached, idle exit, the errors a caller sees.  The kernels behind the broker are tested on the GPU
+(tests/test_gpu_broker.py).  Reference shape: moira/moira.py:398-399,431-454 (Pool workers calling the per-read entry).
+"""
+import ctypes as C
+import multiprocessing as mp
+import os
+import signal
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+E_INVALID, E_HIP, E_NOMEM = -1, -3, -4
+
+
+@pytest.fixture(scope="module")
+def stub_lib(tmp_path_factory, oracle):
+    out = str(tmp_path_factory.mktemp("broker_stub") / "libbroker_test.so")
+    cmd = ["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-Wl,-Bsymbolic", os.path.join(ROOT, "moira_amd", "csrc", "mpb_broker.cpp"),
+           os.path.join(ROOT, "tests", "helpers", "broker_stub.cpp"), oracle._LIB_PATH,
+           "-Wl,-rpath," + os.path.dirname(oracle._LIB_PATH), "-o", out]
+    subprocess.check_call(cmd)
+    return out
+
+
+def _load(path):
+    lib = C.CDLL(path)
+    lib.mpb_broker_serve.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
+    lib.mpb_broker_attach.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.mpb_broker_call.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int32)]
+    lib.mpb_broker_detach.argtypes = [C.c_void_p]
+    lib.mpb_broker_shutdown.argtypes = [C.c_char_p]
+    lib.mpb_broker_stats.argtypes = [C.c_char_p] + [C.POINTER(C.c_int64)] * 3 + [C.POINTER(C.c_int32)] * 2
+    lib.mpb_last_error.restype = C.c_char_p
+    return lib
+
+
+def _serve(path, name, slots, idle_ms):
+    lib = _load(path)
+    os._exit(abs(lib.mpb_broker_serve(C.c_void_p(1), name.encode(), slots, idle_ms)))     # a non-NULL stand-in context
+
+
+def _stats(lib, name):
+    a, b, s, p, n = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+    if lib.mpb_broker_stats(name.encode(), C.byref(a), C.byref(b), C.byref(s), C.byref(p), C.byref(n)) != 0:
+        return None
+    return dict(served=a.value, batches=b.value, solo=s.value, pid=p.value, attached=n.value)
+
+
+def _reads(seed, count):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        n = int(rng.integers(1, 330))
+        lo, hi = [(2, 41), (20, 41), (1, 8), (30, 42)][int(rng.integers(0, 4))]
+        q = rng.integers(lo, hi, n)
+        s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+        amb = rng.random(n) < 0.02
+        s[amb] = np.where(rng.random(int(amb.sum())) < 0.7, ord("N"), ord("n"))
+        out.append((s.tobytes(), q.astype(np.int32), float([0.005, 0.005, 0.005, 0.05][int(rng.integers(0, 4))])))
+    return out
+
+
+def _client(path, name, seed, count, rounds, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import pb_oracle as O
+    lib = _load(path)
+    h = C.c_void_p()
+    rc = lib.mpb_broker_attach(name.encode(), 20000, C.byref(h))
+    if rc:
+        out.put(("attach failed", rc, lib.mpb_last_error().decode()))
+        return
+    reads = _reads(seed, count)
+    want = [O.ee_rowwise(s.decode(), [int(v) for v in q], a)[:2] for s, q, a in reads]
+    ee, ns = C.c_double(), C.c_int32()
+    bad = 0
+    t0 = time.perf_counter()
+    for r in range(rounds):
+        for (s, q, a), w in zip(reads, want):
+            rc = lib.mpb_broker_call(h, s, q.ctypes.data, len(q), a, C.byref(ee), C.byref(ns))
+            if rc or (ee.value, ns.value) != w:
+                bad += 1
+    dt = time.perf_counter() - t0
+    lib.mpb_broker_detach(h)
+    out.put(("ok", bad, count * rounds, dt))
+
+
+@pytest.fixture()
+def broker(stub_lib):
+    ctx = mp.get_context("spawn")
+    name = "t%d_%d" % (os.getpid(), int(time.time() * 1e3) % 100000)
+    p = ctx.Process(target=_serve, args=(stub_lib, name, 8, 0))
+    p.start()
+    lib = _load(stub_lib)
+    t0 = time.time()
+    while _stats(lib, name) is None or not _stats(lib, name)["pid"]:
+        assert p.is_alive() and time.time() - t0 < 30
+        time.sleep(0.01)
+    yield lib, name, p, ctx
+    lib.mpb_broker_shutdown(name.encode())
+    p.join(10)
+    if p.is_alive():
+        p.kill()
+    assert _stats(lib, name) is None                     # the segment is gone with the broker
+
+
+def test_many_workers_get_the_oracles_results(broker, stub_lib):
+    """6 worker processes, 150 reads x 8 rounds each, mixed alphas, N / n, lengths 1..329 (those divisible by 7 come back
+    'row budget missed' from the stub's micro-batch and are re-run alone): every (ee, Ns) equals the oracle's."""
+    lib, name, p, ctx = broker
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_client, args=(stub_lib, name, 100 + k, 150, 8, out)) for k in range(6)]
+    for pr in procs:
+        pr.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for pr in procs:
+        pr.join(30)
+    assert all(r[0] == "ok" and r[1] == 0 for r in res), res
+    total = sum(r[2] for r in res)
+    st = _stats(lib, name)
+    assert st["served"] == total and st["attached"] == 0
+    assert 0 < st["solo"] < total and st["batches"] >= 1
+    assert st["batches"] + st["solo"] <= total           # (equality = no two reads ever shared a launch: allowed, not expected)
+
+
+def test_arguments_and_errors(broker, stub_lib):
+    lib, name, p, ctx = broker
+    h = C.c_void_p()
+    assert lib.mpb_broker_attach(b"no_such_broker_%d" % os.getpid(), 0, C.byref(h)) == E_INVALID
+    assert lib.mpb_broker_attach(b"bad/name", 0, C.byref(h)) == E_INVALID
+    assert lib.mpb_broker_attach(name.encode(), 1000, C.byref(h)) == 0
+    q = np.full(10, 30, np.int32)
+    ee, ns = C.c_double(), C.c_int32()
+    assert lib.mpb_broker_call(h, b"ACGTACGTAC", q.ctypes.data, 10, 0.005, C.byref(ee), C.byref(ns)) == 0
+    assert lib.mpb_broker_call(h, b"ACGTACGTAC", q.ctypes.data, 10, 1.0, C.byref(ee), C.byref(ns)) == E_INVALID
+    assert b"Alpha must be between 0 and 1" in lib.mpb_last_error()
+    assert lib.mpb_broker_call(h, b"ACGT", q.ctypes.data, 10, 0.005, C.byref(ee), C.byref(ns)) == E_INVALID
+    assert b"same length" in lib.mpb_last_error()
+    q[3] = -1
+    assert lib.mpb_broker_call(h, b"ACGTACGTAC", q.ctypes.data, 10, 0.005, C.byref(ee), C.byref(ns)) == -5
+    q[3] = 30
+    assert lib.mpb_broker_call(h, b"", q.ctypes.data, 0, 0.005, C.byref(ee), C.byref(ns)) == 0 and ee.value == 0.0   # no base at all
+    assert lib.mpb_broker_call(h, b"ACGTACGTAC", q.ctypes.data, 10, 0.005, C.byref(ee), C.byref(ns)) == 0              # still usable
+    # a second broker under the same name is refused while the first one lives
+    assert lib.mpb_broker_serve(C.c_void_p(1), name.encode(), 4, 0) == E_INVALID
+    assert b"already serving" in lib.mpb_last_error()
+    # an attachment is per process: a forked child must attach itself
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        rc = lib.mpb_broker_call(h, b"ACGTACGTAC", q.ctypes.data, 10, 0.005, C.byref(ee), C.byref(ns))
+        os.write(w, b"%d" % rc)
+        os._exit(0)
+    os.waitpid(pid, 0)
+    assert os.read(r, 16) == b"%d" % E_INVALID
+    assert lib.mpb_broker_detach(h) == 0
+
+
+def _hold_slot(path, name, ready):
+    lib = _load(path)
+    h = C.c_void_p()
+    assert lib.mpb_broker_attach(name.encode(), 5000, C.byref(h)) == 0
+    ready.set()
+    time.sleep(600)
+
+
+def test_slots_run_out_and_a_dead_owners_slot_comes_back(broker, stub_lib):
+    lib, name, p, ctx = broker                           # 8 slots
+    ready = [ctx.Event() for _ in range(8)]
+    holders = [ctx.Process(target=_hold_slot, args=(stub_lib, name, e)) for e in ready]
+    for pr in holders:
+        pr.start()
+    for e in ready:
+        assert e.wait(30)
+    assert _stats(lib, name)["attached"] == 8
+    h = C.c_void_p()
+    assert lib.mpb_broker_attach(name.encode(), 0, C.byref(h)) == E_NOMEM
+    assert b"every slot" in lib.mpb_last_error()
+    for pr in holders[:3]:
+        os.kill(pr.pid, signal.SIGKILL)                  # no detach: the broker has to notice
+        pr.join()
+    t0 = time.time()
+    while _stats(lib, name)["attached"] != 5:
+        assert time.time() - t0 < 10
+        time.sleep(0.02)
+    assert lib.mpb_broker_attach(name.encode(), 0, C.byref(h)) == 0
+    q = np.full(25, 12, np.int32)
+    ee, ns = C.c_double(), C.c_int32()
+    assert lib.mpb_broker_call(h, b"A" * 25, q.ctypes.data, 25, 0.005, C.byref(ee), C.byref(ns)) == 0 and ee.value > 0
+    lib.mpb_broker_detach(h)
+    for pr in holders[3:]:
+        pr.kill()
+        pr.join()
+
+
+def test_shutdown_is_seen_by_an_attached_client(stub_lib):
+    ctx = mp.get_context("spawn")
+    name = "s%d" % os.getpid()
+    p = ctx.Process(target=_serve, args=(stub_lib, name, 4, 0))
+    p.start()
+    lib = _load(stub_lib)
+    h = C.c_void_p()
+    assert lib.mpb_broker_attach(name.encode(), 20000, C.byref(h)) == 0
+    q = np.full(8, 20, np.int32)
+    ee, ns = C.c_double(), C.c_int32()
+    assert lib.mpb_broker_call(h, b"ACGTACGT", q.ctypes.data, 8, 0.005, C.byref(ee), C.byref(ns)) == 0
+    assert lib.mpb_broker_shutdown(name.encode()) == 0
+    p.join(10)
+    assert p.exitcode == 0
+    assert lib.mpb_broker_call(h, b"ACGTACGT", q.ctypes.data, 8, 0.005, C.byref(ee), C.byref(ns)) == E_HIP
+    assert b"stopped serving" in lib.mpb_last_error()
+    lib.mpb_broker_detach(h)
+
+
+def test_idle_exit_waits_for_attached_processes(stub_lib):
+    ctx = mp.get_context("spawn")
+    name = "i%d" % os.getpid()
+    p = ctx.Process(target=_serve, args=(stub_lib, name, 4, 300))       # leaves 0.3 s after the last attached process
+    p.start()
+    lib = _load(stub_lib)
+    h = C.c_void_p()
+    assert lib.mpb_broker_attach(name.encode(), 20000, C.byref(h)) == 0
+    time.sleep(1.0)
+    assert p.is_alive()                                   # attached and quiet: stays
+    lib.mpb_broker_detach(h)
+    p.join(10)
+    assert p.exitcode == 0 and _stats(lib, name) is None

@@ -1,0 +1,102 @@
+"""The per-read drop-in under `moira.py --processors P` (moira/moira.py:398-399,431-454): P worker processes call
+bernoulli.calculate_errors_PB per read; ONE broker process owns the GPU and micro-batches what they have pending
+(moira_amd/broker.py, moira_amd/csrc/mpb_broker.cpp).  Bit-exact against the oracle from 8 concurrent processes, scores
+above 254 and reads of more than 1024 DP rows included; the broker is started by whichever worker asks first."""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _reads(seed, count):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(count):
+        n = int(rng.integers(1, 420))
+        lo, hi = [(2, 41), (20, 41), (1, 8), (30, 42), (2, 94)][int(rng.integers(0, 5))]
+        q = [int(v) for v in rng.integers(lo, hi, n)]
+        s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+        amb = rng.random(n) < 0.02
+        s[amb] = np.where(rng.random(int(amb.sum())) < 0.7, ord("N"), ord("n"))
+        if k % 41 == 7:
+            q[int(rng.integers(0, n))] = int(rng.choice([255, 300, 1000, 5000]))       # its own code table: run alone
+        if k % 53 == 11:
+            q[int(rng.integers(0, n))] = 0                                             # Q0 -> 1
+        out.append((s.tobytes().decode(), q, float([0.005, 0.005, 0.05, 1e-4][int(rng.integers(0, 4))])))
+    out.append(("A" * 1500, [1 + (i % 3) for i in range(1500)], 0.005))                # > 1024 DP rows: run alone (k_wide)
+    return out
+
+
+def _worker(name, seed, count, rounds, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import pb_oracle as O
+    from moira_amd import broker
+    cl = broker.client(0, name=name, idle_exit=5.0)
+    reads = _reads(seed, count)
+    want = [O.ee_rowwise(s, q, a)[:2] for s, q, a in reads]
+    bad = []
+    t0 = time.perf_counter()
+    for r in range(rounds):
+        for k, ((s, q, a), w) in enumerate(zip(reads, want)):
+            got = cl.calculate_errors_PB(s, q, a)
+            if got != w and len(bad) < 5:
+                bad.append((k, got, w))
+    dt = time.perf_counter() - t0
+    cl.close()
+    out.put((len(bad), bad, len(reads) * rounds, dt))
+
+
+def test_eight_concurrent_processes_are_bit_exact(oracle):
+    from moira_amd import broker
+    name = "gputest_%d" % os.getpid()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(name, 500 + k, 120, 6, out)) for k in range(8)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    st = broker.stats(name)
+    broker.shutdown(name)
+    assert all(r[0] == 0 for r in res), [r[1] for r in res if r[0]]
+    total = sum(r[2] for r in res)
+    assert st is not None and st["served"] == total and st["pid"] > 0
+    assert st["solo"] >= 8 * 6 and st["batches"] < total - st["solo"]       # reads DID share launches
+    assert broker.stats(name) is None
+
+
+def _pool_task(args):
+    s, q, a = args
+    sys.path.insert(0, os.path.join(ROOT, "moira_amd", "dropin"))
+    import bernoulli
+    return bernoulli.calculate_errors_PB(s, q, a), os.getpid()
+
+
+def test_the_dropin_module_uses_the_broker_in_pool_workers(oracle, monkeypatch):
+    """What an unchanged moira.py does: Pool(P).apply_async(process_data ...) -> bernoulli.calculate_errors_PB in the
+    workers.  The workers find (start) the broker by themselves; the parent process never touches it."""
+    from moira_amd import broker
+    name = "gpupool_%d" % os.getpid()
+    monkeypatch.setenv("MOIRA_PB_BROKER_NAME", name)
+    monkeypatch.setenv("PYTHONPATH", ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    reads = _reads(77, 200)[:200]
+    want = [oracle.ee_rowwise(s, q, a)[:2] for s, q, a in reads]
+    with mp.get_context("fork").Pool(4) as pool:           # fork, as Python 2's Pool did
+        got = pool.map(_pool_task, reads, chunksize=5)
+    assert [g[0] for g in got] == want
+    assert len({g[1] for g in got}) > 1                    # several workers took part
+    st = broker.stats(name)
+    assert st is not None and st["served"] >= len(reads)
+    broker.shutdown(name)
+    # and in the parent (not a multiprocessing child) the module keeps a context of its own: no broker is started
+    sys.path.insert(0, os.path.join(ROOT, "moira_amd", "dropin"))
+    import bernoulli
+    assert bernoulli.calculate_errors_PB("ACGT", [0] * 4, 0.005) == (3.987440567842452, 0)
+    assert broker.stats(name) is None

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """What an UNCHANGED moira.py gets from the drop-in: its Pool(processors) workers each call
-bernoulli.calculate_errors_PB per read (moira/moira.py:398-399, 817) -- here P worker processes (each with its own
-context on the same GPU) make per-read calls at the same time; aggregate calls per second by P.
-    python tools/per_read_concurrency.py [P ...]        (at most 5 workers: the GPU boxes allow 6 processes on the card)"""
+bernoulli.calculate_errors_PB per read (moira/moira.py:398-399, 817) -- here P worker processes make per-read calls at
+the same time; aggregate calls per second by P.
+    python tools/per_read_concurrency.py [P ...]                 # round 4: through the broker (one GPU-owning process)
+    MOIRA_PB_BROKER=0 python tools/per_read_concurrency.py 1 2 4 5   # round 3: a context per worker (at most 5 workers:
+                                                                     # the GPU boxes allow 6 processes on the card)"""
 import multiprocessing as mp
 import os
 import sys
@@ -12,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def worker(k, n, start, out):
+    os.environ.setdefault("MOIRA_PB_BROKER", "1")
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "moira_amd", "dropin"))
     import numpy as np
@@ -33,11 +36,13 @@ def worker(k, n, start, out):
 
 
 def main():
-    ps = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 5]
+    ps = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16]
     n = 20000
+    direct = os.environ.get("MOIRA_PB_BROKER") == "0"
+    os.environ.setdefault("MOIRA_PB_BROKER_NAME", "conc_%d" % os.getpid())
     ctx = mp.get_context("spawn")                      # no GPU state is inherited: every worker opens its own context
     for p in ps:
-        p = min(p, 5)
+        p = min(p, 5) if direct else p
         start, out = ctx.Event(), ctx.Queue()
         procs = [ctx.Process(target=worker, args=(k, n, start, out)) for k in range(p)]
         for pr in procs:
@@ -47,7 +52,17 @@ def main():
         times = [out.get() for _ in procs]
         for pr in procs:
             pr.join()
-        print("%d worker process(es): %.1f us per call in a worker, %.3e calls/s in all" % (p, max(times) / n * 1e6, p * n / max(times)), flush=True)
+        extra = ""
+        if not direct:
+            sys.path.insert(0, ROOT)
+            from moira_amd import broker
+            st = broker.stats(os.environ["MOIRA_PB_BROKER_NAME"])
+            if st:
+                extra = "  [broker: %d reads in %d launches + %d alone since it started]" % (st["served"], st["batches"], st["solo"])
+        print("%d worker process(es): %.1f us per call in a worker, %.3e calls/s in all%s" % (p, max(times) / n * 1e6, p * n / max(times), extra), flush=True)
+    if not direct:
+        from moira_amd import broker
+        broker.shutdown(os.environ["MOIRA_PB_BROKER_NAME"])
 
 
 if __name__ == "__main__":
