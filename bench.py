@@ -541,6 +541,10 @@ def main():
     times = eng.kernel_times()
     eng.timing(False)
     hist = eng.class_histogram()
+    # one more pass, untimed, that also sums the algorithmic DP cells on the device (fp64_valu.frac_algorithmic)
+    prm_cells = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", fast_fma=args.fast_fma, count_cells=True)
+    eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm_cells, want_counts=False)
+    alg_cells = eng.algorithmic_cells()
     # extra (NOT the headline, work is skipped by design): opt-in MPB_FLAG_DECISION_ONLY, same batch
     extras = {}
     # N = 1 only: with more ranks the others would sit in the closing barrier (120 s timeout) while rank 0 runs them,
@@ -592,6 +596,7 @@ def main():
             extras["classified_at_source"] = classified_rate(eng, d_q, n, stride, L, params, d_ee, d_ns, d_pass)
             extras["long_reads_ragged_50_2000"] = long_ragged_rate(eng, params)
             extras["host_fed"] = host_fed_rate(eng, L, stride, args.seed)
+            extras["config3_paired"] = config3_paired_rate(eng)
             if n != CONFIG4_SHARD:
                 extras["config4_shard"] = config4_shard_rate(eng, L, stride, args.seed, params)
         extras["poisson_error_calc"] = poisson_rate(eng, d_q, n, stride, L, d_ee, d_ns)
@@ -611,13 +616,15 @@ def main():
         # HBM bytes of one k_dp launch from the PMC counters (collected by tools/collect_profiles.sh in
         # separate rocprofv3 passes, corrected as MI355X_MICROARCH.md prescribes); only valid for the
         # workload it was measured on
-        traffic = None
+        traffic, valu_pmc, pmc_source = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and not args.fast_fma:
             t = json.load(open(tpath))
             w = t.get("workload", {})
             if (w.get("reads"), w.get("length"), w.get("seed")) == (n, L, args.seed):
                 traffic = t["hbm_bytes_per_launch"]
+                valu_pmc = t.get("valu")
+                pmc_source = t.get("source")
         step_s = dt / steps
         fp64_floor_ms = cells * opc / FP64_VALU_PEAK * 1e3
         hbm40_ms = alg_bytes / (0.40 * HBM_PEAK_GBS * 1e9) * 1e3
@@ -680,7 +687,21 @@ def main():
                           "floor_ms_per_launch": fp64_floor_ms,
                           "issued_ops_per_launch": issued,
                           "frac_issued": issued / dp_avg_s / FP64_VALU_PEAK if dp_n else None,
-                          "note": "the binding roof: a scalar FP64 recurrence (SURVEY §8d); `frac` counts 3 ops for every cell, `frac_issued` the FP64 instructions actually issued (row 0 of a one-lane class is one multiply)"},
+                          # the cells the ALGORITHM needs -- sum_k min(k + 1, J) per read, J from the epilogue's crossing row,
+                          # summed on the device in one extra untimed pass (MPB_FLAG_COUNT_CELLS) -- against the cells the
+                          # row-budget classes pay for (`cells_per_launch`)
+                          "cells_algorithmic_per_launch": alg_cells,
+                          "cells_algorithmic_per_read": (alg_cells / n) if alg_cells else None,
+                          "frac_algorithmic": alg_cells * opc / dp_avg_s / FP64_VALU_PEAK if (dp_n and alg_cells) else None,
+                          # VALU issue slots used by k_dp, normalised by the clock the chip held (PMC pass of the same
+                          # command; the counters do not travel with the driver's run, the committed summary does)
+                          "valu_busy_pmc": valu_pmc,
+                          "sources": {"avg_launch_ms, cells_*, frac*": "measured live in this run (HIP events on the library's "
+                                                                      "stream; class histogram; MPB_FLAG_COUNT_CELLS pass)",
+                                      "valu_busy_pmc, roofline.traffic": pmc_source,
+                                      "kernel average to compare avg_launch_ms with": "profiles/r04_kernel_stats.csv "
+                                                                                      "(rocprofv3 --kernel-trace --stats)"},
+                          "note": "the binding roof: a scalar FP64 recurrence (SURVEY §8d); `frac` counts 3 ops for every cell of the row-budget classes, `frac_issued` the FP64 instructions actually issued (row 0 of a one-lane class is one multiply), `frac_algorithmic` 3 ops for every cell the algorithm needs"},
             "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in times.items()},
             "kernel_event_pass": {"steps": ev_steps, "note": "HIP events on the library's stream, separate from the wall-clock region"},
             "outcome": {"pass": n_pass, "fail": n_fail, "overflow_reruns": n_ovf},
@@ -695,6 +716,114 @@ def main():
         b.free()
     eng.close()
     coll.close()
+
+
+def config3_paired_rate(eng, pairs_per_chunk=1_000_000, chunks=4):
+    """BASELINE configs[2] ("100M 2x300 bp paired reads, NW contig on CPU then GPU filter") at a size a bench run can
+    afford: `chunks` x `pairs_per_chunk` synthetic 2 x 300-base pairs (450-base fragments: 150 bases of overlap) as FASTQ
+    TEXT IN MEMORY -> record index -> contig construction on the host cores (mothur-style NW + consensus, the build's own
+    libmoira_contig.so; north_star keeps it on the CPU; ref: moira/moira.py:789-801, moira/nw_align.pyx:49-201) -> pack ->
+    GPU filter from host memory.  Stage rates from a pass with the stages one after the other; the end-to-end rate from a
+    pass in which index + contigs of chunk k+1 run on a second thread while chunk k is packed and filtered (what the CLI
+    does).  The same chunk of text is processed `chunks` times (its content does not change what any stage costs)."""
+    import threading
+    import numpy as np
+    from moira_amd import contig as CT, fastio as F
+    n, L, frag, W = pairs_per_chunk, 300, 450, 615
+    rng = np.random.default_rng(3)
+    base = min(n, 250_000)                                   # distinct pairs generated; tiled up to a chunk
+    B = np.frombuffer(b"ACGT", np.uint8)
+    comp = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    frags = B[rng.integers(0, 4, (base, frag))]
+    fwd, rev = frags[:, :L].copy(), comp[frags[:, frag - L:][:, ::-1]]
+    for a in (fwd, rev):                                     # ~0.7 % substitutions, concentrated towards the 3' end
+        pos = np.minimum((rng.random((base, 2)) ** 0.4 * L).astype(int), L - 1)
+        a[np.arange(base)[:, None], pos] = B[rng.integers(0, 4, (base, 2))]
+    qual = (np.clip(38 - (np.arange(L) / L) ** 3 * rng.integers(4, 30, (base, 1)) - rng.integers(0, 6, (base, L)), 2, 40) + 33).astype(np.uint8)
+    bufs = []
+    for arr in (fwd, rev):                                   # fixed-width records: "@p%08d\n" seq "\n+\n" qual "\n" = 614 bytes
+        rec = np.empty((n, W), np.uint8)
+        rec[:, 0], rec[:, 1] = ord("@"), ord("p")
+        ids = np.arange(n)
+        for d in range(8):
+            rec[:, 9 - d] = 48 + (ids // 10 ** d) % 10
+        rec[:, 10] = 10
+        reps = (n + base - 1) // base
+        rec[:, 11:311] = np.tile(arr, (reps, 1))[:n]
+        rec[:, 311], rec[:, 312], rec[:, 313] = 10, ord("+"), 10
+        rec[:, 314:614] = np.tile(qual, (reps, 1))[:n]
+        rec[:, 614] = 10
+        bufs.append(rec.reshape(-1))
+    del frags, fwd, rev, qual
+    threads = CT.usable_cpus()
+    fbuf, rbuf = bufs
+    eng.filter(np.full((8, 608), 30, np.uint8), fixed_len=600)          # warm-up of the host pipeline's slots
+
+    def front(_k):
+        fidx, fc, e1 = F.index(fbuf, True, n, threads=threads)
+        ridx, rc_, e2 = F.index(rbuf, True, n, threads=threads)
+        assert e1 is None and e2 is None and len(fidx) == len(ridx) == n
+        t = time.perf_counter()
+        out = CT.contigs_from_fastq(fbuf, fidx, rbuf, ridx, 33, threads=threads)
+        return out, t
+
+    def back(cb):
+        cbuf, cidx, aux = cb
+        t0 = time.perf_counter()
+        q, lens, has_n = F.pack(cbuf, cidx, None, 33, 0, stride=608, reuse=True)
+        t1 = time.perf_counter()
+        r = eng.filter(q, lens=lens)
+        return r.n_pass, t1 - t0, time.perf_counter() - t1, float(lens.mean())
+    back(front(0)[0])                                        # untimed: thread pools, page faults of the work buffers
+    # pass 1: one stage after the other (stage rates)
+    t_index = t_contig = t_pack = t_filter = 0.0
+    kept = 0
+    t_all = time.perf_counter()
+    for k in range(chunks):
+        t0 = time.perf_counter()
+        cb, t_c0 = front(k)
+        t1 = time.perf_counter()
+        t_index += t_c0 - t0
+        t_contig += t1 - t_c0
+        np_, tp, tf, mean_len = back(cb)
+        kept += np_
+        t_pack += tp
+        t_filter += tf
+    seq_wall = time.perf_counter() - t_all
+    # pass 2: pipelined (front of chunk k+1 beside back of chunk k)
+    res = {}
+
+    def worker(k):
+        res[k] = front(k)[0]
+    t_all = time.perf_counter()
+    th = threading.Thread(target=worker, args=(0,))
+    th.start()
+    kept2 = 0
+    for k in range(chunks):
+        th.join()
+        cb = res.pop(k)
+        if k + 1 < chunks:
+            th = threading.Thread(target=worker, args=(k + 1,))
+            th.start()
+        kept2 += back(cb)[0]
+    pipe_wall = time.perf_counter() - t_all
+    total = n * chunks
+    assert kept2 == kept
+    rate = total / pipe_wall
+    return {"note": "BASELINE configs[2] at bench size: synthetic 2 x 300-base pairs (150 bases of overlap) as FASTQ text in host "
+                    "memory -> index -> NW + consensus on the host cores (north_star keeps contig construction on the CPU) -> "
+                    "pack -> GPU filter from host memory; NOT the headline (it is bound by the host stages, not by the GPU)",
+            "pairs": total, "chunks": chunks, "host_threads": threads, "mean_contig_length": mean_len,
+            "contigs_kept": kept,
+            "stage_pairs_per_s": {"index_both_files": total / t_index, "contig_construction": total / t_contig,
+                                  "pack": total / t_pack, "gpu_filter_incl_pcie": total / t_filter},
+            "stages_one_after_the_other": {"wall_s": seq_wall, "pairs_per_s": total / seq_wall},
+            "pipelined": {"wall_s": pipe_wall, "pairs_per_s": rate,
+                          "note": "index + contigs of chunk k+1 on a second thread while chunk k is packed and filtered"},
+            "projected_wall_s_for_100M_pairs": 1e8 / rate,
+            "gpu_share_of_the_pipelined_wall": t_filter / pipe_wall}
 
 
 def classified_rate(eng, d_q, n, stride, L, params, d_ee, d_ns, d_pass):

@@ -79,6 +79,11 @@ int64_t mio_pread_mt(int32_t fd, int64_t offset, char *dst, int64_t len, int32_t
  *   final           != 0: the input ends with this call
  *   out             out[0, hist) holds the last `hist` (<= 32768 is enough) bytes of the output produced so far (what
  *                   matches may reach back into); new output is written to out[hist, out_cap)
+ * NOTE for callers: with final == 0 the decoder does not start a piece it cannot see whole -- a gzip header incl. its
+ * optional fields (parsed from one contiguous view; FHCRC is skipped, not verified), a block header (it asks for 320
+ * bytes), a member trailer (8 bytes) -- so a return of 0 with *in_used == 0 and *out_used == 0 is LEGAL until final != 0:
+ * offer the unconsumed tail again with more data behind it (at least 320 bytes beyond the tail, or everything that is left
+ * with final = 1).  Only a call made with final != 0 that makes no progress means a truncated file.
  * Returns 0: every complete symbol of the input has been decoded -- call again with the unconsumed tail
  *            in[*in_used, in_len) followed by more data;  1: the output is full (call again with a new output buffer and
  *            the unconsumed input);  2: the gzip file (all members; zero padding ignored) ended cleanly;  < 0: corrupt or

@@ -76,6 +76,12 @@ extern "C" {
                                     pipelines that never look at the ee of a discarded read. */
 #define MPB_FLAG_TEST_UNDERPREDICT 4u /* test hook: halve every predicted row budget so that the
                                          overflow (second) pass is exercised; results are unchanged */
+#define MPB_FLAG_COUNT_CELLS 32u /* diagnostic (bench.py's fp64_valu.frac_algorithmic): mpb_filter_device also sums, over the reads
+                                    its tile kernel reports, the DP cells the ALGORITHM needs -- sum_k min(k + 1, J) over a read's
+                                    scored bases, J = rows up to and including the one whose CDF crosses 1 - alpha --
+                                    as opposed to the cells its row-budget class pays for.  Fetched with
+                                    mpb_last_algorithmic_cells().  Reads settled elsewhere (k_wide, MPB_FLAG_DECISION_ONLY) are
+                                    not counted.  Results are unchanged. */
 #define MPB_FLAG_BATCHED_ONLY 16u /* mpb_filter_host sends batches of <= 4096 reads through one launch with one
                                      read per wave (latency: what a per-read caller sees) instead of the sorted,
                                      tiled pipeline; this flag forces the pipeline.  Results are identical. */
@@ -406,6 +412,8 @@ int mpb_last_class_histogram(mpb_ctx *ctx, int32_t *caps, int64_t *counts, int32
  * (0 for a read MPB_FLAG_DECISION_ONLY settled without a DP); host array of n int32.  Diagnostic: what
  * tools/class_efficiency.py uses to build single-class batches.  Synchronises. */
 int mpb_last_read_budgets(mpb_ctx *ctx, int32_t *caps_out, int64_t n);
+/* Algorithmic DP cells of the last mpb_filter_device call made with MPB_FLAG_COUNT_CELLS (0 without it).  Synchronises. */
+int mpb_last_algorithmic_cells(mpb_ctx *ctx, int64_t *cells);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

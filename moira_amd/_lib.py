@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmoira_pb.so")
 MAX_LEN = 16383     # MPB_MAX_LEN (csrc/mpb_internal.h): longest read (up to 1024 DP rows: one wave; more: k_wide, 16 waves)
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_RANGE = 0, -1, -2, -3, -4, -5
 AMBIG = {"treat_as_errors": 0, "ignore": 1, "disallow": 2}
-FLAG_ROUND, FLAG_FAST_FMA, FLAG_TEST_UNDERPREDICT, FLAG_DECISION_ONLY, FLAG_BATCHED_ONLY = 1, 2, 4, 8, 16
+FLAG_ROUND, FLAG_FAST_FMA, FLAG_TEST_UNDERPREDICT, FLAG_DECISION_ONLY, FLAG_BATCHED_ONLY, FLAG_COUNT_CELLS = 1, 2, 4, 8, 16, 32
 K_PREPASS, K_SCAN, K_SCATTER, K_DP, K_OVERFLOW, K_LAMBDA, K_WIDE = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = {K_PREPASS: "prepass", K_SCAN: "scan", K_SCATTER: "scatter", K_DP: "dp", K_OVERFLOW: "overflow", K_LAMBDA: "lambda",
                 K_WIDE: "wide"}
@@ -95,6 +95,7 @@ PROTOTYPES = {
     "mpb_kernel_time": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mpb_last_class_histogram": (C.c_int, [_VP, _VP, _VP, C.c_int32]),
     "mpb_last_read_budgets": (C.c_int, [_VP, _VP, C.c_int64]),
+    "mpb_last_algorithmic_cells": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -741,9 +741,11 @@ def bgzf_compress(data, level=4):
 
 
 class _BlockCompressedWriter:
-    """A .gz / .bz2 output written as a sequence of independently compressed blocks (gzip members / bzip2 streams -- both
-    formats define the concatenation of valid files as a valid file, and gzip / bz2 / zcat / bzcat read it as one), so
-    that the blocks are compressed on several threads (zlib and bz2 release the GIL) while the caller goes on formatting:
+    """A .gz output written as a sequence of independently compressed blocks (gzip members: the format defines the
+    concatenation of valid files as a valid file, and gzip / zcat / Python 2 and 3 read it as one), so that the blocks are
+    compressed on several threads (zlib releases the GIL) while the caller goes on formatting; a .bz2 output is ONE bzip2
+    stream compressed in order by a thread of its own (Python 2's BZ2File, the reference's reader, stops after the first
+    stream of a multi-stream file):
     write() cuts its data into 1 MiB blocks, hands them to a pool and writes out, in order, whatever has finished; at
     most `WINDOW` blocks are in flight.  One compressor thread per file is what bounds a run with compressed output
     otherwise: ~60 MB/s of text per file at gzip level 4.  A .gz output is BGZF (bgzf_compress: each 1 MiB block becomes
@@ -767,11 +769,19 @@ class _BlockCompressedWriter:
         self.carry = b""
         self.inflight = collections.deque()
         self.wrote = False
+        # .bz2: ONE bzip2 stream, compressed in order by one thread of its own.  Python 2's bz2.BZ2File -- what the
+        # reference reads its inputs with (moira/moira.py:1083-1084) -- stops after the first stream of a file, so a
+        # multi-stream .bz2 written here and fed back to moira.py would be cut short without a word
+        self.bz = bz2.BZ2Compressor() if kind == "bz2" else None
+        self.own = None
+        if self.bz is not None:
+            from concurrent.futures import ThreadPoolExecutor
+            self.own = ThreadPoolExecutor(1)
 
     def _pack(self, block):
         if self.kind == "gz":
             return bgzf_compress(block, 4)                      # level 4: same content, ~4x the speed of level 9
-        return bz2.compress(block)
+        return self.bz.compress(block)                          # (tasks of the one-thread pool run in submission order)
 
     def _drain(self, keep):
         while len(self.inflight) > keep:
@@ -779,7 +789,7 @@ class _BlockCompressedWriter:
             self.wrote = True
 
     def _submit(self, block):
-        self.inflight.append(self.pool().submit(self._pack, block))
+        self.inflight.append((self.own or self.pool()).submit(self._pack, block))
         self._drain(self.WINDOW)
 
     def write(self, data):
@@ -810,8 +820,9 @@ class _BlockCompressedWriter:
             self._drain(0)
             if self.kind == "gz":
                 self.f.write(BGZF_EOF)                          # (also what makes an empty output a valid archive)
-            elif not self.wrote:
-                self.f.write(self._pack(b""))                   # an empty file is still a valid archive
+            else:
+                self.f.write(self.bz.flush())                   # the end of the one stream (an empty file is a valid archive too)
+                self.own.shutdown()
             self.f.close()
             self.f = None
 

@@ -149,7 +149,12 @@ struct mio_collapse {
         char *reserve(int64_t n, int64_t *off)
         {
             const int64_t cap = (int64_t)1 << ARENA_SHIFT;
-            if (n > cap) throw std::bad_alloc();
+            if (n > cap) {                                    // a header or sequence line longer than a block: a block of its own
+                blocks.emplace_back(new char[(size_t)n]);     // (this used to end as "out of memory while collapsing")
+                *off = (int64_t)(blocks.size() - 1) << ARENA_SHIFT;
+                block_used = cap;                             // the next item opens a fresh block
+                return blocks.back().get();
+            }
             if (blocks.empty() || block_used + n > cap) {
                 blocks.emplace_back(new char[(size_t)cap]);
                 block_used = 0;

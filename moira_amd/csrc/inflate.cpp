@@ -387,7 +387,14 @@ int32_t mio_inflate_gzip(mio_inflate *S, const uint8_t *in_buf, int64_t in_len, 
                 if (!z) short_in = true; else pos = (const uint8_t *)z - p + 1;
             }
             if (!short_in && (flg & 2)) { pos += 2; if (n < pos) short_in = true; }     // FHCRC (not verified)
-            if (short_in) { if (final) { rc = ifail(MIO_E_INVALID, "truncated gzip header"); goto out; } rc = 0; goto need_input; }
+            if (short_in) {
+                if (final) { rc = ifail(MIO_E_INVALID, "truncated gzip header"); goto out; }
+                // the optional fields (FEXTRA <= 64 KiB + 2; FNAME / FCOMMENT: zero-terminated, no limit in RFC 1952) are
+                // parsed from one contiguous view of the input: a header that has not ended after 1 MiB is refused by name
+                // instead of surfacing as "no progress" in the caller
+                if (n > (1 << 20)) { rc = ifail(MIO_E_INVALID, "gzip header field (FNAME / FCOMMENT) longer than 1 MiB is not supported"); goto out; }
+                rc = 0; goto need_input;
+            }
             in.p = p + pos;
             S->crc = 0; S->isize = 0; S->any_member = true;
             fold_crc();                       // (nothing pending: crc_from == op here)

@@ -411,6 +411,7 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
         c->ws.pass_count = (unsigned long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 256);
         c->ws.ovf_total = (long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 320);
         c->ws.wide_count = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256) + 384);
+        c->ws.alg_cells = (unsigned long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 448);
         c->ws.lut = c->d_lut;
     }
     if (n <= c->ws_cap) return MPB_OK;
@@ -649,8 +650,21 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     c->classified.valid = false;                     // the workspace now describes THIS batch
     if ((rc = prepare_batch(c, n, max_len))) return rc;
     const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
+    if (params->flags & MPB_FLAG_COUNT_CELLS) HIPCHK(hipMemsetAsync(c->ws.alg_cells, 0, sizeof(unsigned long long), c->stream));
     { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
     return filter_device_tail(c, d_q, n, row_stride, d_len, prm, d_ee, d_ns, d_pass, counts);
+}
+
+int mpb_last_algorithmic_cells(mpb_ctx *c, int64_t *cells)
+{
+    CTXCHK(c);
+    if (!cells) return fail(MPB_E_INVALID, "NULL output");
+    if (!c->ws_small) { *cells = 0; return MPB_OK; }
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, c->ws.alg_cells, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *cells = (int64_t)v;
+    return MPB_OK;
 }
 
 // ---- classified at source (SURVEY f-4 + VERDICT r2 #6) -------------------------------------------------------------

@@ -102,6 +102,7 @@ struct MpbWorkspace {
     int32_t  *wide_rows;   // [n] ... and the rows predicted for each
     int32_t  *wide_count;  // [1]
     unsigned long long *pass_count;  // [1]
+    unsigned long long *alg_cells;   // [1] MPB_FLAG_COUNT_CELLS: algorithmic DP cells of the last mpb_filter_device call
     const double2 *lut;    // [256] {1-p, p'} on device
 };
 

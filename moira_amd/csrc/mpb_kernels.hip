@@ -35,6 +35,9 @@
 // 4 KB {1-p, p'} LUT in LDS.  Module-scope static LDS: the class bodies (non-inlined functions)
 // address it at a link-time constant, so a lookup is one SDWA shift (byte select * 16) + ds_read_b128.
 __shared__ double2 mpb_s_lut[256];
+// MPB_FLAG_COUNT_CELLS: this workgroup's sum of the ALGORITHMIC DP cells of the reads it reported (k_dp only; one LDS
+// atomic per read when the flag is set, one wave-uniform branch per tile when it is not)
+__shared__ unsigned long long mpb_s_cells;
 
 namespace {
 
@@ -762,6 +765,7 @@ struct DpArgs {
     uint8_t *pass;
     int32_t *ovf_list;
     int32_t *ovf_count;
+    unsigned long long *alg_cells;   // MPB_FLAG_COUNT_CELLS: device total of sum_k min(k+1, J) over the reads reported (k_dp)
     const int32_t *perm;        // with perm_ns: the sorted index array the tiles walk (main pass only)
     const uint16_t *perm_ns;    // ns of perm[k]'s read, or nullptr: gather ns[idx]
     MpbDevParams prm;
@@ -950,6 +954,13 @@ __device__ __noinline__ void dp_tiles(const DpArgs *__restrict__ Ap, const int32
                 if (e < 0) e = 0;
             }
             const int nsv = A.perm_ns ? (int)gload(A.perm_ns + (perm_cls - A.perm) + slot) : gload(A.ns + idx);
+            if ((A.prm.flags & 32u) && !never_crossed) {                 // MPB_FLAG_COUNT_CELLS (diagnostic, off by default)
+                // the table the reference fills for this read: rows 0..js over the L' = len - Ns scored bases, of which
+                // row j is non-zero from base j on: sum_k min(k + 1, J), J = js + 1 (SURVEY 8d "algorithmic flops")
+                const int J = js + 1, Lp = li - nsv;                 // J <= 1024, Lp <= 16383: 32-bit arithmetic is enough
+                const int cells = J <= Lp ? ((J * (J + 1)) >> 1) + (Lp - J) * J : (Lp * (Lp + 1)) >> 1;
+                atomicAdd(&mpb_s_cells, (unsigned long long)(unsigned int)cells);
+            }
             if (A.prm.ambig_mode == 0) e = e + (double)nsv;              // moira.py:827-828
             const double limit = (A.prm.maxerrors == A.prm.maxerrors) ? A.prm.maxerrors          // moira.py:925-926
                                                                       : (double)li * A.prm.uncert; // moira.py:949-950
@@ -994,7 +1005,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(DpArgs args,
 {
     __shared__ DpArgs s_args;
     mpb_s_lut[threadIdx.x] = lut_g[threadIdx.x];
-    if (threadIdx.x == 0) s_args = args;
+    if (threadIdx.x == 0) { s_args = args; mpb_s_cells = 0ull; }
     __syncthreads();
     const DpArgs *A = &s_args;
     const int total = tb->total_tiles;
@@ -1017,6 +1028,10 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_dp(DpArgs args,
             default: break;
             }
         }
+    }
+    if (args.prm.flags & 32u) {                                // MPB_FLAG_COUNT_CELLS: one device atomic per workgroup
+        __syncthreads();
+        if (threadIdx.x == 0 && mpb_s_cells) atomicAdd(args.alg_cells, mpb_s_cells);
     }
 }
 
@@ -1565,7 +1580,7 @@ static DpArgs make_args(const uint8_t *q, int64_t stride, const int32_t *len, co
 {
     DpArgs A;
     A.q = q; A.stride = stride; A.len = len; A.ns = ns; A.cls = ws.cls; A.ee = ee; A.pass = pass;
-    A.ovf_list = ws.ovf_list; A.ovf_count = ws.ovf_count; A.prm = prm; A.final_pass = final_pass;
+    A.ovf_list = ws.ovf_list; A.ovf_count = ws.ovf_count; A.alg_cells = ws.alg_cells; A.prm = prm; A.final_pass = final_pass;
     A.perm = ws.perm; A.perm_ns = final_pass == 0 ? ws.perm_ns : nullptr;   // overflow / small-batch passes walk other lists
     return A;
 }

@@ -123,13 +123,13 @@ class Engine:
     # ---- parameters -------------------------------------------------------------------------
     @staticmethod
     def params(alpha=0.005, uncert=0.01, maxerrors=None, ambigs="treat_as_errors", round_=False,
-               fast_fma=False, test_underpredict=False, decision_only=False, batched_only=False):
+               fast_fma=False, test_underpredict=False, decision_only=False, batched_only=False, count_cells=False):
         if ambigs not in L.AMBIG:
             raise ValueError("ambigs must be one of %s" % sorted(L.AMBIG))
         flags = (L.FLAG_ROUND if round_ else 0) | (L.FLAG_FAST_FMA if fast_fma else 0) | \
                 (L.FLAG_TEST_UNDERPREDICT if test_underpredict else 0) | \
                 (L.FLAG_DECISION_ONLY if decision_only else 0) | \
-                (L.FLAG_BATCHED_ONLY if batched_only else 0)
+                (L.FLAG_BATCHED_ONLY if batched_only else 0) | (L.FLAG_COUNT_CELLS if count_cells else 0)
         return L.FilterParams(float(alpha), float(uncert),
                               math.nan if maxerrors is None else float(maxerrors),
                               L.AMBIG[ambigs], flags)
@@ -322,6 +322,13 @@ class Engine:
         a, b = np.empty(256), np.empty(256)
         L.check(self.lib.mpb_device_lut(self.ctx, a.ctypes.data, b.ctypes.data))
         return a, b
+
+    def algorithmic_cells(self):
+        """DP cells the algorithm needs (sum_k min(k + 1, J) per read) for the last filter_device call made with
+        params(count_cells=True)."""
+        v = C.c_int64()
+        L.check(self.lib.mpb_last_algorithmic_cells(self.ctx, C.byref(v)))
+        return v.value
 
     def read_budgets(self, n):
         """Row budget (class cap) of each of the first n reads of the last filter_device call."""

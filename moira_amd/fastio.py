@@ -398,7 +398,8 @@ class GzipReader:
         if self.eof_in:
             return False
         if self.in_len == self.cap:                       # a full buffer that still needs input cannot happen (a symbol is < 48 bits)
-            raise OSError("gzip decoder made no progress")
+            raise OSError("gzip input: a header (FNAME / FCOMMENT / FEXTRA) or block header does not fit the %d-byte input "
+                          "block" % self.cap)
         got = self.raw.readinto(memoryview(self.inbuf)[self.in_len:self.cap])
         if not got:
             self.eof_in = True
@@ -477,8 +478,9 @@ class GzipReader:
         while produced < n:
             if self.in_pos == self.in_len and not self.eof_in:
                 self._more_input()
+            was_final = self.eof_in                            # did THIS call tell the decoder that the input ends here?
             rc = self.L.mio_inflate_gzip(self.st, self.inbuf.ctypes.data + self.in_pos, self.in_len - self.in_pos,
-                                         1 if self.eof_in else 0, out.ctypes.data, h + produced, h + n,
+                                         1 if was_final else 0, out.ctypes.data, h + produced, h + n,
                                          C.addressof(used), C.addressof(made))
             if rc < 0:
                 raise OSError("gzip input: " + self.L.mio_inflate_error().decode())
@@ -489,8 +491,11 @@ class GzipReader:
                 break
             if rc == 1:
                 break
-            # rc == 0: the decoder wants more input
-            if not self._more_input() and used.value == 0 and made.value == 0:
+            # rc == 0: the decoder wants more input.  Without `final` it may stop short of a block header, a gzip header
+            # or a trailer it cannot see whole (include/moira_io.h: zero progress is legal until final != 0), so "no more
+            # input and no progress" only means a truncated file when the call already ran with final = 1; when the end of
+            # the file has just been discovered, the decoder is called once more, with final = 1
+            if not self._more_input() and used.value == 0 and made.value == 0 and was_final:
                 raise OSError("gzip input: truncated file")
         keep = min(self.WINDOW, h + produced)
         self.hist = out[h + produced - keep:h + produced].copy()

@@ -672,3 +672,28 @@ def test_block_compressed_outputs_hold_the_same_text(tmp_path, oracle, monkeypat
     assert outs["none"].keys() == outs[kind].keys() and len(outs["none"]) >= 6
     assert outs["none"] == outs[kind]
     assert sum(len(v) for v in outs["none"].values()) > 50_000          # many 700-byte members per file
+    if kind == "bz2":
+        # ONE bzip2 stream per file: Python 2's BZ2File -- the reference's reader, moira/moira.py:1083-1084 --
+        # stops after the first stream, so a one-shot decompressor must consume the whole file
+        for f in sorted(os.listdir(tmp_path)):
+            if f.startswith("o_bz2."):
+                d = bz2.BZ2Decompressor()
+                raw = open(tmp_path / f, "rb").read()
+                text = d.decompress(raw)
+                assert d.eof and d.unused_data == b"" and text == outs["none"][f.split(".", 1)[1].replace(".bz2", "")]
+
+
+def test_collapse_takes_lines_longer_than_an_arena_block():
+    """a header or sequence longer than the collapse store's 1 MiB block gets a block of its own (it used to
+    fail as 'out of memory while collapsing')."""
+    big = b"ACGT" * 300_000                                    # 1.2 MB sequence
+    recs = [(b"long_read " + b"x" * 10, big), (b"r2", b"ACGTACGT"), (b"long_again", big), (b"r3", b"ACGTACGT")]
+    buf = b"".join(b"@" + h + b"\n" + sq + b"\n+\n" + b"I" * len(sq) + b"\n" for h, sq in recs)
+    idx, consumed, bad = F.index(buf, True, 16)
+    assert len(idx) == 4 and bad is None
+    col = F.Collapse(threads=2)
+    col.add(buf, idx, np.array([1.0, 2.0, 0.5, 3.0]), np.zeros(4, np.uint8))
+    assert len(col) == 2
+    groups = col.export()
+    col.close()
+    assert groups is not None

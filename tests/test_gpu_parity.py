@@ -139,6 +139,32 @@ def test_overflow_pass_is_exercised_and_exact(eng, oracle):
     assert same(r2.ee, ee)
 
 
+def test_algorithmic_cell_count_is_the_oracles(eng, oracle):
+    """MPB_FLAG_COUNT_CELLS (bench.py's fp64_valu.frac_algorithmic): the device-side sum of sum_k min(k + 1, J) over the
+    reads equals the same sum taken from the oracle's rows J; with and without the overflow pass; results unchanged."""
+    def want(rows, lens, ns):
+        J, Lp = rows.astype(np.int64), (lens - ns).astype(np.int64)
+        return int(np.where(J <= Lp, J * (J + 1) // 2 + (Lp - J) * J, Lp * (Lp + 1) // 2).sum())
+    for kw, gen in (({"fixed_len": 300}, dict(n=60000, stride=320, fixed_len=300, seed=2)),
+                    ({}, dict(n=50000, stride=608, min_len=50, max_len=600, seed=5))):
+        q, lens = oracle.synth_fill(**gen)
+        ee, ns, ps, rows = oracle.filter_batch(q, lens=lens, threads=8)
+        n, stride = q.shape
+        d_q, d_len = eng.alloc(q.nbytes).upload(q), eng.alloc(n * 4).upload(lens)
+        d_ee, d_ns, d_pass = eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
+        for under in (False, True):
+            prm = eng.params(count_cells=True, test_underpredict=under)
+            c = eng.filter_device(d_q, n, stride, d_len=None if kw else d_len, fixed_len=kw.get("fixed_len", 0),
+                                  d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm)
+            assert eng.algorithmic_cells() == want(rows, lens, ns)
+            assert same(d_ee.download(np.float64, n), ee)
+            assert (c.n_overflow > 100) == under
+        eng.filter_device(d_q, n, stride, d_len=None if kw else d_len, fixed_len=kw.get("fixed_len", 0),
+                          d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=eng.params())
+        for b in (d_q, d_len, d_ee, d_ns, d_pass):
+            b.free()
+
+
 def test_wide_classes(eng, oracle):
     """Reads needing hundreds of DP rows (G > 1 classes, DPP row hand-over, staged CDF)."""
     rng = np.random.default_rng(5)

@@ -323,3 +323,40 @@ def test_cli_reads_bgzf_input_like_plain_input(tmp_path, oracle):
                 outs[label][f.split(".", 1)[1].replace(".gz", "")] = data
     assert outs["plain"].keys() == outs["bgzf"].keys() and len(outs["plain"]) >= 6
     assert outs["plain"] == outs["bgzf"]
+
+
+def test_end_of_file_found_just_after_a_full_input_block():
+    """the decoder may stop short of a block header / trailer it cannot see whole until it is told
+    that the input ends; when the read that discovers the end of the file comes right after such a stop, the reader must
+    call the decoder once more with final = 1 instead of reporting a truncated file.  Sweep: compressed size = k x in_block
+    + 1 .. 400 bytes, ending in a tiny last block (after a full flush), single-member and with a BGZF-style empty member
+    at the end; every one is a VALID gzip file."""
+    rng = np.random.default_rng(11)
+    in_block = 4096
+    body = bytes(rng.integers(0, 256, 3 * in_block, dtype=np.uint8))          # incompressible: the size is steerable
+    empty_member = gzip.compress(b"")
+    checked = 0
+    for k in (1, 2):
+        for extra in list(range(1, 60)) + list(range(60, 401, 7)):
+            for tail_kind in ("tiny_block", "empty_member"):
+                target = k * in_block + extra
+                # a stored-ish first part sized so that the whole file lands on `target` bytes
+                for n_body in range(target - 60, target - 10):
+                    c = zlib.compressobj(1, zlib.DEFLATED, 31)
+                    comp = c.compress(body[:n_body]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(b"xy") + c.flush()
+                    if tail_kind == "empty_member":
+                        comp += empty_member
+                    if len(comp) == target:
+                        break
+                else:
+                    continue
+                want = body[:n_body] + b"xy"
+                assert gzip.decompress(comp) == want
+                assert decode(comp, read_size=1 << 16, in_block=in_block) == want, (target, tail_kind)
+                checked += 1
+    assert checked > 150
+    # and a file that really is cut short still fails
+    c = zlib.compressobj(1, zlib.DEFLATED, 31)
+    comp = c.compress(body[:in_block]) + c.flush()
+    with pytest.raises(OSError):
+        decode(comp[:-5], in_block=in_block)

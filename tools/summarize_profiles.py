@@ -77,6 +77,16 @@ if "hbm_read_bytes" in dp and "hbm_write_bytes" in dp:
                "workload": {"reads": 10000000, "length": 300, "stride": 320, "seed": 2},
                "kernel": "k_dp", "hbm_read_bytes_per_launch": dp["hbm_read_bytes"],
                "hbm_write_bytes_per_launch": dp["hbm_write_bytes"],
-               "hbm_bytes_per_launch": dp["hbm_read_bytes"] + dp["hbm_write_bytes"]},
+               "hbm_bytes_per_launch": dp["hbm_read_bytes"] + dp["hbm_write_bytes"],
+               # how busy the vector ALUs were, normalised by the clock the chip actually held: SQ_INSTS_VALU counts
+               # wave-instructions, each occupies its SIMD for 4 cycles (64 lanes over 16); GRBM_GUI_ACTIVE is summed over
+               # the 8 XCDs; 256 CUs x 4 SIMDs
+               "valu": ({"source": "profiles/%s_pmc.json, pass `sq` of tools/collect_profiles.sh" % tag,
+                         "SQ_INSTS_VALU": dp["SQ_INSTS_VALU"], "GRBM_GUI_ACTIVE": dp["GRBM_GUI_ACTIVE"],
+                         "duration_us": dp["duration_us"], "clock_ghz": dp.get("clock_ghz"),
+                         "simd_cycles_issued": dp["SQ_INSTS_VALU"] * 4,
+                         "simd_cycles_available": dp["GRBM_GUI_ACTIVE"] / 8 * 1024,
+                         "valu_busy": dp["SQ_INSTS_VALU"] * 4 / (dp["GRBM_GUI_ACTIVE"] / 8 * 1024)}
+                        if "SQ_INSTS_VALU" in dp and "GRBM_GUI_ACTIVE" in dp else None)},
               open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: {c: round(x, 3) for c, x in v.items()} for k, v in out.items() if k.startswith(("k_dp", "k_prepass"))}, indent=1))
