@@ -145,7 +145,9 @@ __device__ __forceinline__ void pre_chunk(const float2 *tab, const uint4 x, f32x
         for (int t = 0; t < 4; t++) {
             const float2 e = tab[(ww[d] >> (8 * t)) & 0xffu];
             a01 += (f32x2){e.x, e.y};
+#ifndef MPB_PREPASS_NO_K3                                 // experiment (profiles/r04_prepass_variants.txt): 2 instead of 3 VALU per byte
             s3 = __builtin_fmaf(e.x, e.y, s3);            // p == 0 for marked bytes
+#endif
         }
 }
 
@@ -364,7 +366,11 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         const float pvar = rem - MPB_MARK_UPPER * nzero;
         mu += a01.x;
         var += pvar;
+#ifdef MPB_PREPASS_NO_K3
+        k3 += pvar;                                                       // kappa3 := sigma^2: conservative (never under-predicts)
+#else
         k3 += pvar - 2.0f * s3;                                           // sum p(1-p)(1-2p)
+#endif
         ambi += (int)nzero + ((int)n255 << 16);
         };  // panel
         if (LONG) { for (int pb = 0; pb < ncol; pb += 12 * MPB_PRE_NB) panel(pb, min(ncol, pb + 12 * MPB_PRE_NB)); }

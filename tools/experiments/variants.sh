@@ -16,7 +16,7 @@ names=()
 for spec in "$@"; do
   name=${spec%%:*}; rest=${spec#*:}; defs=${rest%%@*}; names+=($name)
   SRC=moira_amd/csrc/mpb_kernels.hip; if [ "$rest" != "$defs" ]; then SRC=${rest#*@}; fi     # name:"-Dflags"@other_kernels.hip
-  /opt/rocm/bin/hipcc $FL $defs $SRC moira_amd/csrc/mpb_api.cpp -o /tmp/var/$name.so 2>/tmp/var/$name.err || { echo "build of $name failed"; tail -5 /tmp/var/$name.err; exit 1; }
+  /opt/rocm/bin/hipcc $FL $defs $SRC moira_amd/csrc/mpb_api.cpp moira_amd/csrc/mpb_broker.cpp -o /tmp/var/$name.so 2>/tmp/var/$name.err || { echo "build of $name failed"; tail -5 /tmp/var/$name.err; exit 1; }
 done
 if [ $TESTS = 1 ]; then for v in "${names[@]}"; do
   echo "== parity $v: $(MOIRA_PB_LIB=/tmp/var/$v.so timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -1)"
