@@ -73,9 +73,20 @@ def _locked_build(lib, deps, flags, cmd, force, verbose):
                 os.replace(tmp, lib)
                 with open(lib + ".stamp", "w") as f:
                     f.write(_digest(deps, flags))
+                if verbose:
+                    print("%s: COMPILED now (sources + flags digest %s)" % (os.path.basename(lib), _digest(deps, flags)[:16]))
+            elif verbose:
+                print("%s: up to date" % os.path.basename(lib))
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
     return lib
+
+
+def report(lib, deps, flags):
+    """One line saying what build() found: VERDICT r3 asked that a no-op build be visible as such."""
+    state = "STALE" if _is_stale(lib, deps, flags) else "up to date: its stamp equals the digest of its sources + flags"
+    print("%s: %s (digest %s, %d bytes)" % (os.path.basename(lib), state, _digest(deps, flags)[:16],
+                                            os.path.getsize(lib) if os.path.exists(lib) else 0))
 
 
 CONTIG_FLAGS = ["-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-pthread", "-Wall"]

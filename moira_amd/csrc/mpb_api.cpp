@@ -20,7 +20,7 @@
 #include <unordered_map>
 #include <vector>
 
-#define MPB_VERSION_STR "moira_pb 0.3.0 (gfx950)"
+#define MPB_VERSION_STR "moira_pb 0.4.0 (gfx950)"
 
 static thread_local char g_err[512] = "";
 
@@ -781,6 +781,10 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
 #ifndef MPB_SMALL_N
 #define MPB_SMALL_N 4096
 #endif
+// small batches whose inputs are at most this many bytes are read by the kernel straight from pinned host memory
+#ifndef MPB_SMALL_ZC_BYTES
+#define MPB_SMALL_ZC_BYTES (1 << 20)
+#endif
 // qualities per chunk of the host pipeline: large enough that a chunk's launch sequence (~0.2 ms fixed) is
 // noise beside its 2 ms of PCIe time; the four slots then hold 4 x (128 MiB of qualities + 5.5 MiB of results) of device
 // memory, the same again of pinned staging when the input is pageable, and 4 x 5.5 MiB of pinned results
@@ -805,7 +809,7 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
     if (in_bytes + out_bytes > c->pin_cap) {
         if (c->pin_host) { HIPCHK(hipHostFree(c->pin_host)); c->pin_host = nullptr; c->pin_cap = 0; }
         const int64_t cap = 2 * (in_bytes + out_bytes);
-        HIPCHK(hipHostMalloc(&c->pin_host, (size_t)cap, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&c->pin_host, (size_t)cap, hipHostMallocMapped));
         c->pin_cap = cap;
     }
     char *h = (char *)c->pin_host, *d = (char *)c->stage_dev;
@@ -816,12 +820,25 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
     double *d_ee = (double *)(d + in_bytes);
     int32_t *d_ns = (int32_t *)(d + in_bytes + b_ee);
     uint8_t *d_pass = (uint8_t *)(d + in_bytes + b_ee + b_ns);
-    HIPCHK(hipMemcpyAsync(d, h, (size_t)(len ? in_bytes : n * row_stride), hipMemcpyHostToDevice, c->stream));
     const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
-    { Span t(c, MPB_K_DP); mpb_launch_small(d_q, n, row_stride, len ? d_len : nullptr, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
-    HIPCHK(hipGetLastError());
     char *ho = h + in_bytes;
-    HIPCHK(hipMemcpyAsync(ho, d + in_bytes, (size_t)out_bytes, hipMemcpyDeviceToHost, c->stream));
+#ifdef MPB_TUNING_KNOBS          // experiment builds only
+    static const int64_t zc_bytes = getenv("MPB_SMALL_ZC_BYTES") ? atoll(getenv("MPB_SMALL_ZC_BYTES")) : MPB_SMALL_ZC_BYTES;
+#else
+    constexpr int64_t zc_bytes = MPB_SMALL_ZC_BYTES;
+#endif
+    if (in_bytes <= zc_bytes) {
+        // a handful of reads (the per-read entry: ONE): the kernel reads the rows from, and writes the results to, the pinned
+        // host block -- one runtime call instead of three dependent ones (copy in, kernel, copy out)
+        { Span t(c, MPB_K_DP); mpb_launch_small((const uint8_t *)h, n, row_stride, len ? (const int32_t *)(h + b_q) : nullptr, prm, c->ws,
+                                                 (int32_t *)(ho + b_ee), (double *)ho, (uint8_t *)(ho + b_ee + b_ns), c->stream); }
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpyAsync(d, h, (size_t)(len ? in_bytes : n * row_stride), hipMemcpyHostToDevice, c->stream));
+        { Span t(c, MPB_K_DP); mpb_launch_small(d_q, n, row_stride, len ? d_len : nullptr, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ho, d + in_bytes, (size_t)out_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint8_t *hp = (const uint8_t *)(ho + b_ee + b_ns);
     int64_t np = 0;

@@ -176,6 +176,7 @@ struct Broker {
     int n_slots;
     Lane lane[BRK_LANES];
     size_t off_q, off_ee, off_ns, off_pass, off_cls, off_ident;       // offsets inside a lane's blocks (n_slots reads)
+    bool zero_copy = true;                                             // MPB_BROKER_COPIES=1: stage through HBM with two async copies
 
     int init_lanes()
     {
@@ -191,8 +192,8 @@ struct Broker {
         const size_t dev_cap = off_ident + ns * 4;
         for (Lane &l : lane) {
             BHIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-            BHIP(hipHostMalloc((void **)&l.pin_in, in_cap, hipHostMallocDefault));
-            BHIP(hipHostMalloc((void **)&l.pin_out, out_cap, hipHostMallocDefault));
+            BHIP(hipHostMalloc((void **)&l.pin_in, in_cap, hipHostMallocMapped));
+            BHIP(hipHostMalloc((void **)&l.pin_out, out_cap, hipHostMallocMapped));
             BHIP(hipMalloc((void **)&l.dev, dev_cap));
             l.in_cap = in_cap; l.out_cap = out_cap; l.dev_cap = dev_cap;
         }
@@ -247,14 +248,25 @@ struct Broker {
         }
         l.m = m; l.stride = stride;
         char *d = l.dev;
-        const size_t in_bytes = off_q + (size_t)m * stride;
-        BHIP(hipMemcpyAsync(d, l.pin_in, in_bytes, hipMemcpyHostToDevice, l.stream));
-        char *d_out = d + l.in_cap;
-        int rc = mpbi_small_async(ctx, (const uint8_t *)d + off_q, m, stride, (const int32_t *)d, alpha, (double *)(d_out + off_ee),
-                                  (int32_t *)(d_out + off_ns), (uint8_t *)(d_out + off_pass), (uint8_t *)d + off_cls,
-                                  (int32_t *)(d + off_ident), l.stream);
-        if (rc) return rc;
-        BHIP(hipMemcpyAsync(l.pin_out, d_out, off_pass + (size_t)n_slots, hipMemcpyDeviceToHost, l.stream));
+        if (zero_copy) {
+            // ONE runtime call per micro-batch: the kernel reads the rows from, and writes the results to, the lane's pinned
+            // host blocks (mapped into the device's address space); only its scratch (class bytes, identity list) is in HBM.
+            // A few hundred bytes per read over the link cost less than two more asynchronous copies cost the broker thread,
+            // which is what bounds the call rate at P = 16.
+            int rc = mpbi_small_async(ctx, (const uint8_t *)l.pin_in + off_q, m, stride, (const int32_t *)l.pin_in, alpha,
+                                      (double *)(l.pin_out + off_ee), (int32_t *)(l.pin_out + off_ns), (uint8_t *)(l.pin_out + off_pass),
+                                      (uint8_t *)d + off_cls, (int32_t *)(d + off_ident), l.stream);
+            if (rc) return rc;
+        } else {
+            const size_t in_bytes = off_q + (size_t)m * stride;
+            BHIP(hipMemcpyAsync(d, l.pin_in, in_bytes, hipMemcpyHostToDevice, l.stream));
+            char *d_out = d + l.in_cap;
+            int rc = mpbi_small_async(ctx, (const uint8_t *)d + off_q, m, stride, (const int32_t *)d, alpha, (double *)(d_out + off_ee),
+                                      (int32_t *)(d_out + off_ns), (uint8_t *)(d_out + off_pass), (uint8_t *)d + off_cls,
+                                      (int32_t *)(d + off_ident), l.stream);
+            if (rc) return rc;
+            BHIP(hipMemcpyAsync(l.pin_out, d_out, off_pass + (size_t)n_slots, hipMemcpyDeviceToHost, l.stream));
+        }
         l.busy = true;
         map.hdr()->batches.fetch_add(1, std::memory_order_relaxed);
         return MPB_OK;
@@ -321,6 +333,7 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
     h->device.store(mpbi_ctx_device(ctx));
     h->heartbeat_ms.store(now_ms());
     h->version = BRK_VERSION;
+    b.zero_copy = !(getenv("MPB_BROKER_COPIES") && atoi(getenv("MPB_BROKER_COPIES")) != 0);
     rc = b.init_lanes();
     if (rc == MPB_OK) {
         std::atomic_thread_fence(std::memory_order_seq_cst);

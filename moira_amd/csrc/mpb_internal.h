@@ -35,6 +35,12 @@ struct MpbClass { int cap, G, R; };
     X(26, 10, 16) X(27, 12, 16) X(28, 16, 16)                                                \
     X(29, 12, 32) X(30, 16, 32) X(31, 16, 64)
 
+// Latency bodies of the one-read-per-wave kernel (k_small): X(id, R, G) with cap = R * G = 2^(id + 1); a read of `rows` rows takes
+// id = ceil(log2(rows)) - 1.  (2, 1) and (16, 64) are tile classes as well; the others exist only here.
+#define MPB_THIN_CLASSES(X)                                                                  \
+    X(0, 2, 1) X(1, 2, 2) X(2, 2, 4) X(3, 2, 8) X(4, 2, 16) X(5, 2, 32) X(6, 2, 64)          \
+    X(7, 4, 64) X(8, 8, 64) X(9, 16, 64)
+
 #define MPB_CLASS_ENTRY(ID, RR, GG) {(RR) * (GG), GG, RR},
 #define MPB_CLASS_TABLE { MPB_CLASSES(MPB_CLASS_ENTRY) }
 

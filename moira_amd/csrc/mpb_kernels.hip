@@ -1274,6 +1274,11 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
         return;
     }
     const int c = c_class_of_rows.t[rows];
+    // One read per wave: a G = 1 body would keep ONE lane busy.  The latency bodies below spread the read's rows over as
+    // many lanes as they fill two (then 4 / 8 / 16) rows each -- cap 2, 4, 8 ... 1024 = the next power of two -- so that a
+    // base costs ~10 instead of ~3 * rows instructions of the wave's dependent chain (a 300-base read of 10 rows:
+    // ~18 -> ~8 us).  Same cell arithmetic, same sequential CDF: the split of the rows over lanes never shows in a result.
+    const int thin = rows <= 2 ? 0 : 31 - __builtin_clz(rows - 1);
     bool settled = false;
     if (prm.flags & 8u) {                                                 // MPB_FLAG_DECISION_ONLY, as k_prepass
         const float t = mu * (1.0f - 1e-4f) - prm.clow * sqrtf(mu) - 0.02f;
@@ -1289,9 +1294,9 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
     if (settled) return;
     __threadfence();                                      // the class body reads ns / cls / ident back
     const int32_t *pc = ident + i;
-    switch (c) {
+    switch (thin) {
 #define MPB_CASE(ID, RR, GG) case ID: dp_tiles<RR, GG, FMA>(&s_args, pc, 1, 0, 1); break;
-        MPB_CLASSES(MPB_CASE)
+        MPB_THIN_CLASSES(MPB_CASE)
 #undef MPB_CASE
     default: break;
     }

@@ -100,8 +100,14 @@ def test_no_fma_in_exact_dp_kernel():
     bodies = re.split(r"\n(?=_ZN\S+:)", text)
     exact = [b for b in bodies if re.match(r"_ZN\S*dp_tilesILi\d+ELi\d+ELb0EE", b)]
     fast = [b for b in bodies if re.match(r"_ZN\S*dp_tilesILi\d+ELi\d+ELb1EE", b)]
-    ncls = int(re.search(r"#define MPB_NCLS (\d+)", open(os.path.join(ROOT, "moira_amd", "csrc", "mpb_internal.h")).read()).group(1))
-    assert len(exact) == ncls and len(fast) == ncls
+    hdr = open(os.path.join(ROOT, "moira_amd", "csrc", "mpb_internal.h")).read()
+    ncls = int(re.search(r"#define MPB_NCLS (\d+)", hdr).group(1))
+    shapes = lambda macro: {(int(r), int(g)) for _, r, g in re.findall(r"X\((\d+), (\d+), (\d+)\)", re.search(
+        r"#define %s\(X\)((?:.*\\\n)*.*)" % macro, hdr).group(1))}
+    tile, thin = shapes("MPB_CLASSES"), shapes("MPB_THIN_CLASSES")       # thin: the latency bodies of k_small (round 4)
+    assert len(tile) == ncls and len(thin) == 10 and len(thin - tile) == 8
+    nbodies = len(tile | thin)
+    assert len(exact) == nbodies and len(fast) == nbodies
     for b in exact:
         assert b.count("v_fma_f64") == 3 and b.count("v_fmac_f64") == 2, b.split(":")[0]
         assert b.count("v_div_fixup_f64") == 1
