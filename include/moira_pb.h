@@ -314,6 +314,24 @@ int mpb_calculate_errors_PB(mpb_ctx *ctx, const char *contig,
                             const int32_t *contig_quals, int32_t len,
                             double alpha, double *ee, int32_t *ns);
 
+/* ---- batches with scores above 254 (round 4) ---------------------------------------------------------------------- */
+/*
+ * ref: moira/bernoullimodule.c:92-108 takes any int score; the byte matrix has 254 score codes.  mpb_pack_batch_coded packs a
+ * batch (concatenated sequences -- NULL: no ambiguous bases -- and INTEGER scores, off[n + 1] offsets; max_len > 0 truncates,
+ * moira/moira.py:806-807) and gives every distinct score above 254 a byte code the batch does not use, from 254 down;
+ * code_scores[256] receives what each code stands for (code_scores[c] == c for the untouched ones; entries 0 and 255 are the
+ * N / n markers).  MPB_E_RANGE when the batch has more such scores than free codes (split it, or use the per-read entry) or a
+ * negative score.  mpb_filter_host_coded is mpb_filter_host on such a matrix: the call runs on a private copy of the
+ * {1 - p, p'} table in which code c carries the values of score code_scores[c] (same libm expressions); NULL = the plain
+ * entry.  A code should stand for a score >= its own value: the row predictor reads codes as scores, so a code that
+ * understates its error probability only costs re-runs, never a result.  Poisson-binomial methods only.
+ */
+int mpb_pack_batch_coded(const char *seq_cat, const int32_t *qual_cat, const int64_t *off, int64_t n, int32_t max_len,
+                         int64_t row_stride, uint8_t *q_out, int32_t *len_out, int32_t *code_scores);
+int mpb_filter_host_coded(mpb_ctx *ctx, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
+                          int32_t fixed_len, const mpb_filter_params *params, const int32_t *code_scores,
+                          double *ee, int32_t *ns, uint8_t *pass, mpb_filter_counts *counts);
+
 /* ---- per-read calls from many worker processes: the broker -------------------------------------- */
 /*
  * Reference shape: moira/moira.py:398-399,431-454 -- `Pool(args.processors)` worker processes, each calling

@@ -76,6 +76,9 @@ PROTOTYPES = {
                                           C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mpb_calculate_errors_poisson": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int32, C.c_double,
                                                C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "mpb_pack_batch_coded": (C.c_int, [C.c_char_p, _VP, _VP, C.c_int64, C.c_int32, C.c_int64, _VP, _VP, _VP]),
+    "mpb_filter_host_coded": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int32,
+                                        C.POINTER(FilterParams), _VP, _VP, _VP, _VP, C.POINTER(FilterCounts)]),
     "mpb_broker_serve": (C.c_int, [_VP, C.c_char_p, C.c_int32, C.c_int32]),
     "mpb_broker_attach": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_VP)]),
     "mpb_broker_call": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int32, C.c_double,

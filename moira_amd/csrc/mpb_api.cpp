@@ -1165,6 +1165,79 @@ struct PrivateTable {
     ~PrivateTable() { if (on) c->ws.lut = c->d_lut; }
 };
 
+// ---- batches whose reads carry scores above 254 (missing 3: the reference takes any int) ----------------
+// The byte matrix has 254 score codes.  A batch rarely uses them all, so -- exactly as the per-read entry does for one read --
+// the packer gives every distinct out-of-range score of the BATCH a code the batch does not use (from 254 down: the row
+// predictor reads codes as scores, and up there every code means "practically never wrong") and reports what each code
+// stands for; mpb_filter_host_coded runs the ordinary pipeline on a private copy of the table built from that list.
+
+int mpb_pack_batch_coded(const char *seq_cat, const int32_t *qual_cat, const int64_t *off, int64_t n, int32_t max_len,
+                         int64_t row_stride, uint8_t *q_out, int32_t *len_out, int32_t *code_scores)
+{
+    if (!qual_cat || !off || !q_out || !len_out || !code_scores || n < 0) return fail(MPB_E_INVALID, "bad arguments");
+    if (row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "row_stride must be a positive multiple of 16");
+    bool used[256] = {};
+    std::unordered_map<int32_t, int> code_of;
+    std::vector<int32_t> big;                         // distinct out-of-range scores in order of first appearance
+    for (int64_t i = 0; i < n; i++) {
+        int64_t L = off[i + 1] - off[i];
+        if (L < 0) return fail(MPB_E_INVALID, "offsets must not decrease");
+        if (max_len > 0 && L > max_len) L = max_len;
+        if (L > row_stride) return fail(MPB_E_INVALID, "read %lld (%lld bases) does not fit row_stride %lld", (long long)i, (long long)L, (long long)row_stride);
+        for (int64_t k = 0; k < L; k++) {
+            const int32_t q = qual_cat[off[i] + k];
+            if (q < 0) return fail(MPB_E_RANGE, "Qualities must have positive values.");
+            if (q <= 254) used[q == 0 ? 1 : q] = true;
+            else if (code_of.emplace(q, -1).second) big.push_back(q);
+        }
+    }
+    for (int c = 0; c < 256; c++) code_scores[c] = c;
+    int next = 254;
+    for (int32_t q : big) {
+        while (next >= 1 && used[next]) next--;
+        if (next < 1)
+            return fail(MPB_E_RANGE, "the batch holds %zu distinct scores above 254 but uses all but %zu of the 254 byte codes: "
+                        "split it (or score such reads through mpb_calculate_errors_PB)", big.size(), (size_t)(&q - big.data()));
+        used[next] = true;
+        code_of[q] = next;
+        code_scores[next] = q;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        int64_t L = off[i + 1] - off[i];
+        if (max_len > 0 && L > max_len) L = max_len;
+        uint8_t *row = q_out + i * row_stride;
+        for (int64_t k = 0; k < L; k++) {
+            const int32_t q = qual_cat[off[i] + k];
+            const char base = seq_cat ? seq_cat[off[i] + k] : 'A';
+            row[k] = pack_one(base, q <= 254 ? q : code_of[q]);
+        }
+        memset(row + L, 0, (size_t)(row_stride - L));
+        len_out[i] = (int32_t)L;
+    }
+    return MPB_OK;
+}
+
+int mpb_filter_host_coded(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len, int32_t fixed_len,
+                          const mpb_filter_params *params, const int32_t *code_scores, double *ee, int32_t *ns, uint8_t *pass,
+                          mpb_filter_counts *counts)
+{
+    CTXCHK(c);
+    if (!code_scores) return mpb_filter_host(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts);
+    double2 h[256];
+    build_lut(h);
+    bool any = false;
+    for (int code = 1; code <= 254; code++) {
+        if (code_scores[code] == code) continue;
+        if (code_scores[code] < 1) return fail(MPB_E_RANGE, "code %d stands for score %d: scores are >= 1 (Q0 is clamped to 1 at pack time)", code, code_scores[code]);
+        lut_entry(code_scores[code], &h[code]);
+        any = true;
+    }
+    PrivateTable guard(c);
+    int rc;
+    if (any && (rc = guard.install(h)) != MPB_OK) return rc;
+    return mpb_filter_host(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts);
+}
+
 // argument rules of the per-read entry (moira/bernoullimodule.c:79-90), shared with the broker's client side
 int mpbi_check_one_read(const char *contig, const int32_t *contig_quals, int32_t len, double alpha, const void *ee, const void *ns)
 {

@@ -243,16 +243,49 @@ class Engine:
                                            C.byref(counts) if want_counts else None))
         return counts if want_counts else None
 
-    def filter(self, q, lens=None, fixed_len=None, out=None, **kw):
-        """Filter a packed host matrix q (n x stride uint8).  Returns FilterResult."""
+    def pack_coded(self, seqs, quals, stride=None, max_len=0):
+        """Reads whose scores may exceed 254 (any non-negative int, as moira/bernoullimodule.c:92-108 takes them) ->
+        (q uint8[n, stride], lens int32[n], code_scores int32[256]): every distinct score above 254 of the BATCH gets a
+        byte code the batch does not use; `code_scores[c]` is what code c stands for.  ValueError (MPB_E_RANGE) when the
+        batch has more such scores than free codes.  Pass code_scores on to filter()."""
+        n = len(quals)
+        off = np.zeros(n + 1, np.int64)
+        if n:
+            off[1:] = np.cumsum([len(x) for x in quals])
+        if seqs is not None and any(len(s) != len(x) for s, x in zip(seqs, quals)):
+            raise ValueError("contig and contig_quals must have the same length")
+        lens_full = off[1:] - off[:-1]
+        longest = int(min(lens_full.max(), max_len) if (n and max_len > 0) else (lens_full.max() if n else 1))
+        if stride is None:
+            stride = _round_up(max(longest, 1), 16)
+        flat = np.concatenate([np.asarray(x, np.int64) for x in quals]) if n and off[-1] else np.empty(0, np.int64)
+        if len(flat) and (flat.min() < -(1 << 31) or flat.max() >= (1 << 31)):
+            raise ValueError("a quality score does not fit a C int")
+        flat = np.ascontiguousarray(flat, np.int32)
+        q = np.empty((n, stride), np.uint8)
+        lens = np.empty(n, np.int32)
+        codes = np.empty(256, np.int32)
+        L.check(self.lib.mpb_pack_batch_coded("".join(seqs).encode() if seqs is not None else None, flat.ctypes.data,
+                                              off.ctypes.data, n, int(max_len), stride, q.ctypes.data, lens.ctypes.data,
+                                              codes.ctypes.data))
+        return q, lens, codes
+
+    def filter(self, q, lens=None, fixed_len=None, out=None, code_scores=None, **kw):
+        """Filter a packed host matrix q (n x stride uint8).  Returns FilterResult.  code_scores: what pack_coded returned
+        (a batch that carries scores above 254)."""
         kw.setdefault("batched_only", self.batched_only)
         params = kw.pop("params", None) or self.params(**kw)
         q, n, stride, lens, (ee, ns, ps) = check_host_batch(q, lens, fixed_len, out, limit=L.MAX_LEN)
         counts = L.FilterCounts()
-        L.check(self.lib.mpb_filter_host(self.ctx, q.ctypes.data, n, stride,
-                                         lens.ctypes.data if lens is not None else None,
-                                         0 if lens is not None else int(fixed_len), C.byref(params),
-                                         ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, C.byref(counts)))
+        if code_scores is not None:
+            code_scores = np.ascontiguousarray(code_scores, np.int32)
+            if code_scores.shape != (256,):
+                raise ValueError("code_scores must hold 256 entries")
+        L.check(self.lib.mpb_filter_host_coded(self.ctx, q.ctypes.data, n, stride,
+                                               lens.ctypes.data if lens is not None else None,
+                                               0 if lens is not None else int(fixed_len), C.byref(params),
+                                               code_scores.ctypes.data if code_scores is not None else None,
+                                               ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, C.byref(counts)))
         return FilterResult(ee, ns, ps.view(bool), counts.n_pass, counts.n_overflow)   # pass bytes are 0 / 1
 
     def filter_poisson(self, q, lens=None, fixed_len=None, out=None, **kw):

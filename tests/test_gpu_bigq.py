@@ -142,3 +142,78 @@ def test_cli_scores_a_qual_file_with_big_scores(tmp_path, oracle):
     for k, (seq, quals) in enumerate(recs):
         e, ns = calculate_errors_poisson(seq, quals, 0.005)
         assert (("r%d" % k) in good) == (not (e > 0.02 * len(seq))), k
+
+
+def test_batches_with_big_scores_through_the_coded_entry(eng, oracle):
+    """Round 4 (missing 3): the BATCH entries take scores above 254 too -- mpb_pack_batch_coded gives every
+    distinct out-of-range score of the batch a spare byte code, mpb_filter_host_coded runs the pipeline on a private copy
+    of the table.  The reference's own results for the big-score reads (tests/golden/bigq.json), in batches; then a large
+    random batch (tile pipeline, all modes) against the per-read oracle; then the case that cannot fit."""
+    reads = [r for r in G.bigq_fixture()]
+    by_alpha = {}
+    for seq, quals, alpha, ee, ns, ub in reads:
+        by_alpha.setdefault(alpha, []).append((seq, quals, ee, ns))
+    checked = 0
+    for alpha, group in by_alpha.items():
+        batch = []
+        for item in group + [None]:
+            trial = batch + [item] if item is not None else batch
+            ok = item is not None
+            if ok:
+                try:
+                    eng.pack_coded([t[0] for t in trial], [t[1] for t in trial])
+                except ValueError:
+                    ok = False                                   # no free code left: close the batch before this read
+            if ok:
+                batch = trial
+                continue
+            if batch:
+                q, lens, codes = eng.pack_coded([t[0] for t in batch], [t[1] for t in batch])
+                assert (codes[1:255] != np.arange(1, 255)).sum() >= 1
+                r = eng.filter(q, lens=lens, alpha=alpha, ambigs="ignore", uncert=1.0, code_scores=codes)
+                assert [(float(e), int(n)) for e, n in zip(r.ee, r.ns)] == [(t[2], t[3]) for t in batch]
+                checked += len(batch)
+            batch = [item] if item is not None else []
+            if item is not None:
+                try:
+                    eng.pack_coded([item[0]], [item[1]])
+                except ValueError:
+                    batch = []                                   # a single read with more big values than free codes
+    assert checked >= 80
+    # a large batch: 6,000 random reads of which a tenth carry big scores -> the sorted, tiled pipeline on the private table
+    rng = np.random.default_rng(77)
+    big = [255, 256, 300, 999, 3239, 3240, 3241, 70000, 2 ** 31 - 1]
+    seqs, quals = [], []
+    for k in range(6000):
+        n = int(rng.integers(1, 330))
+        ql = rng.integers(2, 42, n).tolist()
+        sq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+        amb = rng.random(n) < 0.01
+        sq[amb] = np.where(rng.random(int(amb.sum())) < 0.7, ord("N"), ord("n"))
+        if k % 10 == 0:
+            for pos in rng.integers(0, n, 1 + n // 50):
+                ql[int(pos)] = int(rng.choice(big))
+        if k % 97 == 0:
+            ql[0] = 0
+        seqs.append(sq.tobytes().decode())
+        quals.append(ql)
+    q, lens, codes = eng.pack_coded(seqs, quals)
+    assert sorted(int(v) for v in codes[codes != np.arange(256)]) == sorted(big)
+    for kw in ({}, {"ambigs": "disallow", "round_": True, "maxerrors": 2.0}, {"alpha": 0.05, "ambigs": "ignore"}):
+        r = eng.filter(q, lens=lens, code_scores=codes, batched_only=True, **kw)
+        alpha = kw.get("alpha", 0.005)
+        for i in range(0, 6000, 7):
+            e, ns, _ = oracle.ee_rowwise(seqs[i], quals[i], alpha)
+            if kw.get("ambigs", "treat_as_errors") == "treat_as_errors":
+                e = e + ns
+            if kw.get("round_"):
+                e = float(np.floor(e))
+            assert (float(r.ee[i]), int(r.ns[i])) == (e, ns), (i, kw)
+    # the context's own table is back afterwards
+    kat = G.load_kat()["kat1"]
+    assert eng.calculate_errors_PB(kat["seq"], kat["quals"], kat["alpha"]) == (kat["ee"], kat["ns"])
+    # more distinct big scores than free codes: refused at pack time, by name
+    with pytest.raises(ValueError, match="distinct scores above 254"):
+        eng.pack_coded(["A" * 600], [list(range(1, 255)) + list(range(300, 646))])
+    with pytest.raises(ValueError, match="positive"):
+        eng.pack_coded(["ACGT"], [[3, -1, 3, 3]])

@@ -174,3 +174,44 @@ def test_word_wide_fastq_decode_equals_the_byte_rules(tmp_path):
     subprocess.check_call(["g++", "-O2", "-I", str(tmp_path), os.path.join(ROOT, "tests", "helpers", "swar_decode_check.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-2000:]
+
+
+def test_pack_batch_coded_assigns_spare_codes(oracle):
+    """Host-only half of the coded batch entry (round 4): scores above 254 get byte codes the batch does not use, from
+    254 down, in order of first appearance; everything else packs as mpb_pack_read does."""
+    lib = L.load()
+    seqs = ["ACNTn", "GGG", "", "ACGTACGT"]
+    quals = [[30, 300, 30, 0, 7], [5000, 300, 254], [], [253, 2 ** 31 - 1, 1, 2, 3, 4, 5, 6]]
+    off = np.zeros(5, np.int64)
+    off[1:] = np.cumsum([len(x) for x in quals])
+    flat = np.array(sum(quals, []), np.int32)
+    q = np.full((4, 16), 9, np.uint8)
+    lens = np.empty(4, np.int32)
+    codes = np.empty(256, np.int32)
+    assert lib.mpb_pack_batch_coded("".join(seqs).encode(), flat.ctypes.data, off.ctypes.data, 4, 0, 16, q.ctypes.data,
+                                    lens.ctypes.data, codes.ctypes.data) == 0
+    assert lens.tolist() == [5, 3, 0, 8]
+    changed = {i: int(c) for i, c in enumerate(codes) if c != i}
+    assert changed == {252: 300, 251: 5000, 250: 2 ** 31 - 1}          # 254 and 253 are in use by the batch itself
+    assert q[0, :5].tolist() == [30, 252, 0, 1, 255] and not q[0, 5:].any()
+    assert q[1, :3].tolist() == [251, 252, 254] and q[3, :2].tolist() == [253, 250] and not q[2].any()
+    # without big scores it is the plain packer
+    plain = [[1, 2, 3], [40, 0, 41, 93]]
+    off2 = np.array([0, 3, 7], np.int64)
+    flat2 = np.array(sum(plain, []), np.int32)
+    q2 = np.empty((2, 16), np.uint8)
+    assert lib.mpb_pack_batch_coded(b"ACGNnAC", flat2.ctypes.data, off2.ctypes.data, 2, 0, 16, q2.ctypes.data,
+                                    lens.ctypes.data, codes.ctypes.data) == 0
+    assert codes.tolist() == list(range(256))
+    assert np.array_equal(q2[0], oracle.pack_read("ACG", plain[0], 16)) and np.array_equal(q2[1], oracle.pack_read("NnAC", plain[1], 16))
+    # max_len truncates (moira.py:806-807); a negative score and a batch without a free code are refused
+    assert lib.mpb_pack_batch_coded(None, flat.ctypes.data, off.ctypes.data, 4, 2, 16, q.ctypes.data, lens.ctypes.data, codes.ctypes.data) == 0
+    assert lens.tolist() == [2, 2, 0, 2]
+    neg = np.array([3, -1], np.int32)
+    assert lib.mpb_pack_batch_coded(None, neg.ctypes.data, np.array([0, 2], np.int64).ctypes.data, 1, 0, 16, q.ctypes.data,
+                                    lens.ctypes.data, codes.ctypes.data) == L.E_RANGE
+    full = np.array(list(range(1, 255)) + [300], np.int32)
+    qq = np.empty((1, 256), np.uint8)
+    assert lib.mpb_pack_batch_coded(None, full.ctypes.data, np.array([0, 255], np.int64).ctypes.data, 1, 0, 256, qq.ctypes.data,
+                                    lens.ctypes.data, codes.ctypes.data) == L.E_RANGE
+    assert b"distinct scores above 254" in lib.mpb_last_error()
