@@ -596,7 +596,11 @@ def main():
             extras["classified_at_source"] = classified_rate(eng, d_q, n, stride, L, params, d_ee, d_ns, d_pass)
             extras["long_reads_ragged_50_2000"] = long_ragged_rate(eng, params)
             extras["host_fed"] = host_fed_rate(eng, L, stride, args.seed)
-            extras["config3_paired"] = config3_paired_rate(eng)
+            try:
+                extras["config3_paired"] = config3_paired_rate(eng)
+            except Exception as e:                      # an extra must never cost the headline line
+                extras["config3_paired"] = {"error": repr(e)}
+            extras["per_read_broker"] = per_read_broker_rate()
             if n != CONFIG4_SHARD:
                 extras["config4_shard"] = config4_shard_rate(eng, L, stride, args.seed, params)
         extras["poisson_error_calc"] = poisson_rate(eng, d_q, n, stride, L, d_ee, d_ns)
@@ -981,6 +985,32 @@ def poisson_rate(eng, d_q, n, stride, L, d_lam, d_ns):
         ML.check(eng.lib.mpb_poisson_finish_host(lam.ctypes.data, ns.ctypes.data, None, L, m, C.byref(prm), ee.ctypes.data, ps.ctypes.data))
         dt = time.perf_counter() - t
         out["host_tail"] = {"reads_per_s": m / dt, "reads": m, "pass": int(ps.sum())}
+    except Exception as e:                                  # an extra must never cost the headline line
+        out["error"] = repr(e)
+    return out
+
+
+def per_read_broker_rate():
+    """What an UNCHANGED moira.py --processors P gets from the drop-in module (moira/moira.py:398-399,431-454: Pool workers
+    calling bernoulli.calculate_errors_PB per read): P = the granted CPUs worker processes through ONE GPU-owning broker
+    process (moira_amd/broker.py).  Runs tools/per_read_concurrency.py as a child process; never `value`."""
+    out = {"note": "P worker processes call bernoulli.calculate_errors_PB per read (300-base reads) through the broker: one "
+                   "GPU-owning process micro-batches what they have pending; the reference's own extension on the same cores "
+                   "is cpu_baseline.all_cores; NOT the headline"}
+    try:
+        from moira_amd.contig import usable_cpus
+        p = max(2, min(16, usable_cpus()))
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MOIRA_PB_BROKER")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "per_read_concurrency.py"), "--json", "1", str(p)],
+                           capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+        rows = json.loads([l for l in r.stdout.splitlines() if l.startswith("[")][-1])
+        out["one_worker"] = {"calls_per_s": rows[0]["calls_per_s"], "us_per_call": rows[0]["us_per_call_in_a_worker"]}
+        out["workers"] = rows[1]["workers"]
+        out["calls_per_s"] = rows[1]["calls_per_s"]
+        out["us_per_call_in_a_worker"] = rows[1]["us_per_call_in_a_worker"]
+        b = rows[1]["broker"] or {}
+        if b.get("batches"):
+            out["reads_per_launch_since_the_broker_started"] = b["served"] / (b["batches"] + b["solo"])
     except Exception as e:                                  # an extra must never cost the headline line
         out["error"] = repr(e)
     return out

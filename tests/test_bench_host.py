@@ -145,3 +145,24 @@ def test_rccl_failure_falls_back_to_gloo_in_the_same_process():
     assert line["outcome"]["pass"] + line["outcome"]["fail"] == 3000
     assert "RCCL not used" in line["config"]["collective_backend"]
     assert took < 120
+
+
+def test_config3_extras_host_stages_run_without_a_gpu():
+    """extras.config3_paired (round 4): the host stages (in-memory FASTQ text -> index -> contigs -> pack) and the
+    pipelining are exercised here with a stand-in for the filter call; the GPU part is the driver's bench run."""
+    import types
+    import bench
+
+    class NoGpu:
+        calls = 0
+
+        def filter(self, q, lens=None, fixed_len=None):
+            NoGpu.calls += 1
+            assert q.dtype.name == "uint8" and (lens is None or len(lens) == q.shape[0])
+            return types.SimpleNamespace(n_pass=0 if lens is None else int((lens >= 300).sum()))
+    r = bench.config3_paired_rate(NoGpu(), pairs_per_chunk=20_000, chunks=3)
+    assert r["pairs"] == 60_000 and r["chunks"] == 3 and r["contigs_kept"] == 60_000
+    assert 440 <= r["mean_contig_length"] <= 460                       # 2 x 300 bases, 150 of them shared
+    assert NoGpu.calls == 1 + 1 + 3 + 3                                # warm-up of the slots, untimed chunk, two passes
+    assert r["pipelined"]["pairs_per_s"] > 0 and r["projected_wall_s_for_100M_pairs"] > 0
+    assert set(r["stage_pairs_per_s"]) == {"index_both_files", "contig_construction", "pack", "gpu_filter_incl_pcie"}
