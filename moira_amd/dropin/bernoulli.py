@@ -41,7 +41,10 @@ def _choose():
         return _default_engine().calculate_errors_PB
     from moira_amd import broker as _broker
     device = int(os.environ.get("MOIRA_PB_DEVICE", "0"))
-    state = {"cl": _broker.client(device)}
+    try:
+        state = {"cl": _broker.client(device)}
+    except MemoryError:                                # more worker processes than the broker has slots (64): this one
+        return _default_engine().calculate_errors_PB   # takes a context of its own (slower under contention, still exact)
 
     def call(contig, contig_quals, alpha):
         try:
