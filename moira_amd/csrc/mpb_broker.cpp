@@ -42,7 +42,7 @@
 namespace {
 
 constexpr uint32_t BRK_MAGIC = 0x4d504252u;        // "MPBR"
-constexpr uint32_t BRK_VERSION = 1;
+constexpr uint32_t BRK_VERSION = 2;
 constexpr int BRK_LANES = 4;                        // micro-batches in flight
 constexpr int BRK_MAX_SLOTS = 256;
 
@@ -63,12 +63,18 @@ struct alignas(64) BrkHeader {
     std::atomic<int64_t> heartbeat_ms;
 };
 
+// One cache line per direction: the client spins on the first (state), the request and the result each have a line of their
+// own, so that the broker's result stores do not fight the spinning reader for the line, and one store of `state` hands over.
 struct alignas(64) BrkSlot {
     std::atomic<int32_t> owner;                     // pid of the attached client, 0 = free
     std::atomic<uint32_t> state;                    // ST_*, futex word of the client
     std::atomic<int32_t> waiting;                   // the client sleeps on `state`
-    int32_t len, priv, rc, ns;
-    double alpha, ee;
+    alignas(64) int32_t len;                        // request (written by the client before SUBMITTED)
+    int32_t priv;
+    double alpha;
+    alignas(64) int32_t rc;                         // result (written by the broker before DONE)
+    int32_t ns;
+    double ee;
     char err[160];
     // then: uint8_t row[MPB_MAX_STRIDE]; double2 lut[256] (only read when priv != 0)
 };
@@ -345,7 +351,8 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
     while (rc == MPB_OK && !h->stop.load(std::memory_order_relaxed)) {
         bool progress = false;
         bool any_busy = false;
-        // 1. retire the micro-batches that have finished
+        // 1. retire the micro-batches that have finished (every busy lane is asked: launches on streams of their own do not
+        //    finish in launch order, and asking only the oldest one -- tried -- costs a fifth of the call rate)
         for (Lane &l : b.lane) {
             if (!l.busy) continue;
             const hipError_t q = hipStreamQuery(l.stream);
