@@ -128,8 +128,8 @@ def test_many_workers_get_the_oracles_results(broker, stub_lib):
     total = sum(r[2] for r in res)
     st = _stats(lib, name)
     assert st["served"] == total and st["attached"] == 0
-    assert 0 < st["solo"] < total and st["batches"] >= 1
-    assert st["batches"] + st["solo"] <= total           # (equality = no two reads ever shared a launch: allowed, not expected)
+    assert 0 < st["solo"] < total                        # the reads the stub sent back as "row budget missed", re-run alone
+    assert 1 <= st["batches"] <= total                   # launches (a re-run read was in one too; < total: reads shared launches)
 
 
 def test_arguments_and_errors(broker, stub_lib):
