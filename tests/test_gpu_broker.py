@@ -100,3 +100,41 @@ def test_the_dropin_module_uses_the_broker_in_pool_workers(oracle, monkeypatch):
     import bernoulli
     assert bernoulli.calculate_errors_PB("ACGT", [0] * 4, 0.005) == (3.987440567842452, 0)
     assert broker.stats(name) is None
+
+
+def test_the_python2_form_of_the_dropin(oracle):
+    """moira_amd/dropin/py2/bernoulli.py (ctypes + stdlib only, Python 2 and 3 syntax): the reference's known answers
+    directly, and -- from the workers of a Pool -- through the broker it starts itself."""
+    import importlib.util
+    import subprocess
+    import golden_io as G
+    from moira_amd import broker
+    path = os.path.join(ROOT, "moira_amd", "dropin", "py2", "bernoulli.py")
+    spec = importlib.util.spec_from_file_location("bernoulli_py2form", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kat = G.load_kat()["kat1"]
+    assert mod.calculate_errors_PB(kat["seq"], kat["quals"], kat["alpha"]) == (kat["ee"], kat["ns"])
+    assert mod.calculate_errors_PB("ACGT", [0] * 4, 0.005) == (3.987440567842452, 0)
+    assert mod.calculate_errors_PB(b"ACNT", [30, 300, 7, 5000], 0.05) == oracle.ee_rowwise("ACNT", [30, 300, 7, 5000], 0.05)[:2]
+    name = "gpupy2_%d" % os.getpid()
+    code = (
+        "import sys, multiprocessing as mp\n"
+        "sys.path.insert(0, %r)\n"
+        "import bernoulli\n"
+        "def f(a): return bernoulli.calculate_errors_PB(*a)\n"
+        "if __name__ == '__main__':\n"
+        "    reads = [('ACGT' * 20, [2 + (i * 7) %% 39 for i in range(80)], 0.005)] * 50 + [('A' * 10, [40] * 10, 0.005)]\n"
+        "    pool = mp.Pool(3)\n"
+        "    print(repr(pool.map(f, reads, 3)))\n"
+        "    pool.close(); pool.join()\n" % os.path.dirname(path))
+    env = dict(os.environ, MOIRA_PB_BROKER_NAME=name)
+    env.pop("MOIRA_PB_BROKER", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-1500:]
+    got = eval(r.stdout.strip().splitlines()[-1])
+    want = [oracle.ee_rowwise("ACGT" * 20, [2 + (i * 7) % 39 for i in range(80)], 0.005)[:2]] * 50 + [(0.0, 0)]
+    assert got == want
+    st = broker.stats(name)
+    assert st is not None and st["served"] >= 51
+    broker.shutdown(name)

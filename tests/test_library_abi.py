@@ -215,3 +215,42 @@ def test_pack_batch_coded_assigns_spare_codes(oracle):
     assert lib.mpb_pack_batch_coded(None, full.ctypes.data, np.array([0, 255], np.int64).ctypes.data, 1, 0, 256, qq.ctypes.data,
                                     lens.ctypes.data, codes.ctypes.data) == L.E_RANGE
     assert b"distinct scores above 254" in lib.mpb_last_error()
+
+
+def test_python2_form_of_the_dropin_parses_as_python2_and_checks_its_arguments():
+    """moira.py is Python 2; this image has none.  moira_amd/dropin/py2/bernoulli.py is written for both versions: it must
+    parse under lib2to3's Python-2 grammar (the one with the print statement) and under Python 3, use nothing but ctypes
+    and the standard library, and raise the extension's exceptions (moira/bernoullimodule.c:74-90) before it needs a GPU."""
+    import ast
+    import importlib.util
+    import lib2to3.pgen2.driver as D
+    import lib2to3.pygram as G
+    import lib2to3.pytree as T
+    path = os.path.join(ROOT, "moira_amd", "dropin", "py2", "bernoulli.py")
+    src = open(path).read()
+    ast.parse(src)
+    D.Driver(G.python_grammar, convert=T.convert).parse_string(src + "\n")
+    imported = {n.names[0].name.split(".")[0] for n in ast.walk(ast.parse(src)) if isinstance(n, ast.Import)}
+    assert imported <= {"ctypes", "os", "subprocess", "sys", "time", "fcntl", "multiprocessing"}
+    tree = ast.parse(src)
+    py3_only = (ast.JoinedStr, ast.AnnAssign, ast.Nonlocal, ast.NamedExpr, ast.AsyncFunctionDef, ast.Await, ast.YieldFrom,
+                ast.MatMult)
+    assert not [n for n in ast.walk(tree) if isinstance(n, py3_only)]                       # f-strings, annotations, ...
+    for fn in (n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Lambda))):
+        a = fn.args
+        assert not a.kwonlyargs and not a.posonlyargs and not any(x.annotation for x in a.args)
+        assert isinstance(fn, ast.Lambda) or fn.returns is None
+    spec = importlib.util.spec_from_file_location("bernoulli_py2form", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with pytest.raises(TypeError):
+        mod.calculate_errors_PB(5, [1], 0.005)
+    with pytest.raises(TypeError):
+        mod.calculate_errors_PB("A", (1,), 0.005)
+    with pytest.raises(TypeError):
+        mod.calculate_errors_PB("AC", [30, 1.5], 0.005)
+    with pytest.raises(ValueError, match="Alpha must be between 0 and 1"):
+        mod.calculate_errors_PB("A", [30], 1.0)
+    with pytest.raises(ValueError, match="same length"):
+        mod.calculate_errors_PB("AC", [30], 0.005)
+    assert mod.calculate_errors is mod.calculate_errors_PB
