@@ -117,6 +117,10 @@ def shutdown(name, wait_s=10.0):
         if stats(name) is None:
             break
         time.sleep(0.02)
+    try:                                                   # the start lock of this name (a few bytes in /dev/shm)
+        os.unlink(os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "moira_pb_%s.lock" % name))
+    except OSError:
+        pass
 
 
 def start(device=0, name=None, slots=64, idle_exit=10.0, log=None):
