@@ -192,6 +192,12 @@ CASES = [
     ("pe_scores_2_-3_-1", "derived", {"paired": True, "match": 2, "mismatch": -3, "gap": -1}),
     ("pe_insert30_deltaq3", "derived", {"paired": True, "insert": 30, "deltaq": 3}),
     ("pe_poisson", "derived", {"paired": True, "error_calc": "poisson"}),
+    # ---- the fasta + qual reader (moira/moira.py:1093-1149) on the derived reads, incl. scores of 120 and 300 ----
+    ("fa_se_default", "derived_fasta_qual", {}),
+    ("fa_se_nocollapse_usearch_maxerrors", "derived_fasta_qual", {"collapse": False, "pipeline": "USEARCH", "maxerrors": 1.0}),
+    ("fa_se_truncate200_ignore", "derived_fasta_qual", {"truncate": 200, "ambigs": "ignore"}),
+    ("fa_pe_default", "derived_fasta_qual", {"paired": True}),
+    ("fa_pe_sum_cap0_min_overlap", "derived_fasta_qual", {"paired": True, "consensus_qscore": "sum", "qscore_cap": 0, "min_overlap": 100}),
 ]
 
 
@@ -238,12 +244,20 @@ def open_outputs(args):
 
 
 def drive(M, args, fwd_path, rev_path):
-    """The body of moira.py's main() around the reference's own functions (moira/moira.py:400-504)."""
+    """The body of moira.py's main() around the reference's own functions (moira/moira.py:400-504).  fwd_path / rev_path: a
+    FASTQ file each, or a (fasta, qual) pair each (then the reference's parse_fasta_and_qual reads them)."""
     if args.only_contig:                          # check_arguments, moira/moira.py:698-699
         args.paired = True
     o, files = open_outputs(args)
-    fh = open(fwd_path)
-    rh = open(rev_path) if args.paired else None
+    fasta_qual = isinstance(fwd_path, tuple)
+    if fasta_qual:
+        handles = [open(fwd_path[0]), open(fwd_path[1])] + ([open(rev_path[0]), open(rev_path[1])] if args.paired else [None, None])
+        records = M.parse_fasta_and_qual(*handles)
+        fh, rh = None, None
+    else:
+        fh = open(fwd_path)
+        rh = open(rev_path) if args.paired else None
+        records = M.parse_fastq(fh, rh, args.fastq_offset)
     uniques, order = {}, Py27KeyOrder()
     totals = [0.0, 0.0, 0.0]
     processed = 0
@@ -253,7 +267,7 @@ def drive(M, args, fwd_path, rev_path):
                             o.contig, o.qual, o.names, o.bad_contig, o.bad_qual, o.bad_names, o.report)
         for k in range(3):
             totals[k] += r[k]
-    for header, fs, fq_, rs, rq in M.parse_fastq(fh, rh, args.fastq_offset):
+    for header, fs, fq_, rs, rq in records:
         header, contig, cq, ee, ov, gaps, mism = M.process_data(header, fs, fq_, rs, rq, args)
         assert ee == ee, "NaN from the reference for " + header
         if args.collapse:                         # moira/moira.py:459-475
@@ -279,9 +293,9 @@ def drive(M, args, fwd_path, rev_path):
             v = uniques[seq]
             write(index, v["rep_header"], seq, v["rep_quals"], v["rep_errors"], v["names_info"],
                   v["overlap_length"], v["gaps"], v["mismatches"])
-    fh.close()
-    if rh:
-        rh.close()
+    for f in ([fh, rh] if not fasta_qual else handles):
+        if f:
+            f.close()
     return {k: f.getvalue().encode("latin-1") for k, f in files.items()}, processed, totals
 
 
@@ -298,6 +312,10 @@ def main():
         derived = (os.path.join(tmp, "derived1.fastq"), os.path.join(tmp, "derived2.fastq"))
         G.write_fastq(derived[0], d1)
         G.write_fastq(derived[1], d2)
+        fq_paths = ((os.path.join(tmp, "derived1.fasta"), os.path.join(tmp, "derived1.qual")),
+                    (os.path.join(tmp, "derived2.fasta"), os.path.join(tmp, "derived2.qual")))
+        G.write_fasta_qual(fq_paths[0][0], fq_paths[0][1], d1)
+        G.write_fasta_qual(fq_paths[1][0], fq_paths[1][1], d2)
         sha = lambda b: hashlib.sha256(b).hexdigest()
         manifest = {"source": "moira/moira.py parse_fastq -> process_data -> write_results (lib2to3 copy, bernoulli = "
                               "moira/bernoullimodule.c unmodified, nw = moira/nw_align.pyx), driven by "
@@ -306,13 +324,15 @@ def main():
                     "inputs": {"shipped": ["test1.fastq", "test2.fastq"],
                                "derived": {"by": "tests/golden_io.py:derive_flag_inputs",
                                            "sha256": [sha(open(p, "rb").read()) for p in derived],
-                                           "records": len(d1)}},
+                                           "records": len(d1)},
+                               "derived_fasta_qual": {"by": "tests/golden_io.py:write_fasta_qual on the derived records",
+                                                      "sha256": [sha(open(p, "rb").read()) for pair in fq_paths for p in pair]}},
                     "cases": {}}
         results = {}
         for name, which, flags in CASES:
             args = reference_args(**flags)
             ub0 = M.bernoulli.ub_reads
-            f, r = shipped if which == "shipped" else derived
+            f, r = shipped if which == "shipped" else derived if which == "derived" else fq_paths
             files, processed, totals = drive(M, args, f, r)
             results[name] = files
             manifest["cases"][name] = {"input": which, "flags": flags, "processed": processed, "reads_scored_by_the_python_twin": M.bernoulli.ub_reads - ub0,

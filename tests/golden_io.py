@@ -152,6 +152,21 @@ def write_fastq(path, records):
             f.write("%s\n%s\n%s\n%s\n" % r)
 
 
+def write_fasta_qual(fa_path, qu_path, records, offset=33):
+    """The same reads as fasta + qual (the reference's second reader, moira/moira.py:1093-1149): header text after a blank /
+    tab (which the reader must drop), and -- what no FASTQ file can hold -- a few scores above 93 and above 254."""
+    with open(fa_path, "w") as fa, open(qu_path, "w") as qu:
+        for i, (h, s, _, q) in enumerate(records):
+            name = h[1:].replace("\t", " ").split(" ")[0]
+            quals = [ord(c) - offset for c in q]
+            if i % 37 == 5 and quals:
+                quals[(i * 7) % len(quals)] = 300
+            if i % 41 == 7 and quals:
+                quals[(i * 11) % len(quals)] = 120
+            fa.write(">%s some description %d\n%s\n" % (name, i, s))
+            qu.write(">%s\tother text\n%s\n" % (name, " ".join(map(str, quals))))
+
+
 def flag_manifest():
     return json.load(open(os.path.join(FLAG_DIR, "manifest.json")))
 

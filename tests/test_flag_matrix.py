@@ -1,7 +1,7 @@
 """The CLI's non-default branches, pinned to the REFERENCE's output files.
 
-tests/golden/flag_matrix/ holds what moira.py's own parse_fastq -> process_data -> write_results write for 50 flag
-combinations (tests/golden/make_flag_matrix.py; every label of moira/moira.py:872-946, USEARCH headers :858-863,
+tests/golden/flag_matrix/ holds what moira.py's own parse_fastq / parse_fasta_and_qual -> process_data -> write_results
+write for 55 flag combinations (tests/golden/make_flag_matrix.py; every label of moira/moira.py:872-946, USEARCH headers :858-863,
 --relabel :854-855, --round / --ambigs ignore :827-831, --only_contig :900-908, --min_overlap incl. the reference's
 args.truncate slip in FASTQ mode :886-897, --trim_overlap, sum / posterior consensus scores, the Poisson method).
 Every case must come out byte for byte through BOTH paths of the CLI: the byte-level path (moira_amd/fastio.py) and the
@@ -50,7 +50,13 @@ def inputs(tmp_path_factory):
     G.write_fastq(paths[1], d2)
     got = [hashlib.sha256(open(p, "rb").read()).hexdigest() for p in paths]
     assert got == MAN["inputs"]["derived"]["sha256"], "derived inputs differ from what the reference was run on"
-    return {"shipped": (os.path.join(GOLD, "test1.fastq.gz"), os.path.join(GOLD, "test2.fastq.bz2")), "derived": paths}
+    fq = ((str(d / "derived1.fasta"), str(d / "derived1.qual")), (str(d / "derived2.fasta"), str(d / "derived2.qual")))
+    G.write_fasta_qual(fq[0][0], fq[0][1], d1)
+    G.write_fasta_qual(fq[1][0], fq[1][1], d2)
+    got = [hashlib.sha256(open(p, "rb").read()).hexdigest() for pair in fq for p in pair]
+    assert got == MAN["inputs"]["derived_fasta_qual"]["sha256"], "derived fasta + qual inputs differ from the reference's"
+    return {"shipped": (os.path.join(GOLD, "test1.fastq.gz"), os.path.join(GOLD, "test2.fastq.bz2")), "derived": paths,
+            "derived_fasta_qual": fq}
 
 
 @pytest.fixture(scope="module")
@@ -87,6 +93,7 @@ def oracle_backend(oracle):
         return oracle.filter_batch(q, lens=lens, alpha=alpha, ambigs=ambigs, round_=round_, threads=4)[0]
     backend.matrix = matrix
     backend.methods = ("poisson_binomial", "poisson")
+    backend.per_read = lambda seq, quals, alpha: oracle.ee_rowwise(seq, [int(v) for v in quals], alpha)[:2]   # scores above 254
     return backend
 
 
@@ -96,7 +103,11 @@ def run_case(case, inputs, expected, tmp_path, backend, line_parser):
     flags = dict(spec["flags"])
     paired = flags.get("paired", False) or flags.get("only_contig", False)
     out = str(tmp_path / "o")
-    a = _args(flags, forward_fastq=fwd, reverse_fastq=rev if paired else None, output_prefix=out)
+    if isinstance(fwd, tuple):                   # the fasta + qual reader
+        a = _args(flags, forward_fasta=fwd[0], forward_qual=fwd[1], reverse_fasta=rev[0] if paired else None,
+                  reverse_qual=rev[1] if paired else None, output_prefix=out)
+    else:
+        a = _args(flags, forward_fastq=fwd, reverse_fastq=rev if paired else None, output_prefix=out)
     assert cli.main(a, backend=backend, out=open(os.devnull, "w"), _no_fastio=line_parser) == 0
     want = expected[case]
     made = sorted(p[len("o."):] for p in os.listdir(tmp_path) if p.startswith("o."))
@@ -138,7 +149,8 @@ def test_the_matrix_covers_every_branch_of_write_results(expected):
                    b"\toverlap length below 300\n", b"\tcontains ambiguities\n", b"\terrors > 1.00\n", b"\terrors > 2.50\n",
                    b"\tuncert > 0.010\n", b"\tuncert > 0.020\n", b";size=2;", b">x1\n", b"@s1;ee=", b">Otu_1;ee="):
         assert needle in blob, needle
-    assert len(CASES) >= 50
+    assert len(CASES) >= 55
+    assert b" 300 " in blob and b" 120 " in blob                 # scores no FASTQ file can hold, through the fasta + qual reader
     kinds = {stem for fs in expected.values() for stem in fs}
     assert {"contigs.fasta", "contigs.names", "bad.contigs.fasta", "bad.contigs.names", "bad.contigs.fastq",
             "contigs.report", "qc.good.fastq", "qc.bad.fastq", "qc.good.names"} <= kinds
