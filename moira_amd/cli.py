@@ -13,7 +13,8 @@ quality matrices and filtered on the GPU by libmoira_pb.so, and the per-read res
 same collapse / write logic.
 
 `--error_calc poisson_binomial` and `poisson_binomial_py` both run the HIP path (they are the same
-arithmetic; the reference's two names select its C or Python implementation).  `poisson` sums the
+arithmetic; the reference's two names select its C or Python implementation -- which differ in one thing that is
+kept: the C extension counts a lower-case 'n' as ambiguous, the Python twin scores it as a base).  `poisson` sums the
 per-read lambda on the GPU and finishes the scalar CDF on the host with the reference's libm calls
 (moira/moira.py:1637-1679).  `bootstrap` (deprecated, random) is evaluated on the host as moira.py
 does (moira/moira.py:1682-1720).  `--processors` sets the CPU threads used for contig construction.
@@ -595,7 +596,7 @@ def process_chunk(records, args, backend):
         bset = set(big)
         bq = [[min(int(v), 254) for v in ql] if i in bset else ql for i, ql in enumerate(quals)] if big else quals
 
-        def per_read(fn):
+        def per_read(fn, seqs=seqs):
             # a .qual file may hold any integer and the reference takes it (moira/bernoullimodule.c:92-108,
             # moira/moira.py:1637-1679): such a read goes through the per-read entry (its own code table for that
             # call); the batch saw a capped stand-in
@@ -613,14 +614,17 @@ def process_chunk(records, args, backend):
             for i, sq in enumerate(seqs):
                 if len(sq) > MAX_PB_LEN:
                     raise ReadTooLongError(records[i][0], len(sq))
+            scored = seqs
+            if args.error_calc == "poisson_binomial_py":        # the Python twin counts only 'N' (moira/moira.py:1605): for it
+                scored = [s.replace("n", "A") if "n" in s else s for s in seqs]      # a lower-case n is a base like any other
             if getattr(args, "fast_discard", False) and not args.collapse and args.pipeline == "mothur" \
                     and "poisson" in getattr(backend, "methods", ()):
-                ee = backend(seqs, bq, args.alpha, args.ambigs, args.round,
+                ee = backend(scored, bq, args.alpha, args.ambigs, args.round,
                              fast_discard=(args.uncert, args.maxerrors))
             else:
-                ee = backend(seqs, bq, args.alpha, args.ambigs, args.round)            # includes +Ns / floor
+                ee = backend(scored, bq, args.alpha, args.ambigs, args.round)          # includes +Ns / floor
             ee = [float(x) for x in ee]
-            per_read(getattr(backend, "per_read", None))
+            per_read(getattr(backend, "per_read", None), scored)
         elif args.error_calc == "poisson" and "poisson" in getattr(backend, "methods", ()):
             ee = [float(x) for x in backend(seqs, bq, args.alpha, args.ambigs, args.round, method="poisson")]
             per_read(getattr(backend, "per_read_poisson", None))
@@ -1090,6 +1094,10 @@ def _run_fast_fastq(args, backend, o, say, t0):
     only = bool(args.only_contig)                                # moira.py:809-810, :898-908: contigs, no quality control
     in_off = args.fastq_offset if args.forward_fastq else 0      # fasta+qual records carry the integers themselves
     method = "poisson" if args.error_calc == "poisson" else "poisson_binomial"
+    # a lower-case 'n' is an ambiguous base for the C extension only (moira/bernoullimodule.c:196); the reference's Python
+    # functions -- the Poisson approximation and the twin that --error_calc poisson_binomial_py selects -- score it as a base
+    # (moira/moira.py:1605, :1660 test for 'N' alone)
+    n_is_base = args.error_calc in ("poisson", "poisson_binomial_py")
     fd = None
     if getattr(args, "fast_discard", False) and not args.collapse and args.pipeline == "mothur" \
             and method == "poisson_binomial":
@@ -1149,7 +1157,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
             has_n = np.zeros(n, bool)
             for stride in (np.unique(strides) if not only else ()):
                 sel = np.nonzero(strides == stride)[0]
-                q, ln, fl = F.pack_parallel(pool, threads, buf, idx, sel, in_off, T, method == "poisson", int(stride))
+                q, ln, fl = F.pack_parallel(pool, threads, buf, idx, sel, in_off, T, n_is_base, int(stride))
                 ee[sel] = backend.matrix(q, ln, args.alpha, args.ambigs, args.round, method=method, fast_discard=fd)
                 has_n[sel] = fl
             nan = np.isnan(ee)

@@ -192,6 +192,11 @@ CASES = [
     ("pe_scores_2_-3_-1", "derived", {"paired": True, "match": 2, "mismatch": -3, "gap": -1}),
     ("pe_insert30_deltaq3", "derived", {"paired": True, "insert": 30, "deltaq": 3}),
     ("pe_poisson", "derived", {"paired": True, "error_calc": "poisson"}),
+    # ---- --error_calc poisson_binomial_py: the reference's Python twin (moira/moira.py:820-821), for which a lower-case
+    #      'n' is a scored base (moira/moira.py:1605 counts only 'N'), unlike the C extension (bernoullimodule.c:196)
+    ("se_pbpy_default", "derived", {"error_calc": "poisson_binomial_py"}),
+    ("se_pbpy_nocollapse_ignore_fastq", "derived", {"error_calc": "poisson_binomial_py", "collapse": False, "ambigs": "ignore",
+                                                     "output_format": "fastq"}),
     # ---- the fasta + qual reader (moira/moira.py:1093-1149) on the derived reads, incl. scores of 120 and 300 ----
     ("fa_se_default", "derived_fasta_qual", {}),
     ("fa_se_nocollapse_usearch_maxerrors", "derived_fasta_qual", {"collapse": False, "pipeline": "USEARCH", "maxerrors": 1.0}),
