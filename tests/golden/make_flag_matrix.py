@@ -197,6 +197,12 @@ CASES = [
     ("se_pbpy_default", "derived", {"error_calc": "poisson_binomial_py"}),
     ("se_pbpy_nocollapse_ignore_fastq", "derived", {"error_calc": "poisson_binomial_py", "collapse": False, "ambigs": "ignore",
                                                      "output_format": "fastq"}),
+    # ---- other encodings of the same reads: --fastq_offset 64, and a file full of things strip() forgives ----
+    ("se_offset64_fastq_out", "derived_offset64", {"fastq_offset": 64, "output_format": "fastq"}),
+    ("pe_offset64", "derived_offset64", {"fastq_offset": 64, "paired": True}),
+    ("se_quirks_default", "derived_quirks", {}),
+    ("pe_quirks_nocollapse", "derived_quirks", {"paired": True, "collapse": False}),
+    ("pe_best_cap30", "derived", {"paired": True, "qscore_cap": 30}),
     # ---- the fasta + qual reader (moira/moira.py:1093-1149) on the derived reads, incl. scores of 120 and 300 ----
     ("fa_se_default", "derived_fasta_qual", {}),
     ("fa_se_nocollapse_usearch_maxerrors", "derived_fasta_qual", {"collapse": False, "pipeline": "USEARCH", "maxerrors": 1.0}),
@@ -260,8 +266,8 @@ def drive(M, args, fwd_path, rev_path):
         records = M.parse_fasta_and_qual(*handles)
         fh, rh = None, None
     else:
-        fh = open(fwd_path)
-        rh = open(rev_path) if args.paired else None
+        fh = open(fwd_path, newline="")           # no newline translation: the reference iterates the raw lines and strip()s them
+        rh = open(rev_path, newline="") if args.paired else None
         records = M.parse_fastq(fh, rh, args.fastq_offset)
     uniques, order = {}, Py27KeyOrder()
     totals = [0.0, 0.0, 0.0]
@@ -321,6 +327,11 @@ def main():
                     (os.path.join(tmp, "derived2.fasta"), os.path.join(tmp, "derived2.qual")))
         G.write_fasta_qual(fq_paths[0][0], fq_paths[0][1], d1)
         G.write_fasta_qual(fq_paths[1][0], fq_paths[1][1], d2)
+        off64 = (os.path.join(tmp, "off64_1.fastq"), os.path.join(tmp, "off64_2.fastq"))
+        quirks = (os.path.join(tmp, "quirks1.fastq"), os.path.join(tmp, "quirks2.fastq"))
+        for k, recs in enumerate((d1, d2)):
+            G.write_fastq_offset64(off64[k], recs)
+            G.write_fastq_quirks(quirks[k], recs)
         sha = lambda b: hashlib.sha256(b).hexdigest()
         manifest = {"source": "moira/moira.py parse_fastq -> process_data -> write_results (lib2to3 copy, bernoulli = "
                               "moira/bernoullimodule.c unmodified, nw = moira/nw_align.pyx), driven by "
@@ -330,6 +341,10 @@ def main():
                                "derived": {"by": "tests/golden_io.py:derive_flag_inputs",
                                            "sha256": [sha(open(p, "rb").read()) for p in derived],
                                            "records": len(d1)},
+                               "derived_offset64": {"by": "tests/golden_io.py:write_fastq_offset64",
+                                                    "sha256": [sha(open(p, "rb").read()) for p in off64]},
+                               "derived_quirks": {"by": "tests/golden_io.py:write_fastq_quirks",
+                                                  "sha256": [sha(open(p, "rb").read()) for p in quirks]},
                                "derived_fasta_qual": {"by": "tests/golden_io.py:write_fasta_qual on the derived records",
                                                       "sha256": [sha(open(p, "rb").read()) for pair in fq_paths for p in pair]}},
                     "cases": {}}
@@ -337,7 +352,8 @@ def main():
         for name, which, flags in CASES:
             args = reference_args(**flags)
             ub0 = M.bernoulli.ub_reads
-            f, r = shipped if which == "shipped" else derived if which == "derived" else fq_paths
+            f, r = {"shipped": shipped, "derived": derived, "derived_fasta_qual": fq_paths, "derived_offset64": off64,
+                    "derived_quirks": quirks}[which]
             files, processed, totals = drive(M, args, f, r)
             results[name] = files
             manifest["cases"][name] = {"input": which, "flags": flags, "processed": processed, "reads_scored_by_the_python_twin": M.bernoulli.ub_reads - ub0,

@@ -152,6 +152,34 @@ def write_fastq(path, records):
             f.write("%s\n%s\n%s\n%s\n" % r)
 
 
+def write_fastq_offset64(path, records):
+    """The same reads in the Illumina 1.3-1.7 encoding (quality characters + 31: --fastq_offset 64)."""
+    with open(path, "w") as f:
+        for h, s, p, q in records:
+            f.write("%s\n%s\n%s\n%s\n" % (h, s, p, "".join(chr(ord(c) + 31) for c in q)))
+
+
+def write_fastq_quirks(path, records):
+    """The same reads as a file a tolerant parser still has to read as the reference does (moira/moira.py:1166-1175: every
+    line is strip()ped, the header is cut at the first blank / tab, ALL leading '@' go, ':' becomes '_'): CRLF line ends,
+    doubled '@', trailing blanks and tabs, the header repeated on the '+' line, a last line without a newline."""
+    out = []
+    for i, (h, s, p, q) in enumerate(records):
+        if i % 5 == 1:
+            h = "@" + h
+        if i % 6 == 2:
+            h = h + " \t"
+        if i % 7 == 3:
+            s = s + " "
+        if i % 8 == 4:
+            p = "+" + h.lstrip("@").split(" ")[0]
+        if i % 9 == 5:
+            q = q + "\t"
+        out.append("\r\n".join((h, s, p, q)) if i % 2 else "\n".join((h, s, p, q)))
+    with open(path, "w", newline="") as f:
+        f.write("".join(r + ("\r\n" if k % 3 == 0 else "\n") for k, r in enumerate(out[:-1])) + out[-1])
+
+
 def write_fasta_qual(fa_path, qu_path, records, offset=33):
     """The same reads as fasta + qual (the reference's second reader, moira/moira.py:1093-1149): header text after a blank /
     tab (which the reader must drop), and -- what no FASTQ file can hold -- a few scores above 93 and above 254."""

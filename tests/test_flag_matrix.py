@@ -1,7 +1,7 @@
 """The CLI's non-default branches, pinned to the REFERENCE's output files.
 
 tests/golden/flag_matrix/ holds what moira.py's own parse_fastq / parse_fasta_and_qual -> process_data -> write_results
-write for 57 flag combinations (tests/golden/make_flag_matrix.py; every label of moira/moira.py:872-946, USEARCH headers :858-863,
+write for 62 flag combinations (tests/golden/make_flag_matrix.py; every label of moira/moira.py:872-946, USEARCH headers :858-863,
 --relabel :854-855, --round / --ambigs ignore :827-831, --only_contig :900-908, --min_overlap incl. the reference's
 args.truncate slip in FASTQ mode :886-897, --trim_overlap, sum / posterior consensus scores, the Poisson method).
 Every case must come out byte for byte through BOTH paths of the CLI: the byte-level path (moira_amd/fastio.py) and the
@@ -55,8 +55,15 @@ def inputs(tmp_path_factory):
     G.write_fasta_qual(fq[1][0], fq[1][1], d2)
     got = [hashlib.sha256(open(p, "rb").read()).hexdigest() for pair in fq for p in pair]
     assert got == MAN["inputs"]["derived_fasta_qual"]["sha256"], "derived fasta + qual inputs differ from the reference's"
+    off64 = (str(d / "off64_1.fastq"), str(d / "off64_2.fastq"))
+    quirks = (str(d / "quirks1.fastq"), str(d / "quirks2.fastq"))
+    for k, recs in enumerate((d1, d2)):
+        G.write_fastq_offset64(off64[k], recs)
+        G.write_fastq_quirks(quirks[k], recs)
+    for kind, pair in (("derived_offset64", off64), ("derived_quirks", quirks)):
+        assert [hashlib.sha256(open(p, "rb").read()).hexdigest() for p in pair] == MAN["inputs"][kind]["sha256"], kind
     return {"shipped": (os.path.join(GOLD, "test1.fastq.gz"), os.path.join(GOLD, "test2.fastq.bz2")), "derived": paths,
-            "derived_fasta_qual": fq}
+            "derived_fasta_qual": fq, "derived_offset64": off64, "derived_quirks": quirks}
 
 
 @pytest.fixture(scope="module")
@@ -149,7 +156,7 @@ def test_the_matrix_covers_every_branch_of_write_results(expected):
                    b"\toverlap length below 300\n", b"\tcontains ambiguities\n", b"\terrors > 1.00\n", b"\terrors > 2.50\n",
                    b"\tuncert > 0.010\n", b"\tuncert > 0.020\n", b";size=2;", b">x1\n", b"@s1;ee=", b">Otu_1;ee="):
         assert needle in blob, needle
-    assert len(CASES) >= 57
+    assert len(CASES) >= 62
     assert b" 300 " in blob and b" 120 " in blob                 # scores no FASTQ file can hold, through the fasta + qual reader
     kinds = {stem for fs in expected.values() for stem in fs}
     assert {"contigs.fasta", "contigs.names", "bad.contigs.fasta", "bad.contigs.names", "bad.contigs.fastq",
