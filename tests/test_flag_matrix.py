@@ -115,7 +115,23 @@ def run_case(case, inputs, expected, tmp_path, backend, line_parser):
                   reverse_qual=rev[1] if paired else None, output_prefix=out)
     else:
         a = _args(flags, forward_fastq=fwd, reverse_fastq=rev if paired else None, output_prefix=out)
-    assert cli.main(a, backend=backend, out=open(os.devnull, "w"), _no_fastio=line_parser) == 0
+    import io
+    a.silent = False                             # the closing summary (moira/moira.py:508-519) is part of what is compared
+    said = io.StringIO()
+    assert cli.main(a, backend=backend, out=said, _no_fastio=line_parser) == 0
+    n = spec["processed"]
+    d_err, d_len, d_ov = spec["discarded_errors_minlength_minoverlap"]
+    kept = n - d_err - d_len - d_ov
+    lines = ["- Kept %d (%.2f%%) of the original sequences." % (kept, kept / n * 100)]
+    if flags.get("truncate"):
+        lines.append("- %d (%.2f%%) of the original sequences were discarded due to length < %s." % (d_len, d_len / n * 100, flags["truncate"]))
+    if paired and flags.get("min_overlap"):
+        lines.append("- %d (%.2f%%) of the original sequences were discarded due to paired-end reads having an overlap "
+                     "length < %s." % (d_ov, d_ov / n * 100, flags["min_overlap"]))
+    lines.append("- %d (%.2f%%) of the original sequences were discarded due to low quality." % (d_err, d_err / n * 100))
+    text = said.getvalue()
+    for line in lines:                           # the reference's counts (manifest) in the reference's words
+        assert line in text, (line, text[-600:])
     want = expected[case]
     made = sorted(p[len("o."):] for p in os.listdir(tmp_path) if p.startswith("o."))
     assert made == sorted(spec["files"]), "output file set"
