@@ -13,6 +13,7 @@ one as a FRESH CHILD PROCESS (a new interpreter, nothing inherited) before this 
 file lock, so that the P workers of a pool start exactly one.  The broker leaves by itself `idle_exit` seconds after
 its last attached process has gone.
 """
+import array
 import ctypes as C
 import fcntl
 import os
@@ -33,7 +34,9 @@ def default_name(device=0):
 
 def marshal_read(contig, contig_quals, alpha):
     """Argument rules of bernoulli.calculate_errors_PB (moira/bernoullimodule.c:66-108: "sO!d", alpha in (0, 1), equal
-    lengths, PyInt_AsLong per element) -> (bytes, int32 array, float).  Shared by the direct and the broker entry."""
+    lengths, PyInt_AsLong per element) -> (bytes, int32 buffer, its address, float).  Shared by the direct and the broker
+    entry.  The list goes through array.array('i', ...): one C loop, half the time of numpy's list conversion, and a
+    TypeError for anything that is not an integer -- as PyInt_AsLong would raise."""
     if not isinstance(contig, str):
         raise TypeError("argument 1 must be str, not %s" % type(contig).__name__)
     if not isinstance(contig_quals, list):
@@ -43,18 +46,18 @@ def marshal_read(contig, contig_quals, alpha):
         raise ValueError("Alpha must be between 0 and 1")
     if len(contig_quals) != len(contig):
         raise ValueError("contig and contig_quals must have the same length")
-    qi = None
-    if len(contig_quals):
-        a = np.asarray(contig_quals)                       # one C loop for the common case: a list of Python ints
-        if a.ndim == 1 and a.dtype.kind in "ib":
-            qi = a.astype(np.int32)                        # wraps as (int)PyInt_AsLong does (bernoullimodule.c:97)
-    if qi is None:                                         # anything else: element by element, as PyInt_AsLong would
-        qi = np.empty(len(contig_quals), np.int32)
+    try:
+        qi = array.array("i", contig_quals)
+        return contig.encode(), qi, qi.buffer_info()[0], alpha
+    except TypeError:
+        raise TypeError("an integer is required")
+    except OverflowError:                                  # a Python int beyond 32 bits: wraps as (int)PyInt_AsLong does
+        qi = np.empty(len(contig_quals), np.int32)         # (bernoullimodule.c:97)
         for i, v in enumerate(contig_quals):
             if not isinstance(v, int):
                 raise TypeError("an integer is required")
-            qi[i] = v
-    return contig.encode(), qi, alpha
+            qi[i] = ((v + 0x80000000) & 0xFFFFFFFF) - 0x80000000
+        return contig.encode(), qi, qi.ctypes.data, alpha
 
 
 class BrokerGone(L.MoiraPBError):
@@ -74,8 +77,8 @@ class BrokerClient:
 
     def calculate_errors_PB(self, contig, contig_quals, alpha):
         """bernoulli.calculate_errors_PB(contig, contig_quals, alpha) -> (expected_errors, Ns), through the broker."""
-        seq, qi, alpha = marshal_read(contig, contig_quals, alpha)
-        rc = self.lib.mpb_broker_call(self.h, seq, qi.ctypes.data, len(qi), alpha, C.byref(self._ee), C.byref(self._ns))
+        seq, qi, addr, alpha = marshal_read(contig, contig_quals, alpha)
+        rc = self.lib.mpb_broker_call(self.h, seq, addr, len(qi), alpha, C.byref(self._ee), C.byref(self._ns))
         if rc == L.E_HIP:
             raise BrokerGone(self.lib.mpb_last_error().decode(errors="replace"))
         L.check(rc)

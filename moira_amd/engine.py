@@ -304,9 +304,9 @@ class Engine:
         """Exact twin of bernoulli.calculate_errors_PB -> (expected_errors, Ns).
         ref: moira/bernoullimodule.c:66-114 (argument and error behaviour)."""
         from .broker import marshal_read               # the argument rules, shared with the broker entry
-        seq, qi, alpha = marshal_read(contig, contig_quals, alpha)
+        seq, qi, addr, alpha = marshal_read(contig, contig_quals, alpha)
         ee, ns = C.c_double(), C.c_int32()
-        L.check(self.lib.mpb_calculate_errors_PB(self.ctx, seq, qi.ctypes.data, len(qi), alpha,
+        L.check(self.lib.mpb_calculate_errors_PB(self.ctx, seq, addr, len(qi), alpha,
                                                  C.byref(ee), C.byref(ns)))
         return ee.value, ns.value
 
