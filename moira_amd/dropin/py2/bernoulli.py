@@ -16,6 +16,7 @@ MOIRA_PB_DEVICE picks the GPU, MOIRA_PB_LIB the library (default: ../../libmoira
 This image has no Python 2: the file is exercised under Python 3 (tests/test_gpu_broker.py) and parsed with lib2to3's
 Python-2 grammar (tests/test_library_abi.py); it has never run under a real Python 2.7.
 """
+import array as _array
 import ctypes as _C
 import os as _os
 import subprocess as _subprocess
@@ -133,16 +134,22 @@ def calculate_errors_PB(contig, contig_quals, alpha):
     n = len(contig_quals)
     if n != len(contig):
         raise ValueError("contig and contig_quals must have the same length")
-    for v in contig_quals:
-        if not isinstance(v, _INTS):
-            raise TypeError("an integer is required")
+    try:
+        q = _array.array("i", contig_quals)                                    # one C loop; TypeError for a non-integer
+    except TypeError:
+        raise TypeError("an integer is required")
+    except OverflowError:                                                      # beyond 32 bits: wraps as (int)PyInt_AsLong does
+        for v in contig_quals:
+            if not isinstance(v, _INTS):
+                raise TypeError("an integer is required")
+        q = _array.array("i", [((v + 0x80000000) & 0xFFFFFFFF) - 0x80000000 for v in contig_quals])
     seq = contig if isinstance(contig, bytes) else contig.encode("ascii")
-    q = (_C.c_int32 * max(n, 1))(*[((v + 0x80000000) & 0xFFFFFFFF) - 0x80000000 for v in contig_quals])   # wraps as (int)PyInt_AsLong does
+    addr = q.buffer_info()[0]
     pid = _os.getpid()
     if _state["pid"] != pid:                                                   # first call in this process (a forked worker decides for itself)
         _state["call"], _state["pid"] = _choose(), pid
     ee, ns = _C.c_double(), _C.c_int32()
-    rc = _state["call"](seq, q, n, alpha, _C.byref(ee), _C.byref(ns))
+    rc = _state["call"](seq, addr, n, alpha, _C.byref(ee), _C.byref(ns))
     if rc:
         _raise(rc)
     return ee.value, ns.value
