@@ -831,7 +831,7 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
         // a handful of reads (the per-read entry: ONE): the kernel reads the rows from, and writes the results to, the pinned
         // host block -- one runtime call instead of three dependent ones (copy in, kernel, copy out)
         { Span t(c, MPB_K_DP); mpb_launch_small((const uint8_t *)h, n, row_stride, len ? (const int32_t *)(h + b_q) : nullptr, prm, c->ws,
-                                                 (int32_t *)(ho + b_ee), (double *)ho, (uint8_t *)(ho + b_ee + b_ns), c->stream); }
+                                                 (int32_t *)(ho + b_ee), (double *)ho, (uint8_t *)(ho + b_ee + b_ns), c->stream, d_q); }
         HIPCHK(hipGetLastError());
     } else {
         HIPCHK(hipMemcpyAsync(d, h, (size_t)(len ? in_bytes : n * row_stride), hipMemcpyHostToDevice, c->stream));
@@ -1283,7 +1283,7 @@ int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *conti
 // back with pass == 2 and the broker re-runs it alone.  cls / ident are the launch's own scratch (m bytes / m int32),
 // so that several micro-batches can be in flight on different streams.
 int mpbi_small_async(mpb_ctx *c, const uint8_t *d_q, int64_t m, int64_t stride, const int32_t *d_len, double alpha,
-                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *d_cls, int32_t *d_ident, hipStream_t s)
+                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *d_cls, int32_t *d_ident, hipStream_t s, uint8_t *d_stage)
 {
     mpb_filter_params prm;
     prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
@@ -1295,7 +1295,7 @@ int mpbi_small_async(mpb_ctx *c, const uint8_t *d_q, int64_t m, int64_t stride, 
     ws.lut = c->d_lut;
     ws.cls = d_cls;
     ws.perm = d_ident;
-    mpb_launch_small(d_q, m, stride, d_len, dp, ws, d_ns, d_ee, d_pass, s);
+    mpb_launch_small(d_q, m, stride, d_len, dp, ws, d_ns, d_ee, d_pass, s, d_stage);
     HIPCHK(hipGetLastError());
     return MPB_OK;
 }

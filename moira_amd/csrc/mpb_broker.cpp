@@ -261,7 +261,7 @@ struct Broker {
             // which is what bounds the call rate at P = 16.
             int rc = mpbi_small_async(ctx, (const uint8_t *)l.pin_in + off_q, m, stride, (const int32_t *)l.pin_in, alpha,
                                       (double *)(l.pin_out + off_ee), (int32_t *)(l.pin_out + off_ns), (uint8_t *)(l.pin_out + off_pass),
-                                      (uint8_t *)d + off_cls, (int32_t *)(d + off_ident), l.stream);
+                                      (uint8_t *)d + off_cls, (int32_t *)(d + off_ident), l.stream, (uint8_t *)d + off_q);
             if (rc) return rc;
         } else {
             const size_t in_bytes = off_q + (size_t)m * stride;
@@ -269,7 +269,7 @@ struct Broker {
             char *d_out = d + l.in_cap;
             int rc = mpbi_small_async(ctx, (const uint8_t *)d + off_q, m, stride, (const int32_t *)d, alpha, (double *)(d_out + off_ee),
                                       (int32_t *)(d_out + off_ns), (uint8_t *)(d_out + off_pass), (uint8_t *)d + off_cls,
-                                      (int32_t *)(d + off_ident), l.stream);
+                                      (int32_t *)(d + off_ident), l.stream, nullptr);
             if (rc) return rc;
             BHIP(hipMemcpyAsync(l.pin_out, d_out, off_pass + (size_t)n_slots, hipMemcpyDeviceToHost, l.stream));
         }

@@ -18,7 +18,8 @@ int mpbi_pack_one_read(const char *contig, const int32_t *quals, int32_t len, bo
 int mpbi_run_packed_read(mpb_ctx *c, const uint8_t *row, int32_t len, int32_t stride, const double2 *h, double alpha,
                          double *ee, int32_t *ns);
 int mpbi_small_async(mpb_ctx *c, const uint8_t *d_q, int64_t m, int64_t stride, const int32_t *d_len, double alpha,
-                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *d_cls, int32_t *d_ident, hipStream_t s);
+                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *d_cls, int32_t *d_ident, hipStream_t s,
+                     uint8_t *d_stage /* nullptr, or m x stride bytes of device memory when d_q is pinned host memory */);
 
 }
 

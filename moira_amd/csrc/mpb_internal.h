@@ -123,8 +123,9 @@ void mpb_launch_decode_classify(const uint8_t *seq, const uint8_t *qual, int32_t
                                 int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                                 const MpbWorkspace &ws, int32_t *ns_out, double *ee_out, uint8_t *pass_out, hipStream_t s);
 void mpb_launch_encode(const uint8_t *q, int64_t n, int64_t stride, int32_t offset, uint8_t *seq, uint8_t *qual, hipStream_t s);
+// stage: nullptr, or n x stride bytes of DEVICE memory when q is pinned host memory (the rows are parked there by the kernel)
 void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
-                      const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s);
+                      const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s, uint8_t *stage = nullptr);
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s);
 void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const MpbDevParams &prm, const MpbWorkspace &ws,
                         hipStream_t s);

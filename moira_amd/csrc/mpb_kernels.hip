@@ -1220,8 +1220,13 @@ template <bool FMA>
 __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args, const double2 *__restrict__ lut_g,
                                                                     int64_t n, int32_t *__restrict__ ns_out,
                                                                     uint8_t *__restrict__ cls_out,
-                                                                    int32_t *__restrict__ ident)
+                                                                    int32_t *__restrict__ ident,
+                                                                    uint8_t *__restrict__ stage)
 {
+    // stage != nullptr: args.q is pinned HOST memory (the per-read entry and the broker's micro-batches: one runtime call
+    // per launch, no copy in).  The statistics pass below reads every chunk of the row anyway -- one trip over the link, all
+    // lanes at once -- and leaves it in `stage` (device memory, same shape), which is what the class body then walks: its
+    // five dependent 64-byte trips per 300 bases would otherwise each pay the link's latency.
     __shared__ float2 s_tab[256];
     __shared__ DpArgs s_args;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -1232,7 +1237,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
         p = amb ? 0.0f : p;
         s_tab[tid] = make_float2(p, tid == 0 ? MPB_MARK_UPPER : tid == 255 ? MPB_MARK_LOWER : p * (1.0f - p));
     }
-    if (tid == 0) s_args = args;
+    if (tid == 0) { s_args = args; if (stage) s_args.q = stage; }
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 4 + w;
     if (i >= n) return;                                   // wave-uniform; no barrier below
@@ -1245,6 +1250,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
         const int nv = li - (c0 + lane) * 16;
         if (nv > 0) {
             uint4 y = *reinterpret_cast<const uint4 *>(args.q + i * args.stride + (int64_t)(c0 + lane) * 16);
+            if (stage) *reinterpret_cast<uint4 *>(stage + i * args.stride + (int64_t)(c0 + lane) * 16) = y;
             y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
             y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
             pre_chunk(s_tab, y, a01, s3);
@@ -1709,12 +1715,12 @@ void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, 
 
 // Small batches: one launch, one read per wave (k_small).  Overflow is reported through pass == 2.
 void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
-                      const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s)
+                      const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s, uint8_t *stage)
 {
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 2);
     const int blocks = (int)((n + 3) / 4);
     if (prm.flags & 2u)
-        hipLaunchKernelGGL((k_small<true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm);
+        hipLaunchKernelGGL((k_small<true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage);
     else
-        hipLaunchKernelGGL((k_small<false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm);
+        hipLaunchKernelGGL((k_small<false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage);
 }

@@ -63,7 +63,7 @@ int mpbi_run_packed_read(mpb_ctx *, const uint8_t *row, int32_t len, int32_t str
 }
 
 int mpbi_small_async(mpb_ctx *, const uint8_t *d_q, int64_t m, int64_t stride, const int32_t *d_len, double alpha,
-                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *, int32_t *, hipStream_t)
+                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *, int32_t *, hipStream_t, uint8_t *)
 {
     int rc = oracle_rows(d_q, m, stride, d_len, alpha, d_ee, d_ns, d_pass);
     for (int64_t i = 0; i < m && !rc; i++)
