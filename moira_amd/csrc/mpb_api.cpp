@@ -9,6 +9,8 @@
 #include "mpb_internal.h"
 #include "mpb_host_internal.h"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -91,6 +93,7 @@ struct mpb_ctx {
     // pinned host scratch of the small-batch path (inputs and outputs of one call, back to back)
     void *pin_host = nullptr;
     int64_t pin_cap = 0;
+    uint32_t small_token = 0;            // completion token of the last zero-copy k_small launch (never 0)
 };
 
 // Threads that copy a pageable input chunk into its pinned staging block: half of the CPUs this process is
@@ -782,6 +785,10 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
 #define MPB_SMALL_N 4096
 #endif
 // small batches whose inputs are at most this many bytes are read by the kernel straight from pinned host memory
+// ... and batches of at most this many reads report their completion through a word per read in pinned memory
+#ifndef MPB_SMALL_FLAG_N
+#define MPB_SMALL_FLAG_N 256
+#endif
 #ifndef MPB_SMALL_ZC_BYTES
 #define MPB_SMALL_ZC_BYTES (1 << 20)
 #endif
@@ -792,6 +799,26 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
 #define MPB_HOST_CHUNK_BYTES (128ll << 20)
 #endif
 
+// Wait until done[0..n) all hold `token` (k_small writes it once a read's results are visible to the host).  The kernel
+// normally takes tens of microseconds: spin; a launch that has not finished after 20 ms is asked about through the runtime
+// (which also reports a fault), and its flags are then looked at once more.
+int mpbi_wait_flags(const volatile uint32_t *done, int64_t n, uint32_t token, hipStream_t s)
+{
+    int64_t k = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        while (k < n && done[k] == token) k++;
+        if (k == n) { std::atomic_thread_fence(std::memory_order_acquire); return MPB_OK; }
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            HIPCHK(hipStreamSynchronize(s));
+            while (k < n && done[k] == token) k++;
+            if (k == n) return MPB_OK;
+            return fail(MPB_E_HIP, "k_small finished without reporting read %lld", (long long)k);
+        }
+    }
+}
+
 static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride, const int32_t *len,
                              int32_t fixed_len, const mpb_filter_params *params, double *ee, int32_t *ns,
                              uint8_t *pass, mpb_filter_counts *counts, bool *done)
@@ -800,15 +827,15 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
     const int32_t max_len = len ? (int32_t)(row_stride < MPB_MAX_LEN ? row_stride : MPB_MAX_LEN) : fixed_len;
     const int64_t b_q = align_up(n * row_stride, 256), b_len = align_up(n * 4, 256);
     const int64_t b_ee = align_up(n * 8, 256), b_ns = align_up(n * 4, 256), b_pass = align_up(n, 256);
-    const int64_t in_bytes = b_q + b_len, out_bytes = b_ee + b_ns + b_pass;
+    const int64_t in_bytes = b_q + b_len, out_bytes = b_ee + b_ns + b_pass, b_done = align_up(n * 4, 256);
     int rc = ensure_stage(c, in_bytes + out_bytes);
     if (rc) return rc;
     rc = ensure_workspace(c, n);
     if (rc) return rc;
     c->classified.valid = false;                           // k_small rewrites the class bytes
-    if (in_bytes + out_bytes > c->pin_cap) {
-        if (c->pin_host) { HIPCHK(hipHostFree(c->pin_host)); c->pin_host = nullptr; c->pin_cap = 0; }
-        const int64_t cap = 2 * (in_bytes + out_bytes);
+    if (in_bytes + out_bytes + b_done > c->pin_cap) {
+        if (c->pin_host) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->pin_host)); c->pin_host = nullptr; c->pin_cap = 0; }
+        const int64_t cap = 2 * (in_bytes + out_bytes + b_done);
         HIPCHK(hipHostMalloc(&c->pin_host, (size_t)cap, hipHostMallocMapped));
         c->pin_cap = cap;
     }
@@ -829,10 +856,23 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
 #endif
     if (in_bytes <= zc_bytes) {
         // a handful of reads (the per-read entry: ONE): the kernel reads the rows from, and writes the results to, the pinned
-        // host block -- one runtime call instead of three dependent ones (copy in, kernel, copy out)
+        // host block -- one runtime call instead of three dependent ones (copy in, kernel, copy out) -- and the host learns
+        // that the results are there from a word per read in the same block, not from the runtime
+        // (a word and a system-scope fence per read pay for a few reads -- 1: 33 -> 27 us, 64: 35 -> 32 -- and cost more than
+        // the runtime's one completion signal for many: 1,024 reads 64 -> 82 us; hence the limit)
+        const bool flags = n <= MPB_SMALL_FLAG_N;
+        if (++c->small_token == 0) c->small_token = 1;
+        volatile uint32_t *done = (volatile uint32_t *)(ho + out_bytes);
+        for (int64_t i = 0; flags && i < n; i++) done[i] = 0;
+        const MpbSmallHost hostside{d_q, d_ns, flags ? (uint32_t *)(ho + out_bytes) : nullptr, c->small_token};
         { Span t(c, MPB_K_DP); mpb_launch_small((const uint8_t *)h, n, row_stride, len ? (const int32_t *)(h + b_q) : nullptr, prm, c->ws,
-                                                 (int32_t *)(ho + b_ee), (double *)ho, (uint8_t *)(ho + b_ee + b_ns), c->stream, d_q); }
+                                                 (int32_t *)(ho + b_ee), (double *)ho, (uint8_t *)(ho + b_ee + b_ns), c->stream, &hostside); }
         HIPCHK(hipGetLastError());
+        if (flags) {
+            if ((rc = mpbi_wait_flags(done, n, c->small_token, c->stream)) != MPB_OK) return rc;
+            if (c->timing) HIPCHK(hipStreamSynchronize(c->stream));      // the spans' events are read after the call
+            goto have_results;
+        }
     } else {
         HIPCHK(hipMemcpyAsync(d, h, (size_t)(len ? in_bytes : n * row_stride), hipMemcpyHostToDevice, c->stream));
         { Span t(c, MPB_K_DP); mpb_launch_small(d_q, n, row_stride, len ? d_len : nullptr, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
@@ -840,6 +880,7 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
         HIPCHK(hipMemcpyAsync(ho, d + in_bytes, (size_t)out_bytes, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
+have_results:
     const uint8_t *hp = (const uint8_t *)(ho + b_ee + b_ns);
     int64_t np = 0;
     for (int64_t i = 0; i < n; i++) {
@@ -1283,7 +1324,8 @@ int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *conti
 // back with pass == 2 and the broker re-runs it alone.  cls / ident are the launch's own scratch (m bytes / m int32),
 // so that several micro-batches can be in flight on different streams.
 int mpbi_small_async(mpb_ctx *c, const uint8_t *d_q, int64_t m, int64_t stride, const int32_t *d_len, double alpha,
-                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *d_cls, int32_t *d_ident, hipStream_t s, uint8_t *d_stage)
+                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *d_cls, int32_t *d_ident, hipStream_t s,
+                     const MpbSmallHost *host)
 {
     mpb_filter_params prm;
     prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
@@ -1295,7 +1337,7 @@ int mpbi_small_async(mpb_ctx *c, const uint8_t *d_q, int64_t m, int64_t stride, 
     ws.lut = c->d_lut;
     ws.cls = d_cls;
     ws.perm = d_ident;
-    mpb_launch_small(d_q, m, stride, d_len, dp, ws, d_ns, d_ee, d_pass, s, d_stage);
+    mpb_launch_small(d_q, m, stride, d_len, dp, ws, d_ns, d_ee, d_pass, s, host);
     HIPCHK(hipGetLastError());
     return MPB_OK;
 }

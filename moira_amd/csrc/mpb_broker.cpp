@@ -174,6 +174,9 @@ struct Lane {
     int m = 0;
     int64_t stride = 0;
     int slots[BRK_MAX_SLOTS];
+    uint32_t token = 0;         // completion token of the launch in flight (zero-copy lanes: k_small reports through pin_out)
+    int reported = 0;           // reads of it whose flag has been seen
+    int64_t launched_us = 0;
 };
 
 struct Broker {
@@ -181,7 +184,7 @@ struct Broker {
     Mapping map;
     int n_slots;
     Lane lane[BRK_LANES];
-    size_t off_q, off_ee, off_ns, off_pass, off_cls, off_ident;       // offsets inside a lane's blocks (n_slots reads)
+    size_t off_q, off_ee, off_ns, off_pass, off_done, off_cls, off_ident, off_nsdev;   // offsets inside a lane's blocks (n_slots reads)
     bool zero_copy = true;                                             // MPB_BROKER_COPIES=1: stage through HBM with two async copies
 
     int init_lanes()
@@ -192,10 +195,12 @@ struct Broker {
         off_ee = 0;                                                   // output block: ee | ns | pass
         off_ns = ns * 8;
         off_pass = off_ns + ns * 4;
-        const size_t out_cap = (off_pass + ns + 255) & ~(size_t)255;
-        off_cls = in_cap + out_cap;                                   // device block: input | output | cls | ident
+        off_done = (off_pass + ns + 63) & ~(size_t)63;                // ... | completion word per read (zero-copy lanes)
+        const size_t out_cap = (off_done + ns * 4 + 255) & ~(size_t)255;
+        off_cls = in_cap + out_cap;                                   // device block: input | output | cls | ident | ns
         off_ident = (off_cls + ns + 255) & ~(size_t)255;
-        const size_t dev_cap = off_ident + ns * 4;
+        off_nsdev = off_ident + ns * 4;
+        const size_t dev_cap = off_nsdev + ns * 4;
         for (Lane &l : lane) {
             BHIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
             BHIP(hipHostMalloc((void **)&l.pin_in, in_cap, hipHostMallocMapped));
@@ -259,10 +264,16 @@ struct Broker {
             // host blocks (mapped into the device's address space); only its scratch (class bytes, identity list) is in HBM.
             // A few hundred bytes per read over the link cost less than two more asynchronous copies cost the broker thread,
             // which is what bounds the call rate at P = 16.
+            if (++l.token == 0) l.token = 1;
+            volatile uint32_t *done = (volatile uint32_t *)(l.pin_out + off_done);
+            for (int k = 0; k < m; k++) done[k] = 0;
+            l.reported = 0;
+            const MpbSmallHost hostside{(uint8_t *)d + off_q, (int32_t *)(d + off_nsdev), (uint32_t *)(l.pin_out + off_done), l.token};
             int rc = mpbi_small_async(ctx, (const uint8_t *)l.pin_in + off_q, m, stride, (const int32_t *)l.pin_in, alpha,
                                       (double *)(l.pin_out + off_ee), (int32_t *)(l.pin_out + off_ns), (uint8_t *)(l.pin_out + off_pass),
-                                      (uint8_t *)d + off_cls, (int32_t *)(d + off_ident), l.stream, (uint8_t *)d + off_q);
+                                      (uint8_t *)d + off_cls, (int32_t *)(d + off_ident), l.stream, &hostside);
             if (rc) return rc;
+            l.launched_us = now_us();
         } else {
             const size_t in_bytes = off_q + (size_t)m * stride;
             BHIP(hipMemcpyAsync(d, l.pin_in, in_bytes, hipMemcpyHostToDevice, l.stream));
@@ -276,6 +287,25 @@ struct Broker {
         l.busy = true;
         map.hdr()->batches.fetch_add(1, std::memory_order_relaxed);
         return MPB_OK;
+    }
+
+    // hipSuccess: the lane's launch has delivered; hipErrorNotReady: not yet; anything else: the runtime's error.
+    // Zero-copy lanes are told by the kernel itself (a word per read in pinned memory: no runtime call per iteration, and no
+    // wait for the completion signal, which trails the last wave by microseconds); a launch that has been out for 20 ms is
+    // asked about through the runtime, which is also where a fault would show.
+    hipError_t finished(Lane &l)
+    {
+        if (!zero_copy) return hipStreamQuery(l.stream);
+        const volatile uint32_t *done = (const volatile uint32_t *)(l.pin_out + off_done);
+        while (l.reported < l.m && done[l.reported] == l.token) l.reported++;
+        if (l.reported == l.m) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
+        if (now_us() - l.launched_us > 20000) {
+            const hipError_t q = hipStreamQuery(l.stream);
+            if (q != hipSuccess) return q;
+            while (l.reported < l.m && done[l.reported] == l.token) l.reported++;
+            return l.reported == l.m ? hipSuccess : hipErrorUnknown;
+        }
+        return hipErrorNotReady;
     }
 
     void retire(Lane &l)
@@ -355,7 +385,7 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
         //    finish in launch order, and asking only the oldest one -- tried -- costs a fifth of the call rate)
         for (Lane &l : b.lane) {
             if (!l.busy) continue;
-            const hipError_t q = hipStreamQuery(l.stream);
+            const hipError_t q = b.finished(l);
             if (q == hipSuccess) { b.retire(l); progress = true; }
             else if (q != hipErrorNotReady) {
                 mpbi_fail(MPB_E_HIP, hipGetErrorString(q));

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 struct mpb_ctx;
+struct MpbSmallHost;
 
 extern "C" {      // (defined inside mpb_api.cpp's extern "C" block; hidden: the version script exports `mpb_*` only)
 
@@ -19,7 +20,9 @@ int mpbi_run_packed_read(mpb_ctx *c, const uint8_t *row, int32_t len, int32_t st
                          double *ee, int32_t *ns);
 int mpbi_small_async(mpb_ctx *c, const uint8_t *d_q, int64_t m, int64_t stride, const int32_t *d_len, double alpha,
                      double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *d_cls, int32_t *d_ident, hipStream_t s,
-                     uint8_t *d_stage /* nullptr, or m x stride bytes of device memory when d_q is pinned host memory */);
+                     const MpbSmallHost *host /* nullptr, or the device scratch + completion flags that go with inputs and
+                                                 outputs in pinned host memory (mpb_internal.h) */);
+int mpbi_wait_flags(const volatile uint32_t *done, int64_t n, uint32_t token, hipStream_t s);
 
 }
 

@@ -123,9 +123,17 @@ void mpb_launch_decode_classify(const uint8_t *seq, const uint8_t *qual, int32_t
                                 int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                                 const MpbWorkspace &ws, int32_t *ns_out, double *ee_out, uint8_t *pass_out, hipStream_t s);
 void mpb_launch_encode(const uint8_t *q, int64_t n, int64_t stride, int32_t offset, uint8_t *seq, uint8_t *qual, hipStream_t s);
-// stage: nullptr, or n x stride bytes of DEVICE memory when q is pinned host memory (the rows are parked there by the kernel)
+// k_small on inputs / outputs that live in pinned HOST memory (one runtime call per launch: no copies): the device scratch and
+// the completion flags that go with it
+struct MpbSmallHost {
+    uint8_t *stage;        // n x stride bytes of device memory: the rows are parked here by the kernel's statistics pass
+    int32_t *ns_dev;       // n ints of device memory: the ambiguity counts for the class body (the report goes to `ns`)
+    uint32_t *done;        // n words of pinned host memory, or nullptr: done[i] = token once read i's results are visible
+    uint32_t token;
+};
 void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
-                      const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s, uint8_t *stage = nullptr);
+                      const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s,
+                      const MpbSmallHost *host = nullptr);
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s);
 void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const MpbDevParams &prm, const MpbWorkspace &ws,
                         hipStream_t s);

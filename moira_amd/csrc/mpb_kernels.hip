@@ -1221,8 +1221,14 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
                                                                     int64_t n, int32_t *__restrict__ ns_out,
                                                                     uint8_t *__restrict__ cls_out,
                                                                     int32_t *__restrict__ ident,
-                                                                    uint8_t *__restrict__ stage)
+                                                                    uint8_t *__restrict__ stage,
+                                                                    uint32_t *__restrict__ done, uint32_t token)
 {
+    // done != nullptr (pinned host memory): when a read's results are out -- and visible system-wide -- its wave writes
+    // `token` to done[i], so that the host learns of the END OF ITS READS from memory instead of from the runtime's
+    // completion signal (which comes several microseconds after the last wave, and costs a runtime call to ask for).
+    // ns_out is where the ambiguity counts are REPORTED; args.ns (device memory, may be the same array) is where the class
+    // body reads them back: a report that lives in host memory is not read back over the link.
     // stage != nullptr: args.q is pinned HOST memory (the per-read entry and the broker's micro-batches: one runtime call
     // per launch, no copy in).  The statistics pass below reads every chunk of the row anyway -- one trip over the link, all
     // lanes at once -- and leaves it in `stage` (device memory, same shape), which is what the class body then walks: its
@@ -1241,6 +1247,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 4 + w;
     if (i >= n) return;                                   // wave-uniform; no barrier below
+    do {                                                  // (one exit for every read: the completion flag below)
     const MpbDevParams &prm = args.prm;
     const int li = args.len ? clamp_len(args.len[i], prm.max_len) : prm.fixed_len;
     // lane k takes the 16-byte chunks k, k + 64, ... of the row (at most 16 of them: 256 bytes, so the markers peel exactly)
@@ -1277,7 +1284,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
     rows = max(min(rows, li - nzero - n_lower + 1), 1);
     if (rows > MPB_TILE_MAX_ROWS) {                                       // a wide read: the host sends the batch down the pipeline
         if (lane == 0) args.pass[i] = 2;
-        return;
+        break;
     }
     const int c = c_class_of_rows.t[rows];
     // One read per wave: a G = 1 body would keep ONE lane busy.  The latency bodies below spread the read's rows over as
@@ -1293,11 +1300,12 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
     }
     if (lane == 0) {
         ns_out[i] = nzero + n_lower;
+        if (args.ns != ns_out) const_cast<int32_t *>(args.ns)[i] = nzero + n_lower;
         cls_out[i] = (uint8_t)((settled ? MPB_CLS_SETTLED : c) | (nzero > 0 ? 0x80 : 0));
         ident[i] = (int32_t)i;
         if (settled) { args.ee[i] = __builtin_inf(); args.pass[i] = 0; }
     }
-    if (settled) return;
+    if (settled) break;
     __threadfence();                                      // the class body reads ns / cls / ident back
     const int32_t *pc = ident + i;
     switch (thin) {
@@ -1305,6 +1313,12 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
         MPB_THIN_CLASSES(MPB_CASE)
 #undef MPB_CASE
     default: break;
+    }
+    } while (0);
+    if (done) {
+        __threadfence_system();                           // every lane's stores of this wave: out, and visible to the host
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(done + i, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1715,12 +1729,17 @@ void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, 
 
 // Small batches: one launch, one read per wave (k_small).  Overflow is reported through pass == 2.
 void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
-                      const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s, uint8_t *stage)
+                      const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s, const MpbSmallHost *host)
 {
-    DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 2);
+    // host == nullptr: everything in device memory.  Else q / ns / ee / pass are pinned host memory and `host` names the
+    // device scratch the kernel parks the rows and the counts in, and the completion flags (see k_small).
+    DpArgs A = make_args(q, stride, len, prm, ws, host && host->ns_dev ? host->ns_dev : ns, ee, pass, 2);
     const int blocks = (int)((n + 3) / 4);
+    uint8_t *stage = host ? host->stage : nullptr;
+    uint32_t *done = host ? host->done : nullptr;
+    const uint32_t token = host ? host->token : 0u;
     if (prm.flags & 2u)
-        hipLaunchKernelGGL((k_small<true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage);
+        hipLaunchKernelGGL((k_small<true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage, done, token);
     else
-        hipLaunchKernelGGL((k_small<false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage);
+        hipLaunchKernelGGL((k_small<false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage, done, token);
 }

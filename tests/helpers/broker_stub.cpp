@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "../../include/moira_pb.h"
+#include "../../moira_amd/csrc/mpb_internal.h"
 
 extern "C" {
 typedef struct pbo_params { double alpha, uncert, maxerrors; int32_t ambig_mode; uint32_t flags; } pbo_params;
@@ -63,13 +64,16 @@ int mpbi_run_packed_read(mpb_ctx *, const uint8_t *row, int32_t len, int32_t str
 }
 
 int mpbi_small_async(mpb_ctx *, const uint8_t *d_q, int64_t m, int64_t stride, const int32_t *d_len, double alpha,
-                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *, int32_t *, hipStream_t, uint8_t *)
+                     double *d_ee, int32_t *d_ns, uint8_t *d_pass, uint8_t *, int32_t *, hipStream_t, const MpbSmallHost *host)
 {
     int rc = oracle_rows(d_q, m, stride, d_len, alpha, d_ee, d_ns, d_pass);
     for (int64_t i = 0; i < m && !rc; i++)
         if (d_len[i] % 7 == 0) { d_pass[i] = 2; d_ee[i] = -12345.0; }    // "row budget missed": the broker must re-run it alone
+    if (host && host->done)                                              // what k_small does last: one word per read
+        for (int64_t i = m - 1; i >= 0; i--) __atomic_store_n(host->done + i, host->token, __ATOMIC_RELEASE);
     return rc;
 }
+int mpbi_wait_flags(const volatile uint32_t *, int64_t, uint32_t, hipStream_t) { return MPB_OK; }
 
 // ---- the HIP entry points mpb_broker.cpp calls, on host memory ----
 hipError_t hipSetDevice(int) { return hipSuccess; }
