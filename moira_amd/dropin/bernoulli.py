@@ -14,7 +14,8 @@ Under an unchanged `moira.py --processors P` the callers are the P worker proces
 (moira/moira.py:398-399,431-454).  Those do not open P GPU contexts (which would time-share the card): a process that
 was started by multiprocessing attaches to ONE GPU-owning broker process (moira_amd/broker.py; started on demand as a
 fresh child before this process has touched the GPU), which micro-batches whatever the workers have pending into one
-launch.  MOIRA_PB_BROKER=1 / 0 forces / forbids the broker; MOIRA_PB_DEVICE picks the GPU (default 0).
+launch.  MOIRA_PB_BROKER=1 / 0 forces / forbids the broker; MOIRA_PB_DEVICE picks the GPU (default 0; a list such as
+0,1,2,3 spreads the worker processes over one broker per GPU).
 """
 import os
 import sys
@@ -40,7 +41,8 @@ def _choose():
     if not use_broker:
         return _default_engine().calculate_errors_PB
     from moira_amd import broker as _broker
-    device = int(os.environ.get("MOIRA_PB_DEVICE", "0"))
+    devices = [int(d) for d in os.environ.get("MOIRA_PB_DEVICE", "0").split(",") if d.strip() != ""] or [0]
+    device = devices[os.getpid() % len(devices)]       # "0,1,...,7": the workers spread over one broker per GPU
     try:
         state = {"cl": _broker.client(device)}
     except MemoryError:                                # more worker processes than the broker has slots (64): this one
