@@ -203,3 +203,27 @@ print("checked", (n + 1) // 2, "bad", bad)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().endswith("bad 0") and "checked 2404" in out.stdout, out.stdout
+
+
+def test_nw_align_dropin_module_is_the_references(kat):
+    """moira_amd/dropin/nw_align.py: what an unchanged moira.py gets from `import nw_align as nw` (moira/moira.py:241-245,
+    :794) -- the reference's own known answer and a sample of the 4,808 alignments its Cython code produced."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "moira_amd", "dropin", "nw_align.py")
+    spec = importlib.util.spec_from_file_location("nw_align_dropin", path)
+    nw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(nw)
+    c, a = kat["contig"], kat["contig"]["args"]
+    rc = CT.reverse_complement(c["seq2"])
+    got = nw.nw_align(kat["kat1"]["seq"], rc, a["match"], a["mismatch"], a["gap"])
+    assert list(got) == c["aligned"] and got[2] == 13431
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nw_pairs.npz"))
+    params = z["params"]
+    for k in range(0, len(z["score"]), 37):
+        s1 = z["seq1"][z["off1"][k]:z["off1"][k + 1]].tobytes().decode()
+        s2 = z["seq2"][z["off2"][k]:z["off2"][k + 1]].tobytes().decode()
+        a1 = z["aln1"][z["aoff1"][k]:z["aoff1"][k + 1]].tobytes().decode()
+        a2 = z["aln2"][z["aoff2"][k]:z["aoff2"][k + 1]].tobytes().decode()
+        m, mm, g = (int(v) for v in params[z["param"][k]])
+        assert nw.nw_align(s1, s2, m, mm, g) == (a1, a2, int(z["score"][k]))
