@@ -1,0 +1,54 @@
+"""The drop-in boundary seen from the REFERENCE's side: moira.py's own parse_fastq -> process_data -> make_contig ->
+write_results (a lib2to3 copy in a temp dir outside the repo, exactly as tests/golden/make_flag_matrix.py loads it), with
+`nw` bound to moira_amd/dropin/nw_align.py instead of the reference's Cython extension (moira/moira.py:241-245, :794),
+must write the very files the reference wrote with its own aligner (tests/golden/flag_matrix/, incl. the reference's
+golden paired dataset).  Runs only where /root/reference exists (the build container); the `bernoulli` half of the
+boundary needs a GPU and is tested there against the oracle and the same fixtures (tests/test_gpu_*.py)."""
+import importlib.util
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/moira"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout exists in the build container only")
+
+
+@pytest.fixture(scope="module")
+def reference_with_dropin_aligner(oracle):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_flag_matrix as FM
+    import make_golden as MG
+    ref = oracle.reference_module()
+    if ref is None:
+        pytest.skip("oracle/_ref/bernoulli.so is not built")
+    M, tmp = MG.load_python_reference()
+    spec = importlib.util.spec_from_file_location("nw_align_dropin", os.path.join(ROOT, "moira_amd", "dropin", "nw_align.py"))
+    nw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(nw)
+    M.nw, M.Cy_nw_align = nw, True                                   # what `import nw_align as nw` binds with the drop-in first on the path
+    M.bernoulli, M.Cbernoulli = FM.DefinedBernoulli(ref, M), True     # the reference's own extension (as the generator used it)
+    yield M, FM, tmp
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+@pytest.mark.parametrize("case", ["pe_shipped_default", "pe_scores_2_-3_-1", "pe_sum_cap0_fastq", "pe_trim_overlap"])
+def test_reference_pipeline_on_the_dropin_aligner_writes_the_references_files(case, reference_with_dropin_aligner):
+    import golden_io as G
+    M, FM, tmp = reference_with_dropin_aligner
+    spec = G.flag_manifest()["cases"][case]
+    if spec["input"] == "shipped":
+        fwd, rev = os.path.join(REF, "test", "test1.fastq"), os.path.join(REF, "test", "test2.fastq")
+    else:
+        d1, d2 = G.derive_flag_inputs(G.read_fastq_records(os.path.join(G.GOLDEN, "test1.fastq.gz")),
+                                      G.read_fastq_records(os.path.join(G.GOLDEN, "test2.fastq.bz2")))
+        fwd, rev = os.path.join(tmp, "d1.fastq"), os.path.join(tmp, "d2.fastq")
+        G.write_fastq(fwd, d1)
+        G.write_fastq(rev, d2)
+    files, processed, totals = FM.drive(M, FM.reference_args(**spec["flags"]), fwd, rev)
+    want = G.flag_outputs()[case]
+    assert processed == spec["processed"] and sorted(files) == sorted(want)
+    for stem in want:
+        assert files[stem] == want[stem], (case, stem)
