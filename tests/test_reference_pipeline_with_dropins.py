@@ -52,3 +52,71 @@ def test_reference_pipeline_on_the_dropin_aligner_writes_the_references_files(ca
     assert processed == spec["processed"] and sorted(files) == sorted(want)
     for stem in want:
         assert files[stem] == want[stem], (case, stem)
+
+
+def _serve_stub(path, name):
+    import ctypes as C
+    lib = C.CDLL(path)
+    lib.mpb_broker_serve.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
+    os._exit(abs(lib.mpb_broker_serve(C.c_void_p(1), name.encode(), 8, 0)))
+
+
+@pytest.mark.parametrize("case", ["se_shipped_default", "se_relabel_usearch_truncate", "se_alpha05_uncert02"])
+def test_reference_pipeline_on_the_dropin_bernoulli_module(case, reference_with_dropin_aligner, oracle, tmp_path_factory, monkeypatch):
+    """The other half of the boundary, as far as it goes without a GPU: moira.py's own process_data calling
+    moira_amd/dropin/bernoulli.py (the real module, the real client side of libmoira_pb.so: packer, shared-memory slot,
+    hand-over) -- with the broker process served by the CPU stand-in of tests/test_broker_protocol.py (mpb_broker.cpp
+    compiled unchanged, the oracle for the arithmetic).  What this pins: the module's signature / marshalling / broker
+    protocol inside the reference's pipeline; the kernels behind it are pinned on the GPU."""
+    import ctypes as C
+    import multiprocessing as mp
+    import subprocess
+    import time
+    import golden_io as G
+    M, FM, tmp = reference_with_dropin_aligner
+    out = str(tmp_path_factory.mktemp("stub") / "libbroker_test.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-Wl,-Bsymbolic", os.path.join(ROOT, "moira_amd", "csrc", "mpb_broker.cpp"),
+                           os.path.join(ROOT, "tests", "helpers", "broker_stub.cpp"), oracle._LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(oracle._LIB_PATH), "-o", out])
+    name = "refside_%d_%s" % (os.getpid(), case[:12].replace("-", "_"))
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_serve_stub, args=(out, name))
+    p.start()
+    monkeypatch.setenv("MOIRA_PB_BROKER", "1")
+    monkeypatch.setenv("MOIRA_PB_BROKER_NAME", name)
+    try:
+        from moira_amd import broker
+        t0 = time.time()
+        while broker.stats(name) is None or not broker.stats(name)["pid"]:
+            assert p.is_alive() and time.time() - t0 < 30
+            time.sleep(0.01)
+        spec_ = importlib.util.spec_from_file_location("bernoulli_dropin_%s" % case[:8], os.path.join(ROOT, "moira_amd", "dropin", "bernoulli.py"))
+        mod = importlib.util.module_from_spec(spec_)
+        spec_.loader.exec_module(mod)
+        saved = M.bernoulli
+        M.bernoulli = mod                                     # what `import bernoulli` binds with the drop-in first on the path
+        try:
+            spec = G.flag_manifest()["cases"][case]
+            if spec["input"] == "shipped":
+                fwd = os.path.join(REF, "test", "test1.fastq")
+            else:
+                d1, _ = G.derive_flag_inputs(G.read_fastq_records(os.path.join(G.GOLDEN, "test1.fastq.gz")),
+                                             G.read_fastq_records(os.path.join(G.GOLDEN, "test2.fastq.bz2")))
+                fwd = os.path.join(tmp, "s1.fastq")
+                G.write_fastq(fwd, d1)
+            files, processed, totals = FM.drive(M, FM.reference_args(**spec["flags"]), fwd, None)
+        finally:
+            M.bernoulli = saved
+        want = G.flag_outputs()[case]
+        assert processed == spec["processed"] and sorted(files) == sorted(want)
+        for stem in want:
+            assert files[stem] == want[stem], (case, stem)
+        assert broker.stats(name)["served"] >= processed      # every read went through the broker
+    finally:
+        lib = C.CDLL(out)
+        lib.mpb_broker_shutdown.argtypes = [C.c_char_p]
+        lib.mpb_broker_shutdown(name.encode())
+        p.join(10)
+        if p.is_alive():
+            p.kill()
