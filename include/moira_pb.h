@@ -217,14 +217,16 @@ int mpb_encode_ascii_device(mpb_ctx *ctx, const uint8_t *d_q, int64_t n, int64_t
  * d_ee[i] is the value process_data returns (after +Ns / floor).
  * Asynchronous on the context's stream unless `counts` is given.
  *
- * Read length: up to 16383 bases (row_stride <= 16384).  A read whose DP needs at most 1024 rows -- every read of
- * up to 1023 bases, and any longer read with fewer than about a thousand expected errors -- runs in one wave
+ * Read length: up to 65535 bases (row_stride <= 65536; rounds 1-3: 16383).  A read whose DP needs at most 1024 rows --
+ * every read of up to 1023 bases, and any longer read with fewer than about a thousand expected errors -- runs in one wave
  * (the running probability vector in registers, 16 rows per lane); one that needs more is run by a workgroup of up to
  * 16 waves, the row that crosses a wave boundary travelling through an LDS stream.  Same arithmetic either way.
+ * What a read may NEED is 16384 DP rows (16 waves x 1024: about 16,000 expected errors).  A read of up to 16383 bases can
+ * never need more; a longer one that does -- tens of thousands of bases of which a third are wrong -- gets ee = NaN, pass = 0.
  * (The reference's C extension keeps its table on the stack and overruns it near 1000 bases; its Python twin,
  * ref: moira/moira.py:1561-1634, has no limit -- `--error_calc poisson_binomial_py`.)
  *
- * A length in d_len outside 0..min(row_stride, 16383) is NEVER clamped: that read gets ee = NaN, pass = 0, Ns = 0 (so
+ * A length in d_len outside 0..min(row_stride, 65535) is NEVER clamped: that read gets ee = NaN, pass = 0, Ns = 0 (so
  * a caller that passes counts == NULL and never synchronises on an error cannot consume a result computed on a
  * different length), a device-side counter is raised, and the next call on this context that fetches `counts` from
  * mpb_filter_device fails with MPB_E_INVALID and clears it.
@@ -272,7 +274,7 @@ int mpb_filter_device_classified(mpb_ctx *ctx,
  * kernel straight from the library's pinned block (one runtime call, no copies), and up to 256 reads report their completion
  * through a word per read in the same block instead of the runtime's completion signal: 27 us for one read.  Results are
  * identical either way.
- * Lengths are validated, never clamped: a len[i] < 0, > row_stride or > 16383 fails the call with
+ * Lengths are validated, never clamped: a len[i] < 0, > row_stride or > 65535 fails the call with
  * MPB_E_INVALID before anything is computed (mpb_filter_device, whose lengths live on the device, gives such a
  * read ee = NaN, pass = 0 and reports the condition from a device-side counter when `counts` is requested).
  */

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmoira_pb.so")
 
-MAX_LEN = 16383     # MPB_MAX_LEN (csrc/mpb_internal.h): longest read (up to 1024 DP rows: one wave; more: k_wide, 16 waves)
+MAX_LEN = 65535     # MPB_MAX_LEN (csrc/mpb_internal.h): longest read; a read may NEED up to 16384 DP rows (1024: one wave; more: k_wide, 16 waves)
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_RANGE = 0, -1, -2, -3, -4, -5
 AMBIG = {"treat_as_errors": 0, "ignore": 1, "disallow": 2}
 FLAG_ROUND, FLAG_FAST_FMA, FLAG_TEST_UNDERPREDICT, FLAG_DECISION_ONLY, FLAG_BATCHED_ONLY, FLAG_COUNT_CELLS = 1, 2, 4, 8, 16, 32

@@ -67,7 +67,7 @@ class QualityTooHighError(UnsupportedReadError):
 
 
 class ReadTooLongError(UnsupportedReadError):
-    """Not a reference exception: the Poisson-binomial kernels cover reads of up to 16383 bases (the reference's
+    """Not a reference exception: the Poisson-binomial kernels cover reads of up to 65535 bases (the reference's
     own C path overruns its stack near 1000; its Python twin has no limit but needs O(J^2 L) Python
     steps).  Raised BEFORE the chunk is filtered; main() removes the partial output files and explains the
     alternatives."""
@@ -80,7 +80,7 @@ class ReadTooLongError(UnsupportedReadError):
                 "for reads > 500 nt) or --truncate." % (self.header, self.length, MAX_PB_LEN))
 
 
-MAX_PB_LEN = 16383       # MPB_MAX_LEN of the HIP library
+MAX_PB_LEN = 65535       # MPB_MAX_LEN of the HIP library (a read may NEED at most 16384 DP rows: ~16,000 expected errors)
 
 
 class ReturnedNaNError(Exception):
@@ -157,7 +157,8 @@ def build_parser():
     p = argparse.ArgumentParser(
         description="Perform quality filtering on a set of sequences.",
         epilog="Limits of this build (a run that meets one stops with a message and leaves no partial output): the "
-               "poisson_binomial methods score reads of up to 16383 bases (--error_calc poisson: any length).")
+               "poisson_binomial methods score reads of up to 65535 bases that need at most 16384 rows of the error table, i.e. about "
+               "16,000 expected errors (--error_calc poisson: any length).")
     g = p.add_argument_group("General options")
     g.add_argument("-ff", "--forward_fasta", type=str, help="Forward fasta file (can be gzip or bzip2 compressed).")
     g.add_argument("-fq", "--forward_qual", type=str, help="Forward qual file (can be gzip or bzip2 compressed).")

@@ -1117,12 +1117,12 @@ int mpb_filter_host(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t row_stride,
         for (int64_t i = 0; i < n; i++)
             if (len[i] < 0 || len[i] > lim)
                 return fail(MPB_E_INVALID, len[i] > row_stride || len[i] < 0 ? "read %lld: length %d does not fit the %lld-byte row"
-                                                                             : "read %lld: %d bases; reads longer than 16383 bases are not supported (row of %lld bytes)",
+                                                                             : "read %lld: %d bases; reads longer than 65535 bases are not supported (row of %lld bytes)",
                             (long long)i, len[i], (long long)row_stride);
     }
     if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
     if (n == 0) return MPB_OK;
-    if (n <= MPB_SMALL_N && n * row_stride <= (8ll << 20) && !(params->flags & MPB_FLAG_BATCHED_ONLY)) {
+    if (n <= MPB_SMALL_N && n * row_stride <= (8ll << 20) && row_stride <= MPB_SMALL_MAX_STRIDE && !(params->flags & MPB_FLAG_BATCHED_ONLY)) {
         bool done = false;
         rc = filter_host_small(c, q, n, row_stride, len, fixed_len, params, ee, ns, pass, counts, &done);
         if (rc || done) return rc;

@@ -191,7 +191,7 @@ struct Broker {
     {
         const size_t ns = (size_t)n_slots;
         off_q = (ns * 4 + 255) & ~(size_t)255;                        // input block: len[n_slots] | q[m x stride]
-        const size_t in_cap = off_q + ns * (size_t)MPB_MAX_STRIDE;
+        const size_t in_cap = off_q + ns * (size_t)MPB_SMALL_MAX_STRIDE;   // (a longer read is run alone, through the pipeline)
         off_ee = 0;                                                   // output block: ee | ns | pass
         off_ns = ns * 8;
         off_pass = off_ns + ns * 4;
@@ -404,7 +404,7 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
             for (int i = 0; i < n_slots; i++) {
                 BrkSlot *s = b.map.slot(i);
                 if (s->state.load(std::memory_order_acquire) != ST_SUBMITTED) continue;
-                if (s->priv) {                       // its own code table: cannot share a launch
+                if (s->priv || s->len > MPB_SMALL_MAX_STRIDE - 1) {   // its own code table, or a row too long for k_small: cannot share a launch
                     s->state.store(ST_RUNNING, std::memory_order_relaxed);
                     b.run_solo(i);
                     progress = true;

@@ -14,13 +14,16 @@
 // Tile classes (below) cover up to MPB_TILE_MAX_ROWS rows of the DP table: one wave, 64 lanes x 16 registers.
 // A read predicted to need more rows is a WIDE read: one workgroup of up to MPB_WIDE_WAVES waves holds its running
 // vector (wave w keeps rows w*1024 .. w*1024+1023), the waves run one 64-base block apart and hand the row that
-// crosses a wave boundary on through an LDS stream (k_wide).  16 waves x 1024 rows = 16384 rows = a read of
-// MPB_MAX_LEN bases in which every base is an error.
+// crosses a wave boundary on through an LDS stream (k_wide).  16 waves x 1024 rows = 16384 rows: what a read may NEED (about
+// 16,000 expected errors); a read that needs more has no result (NaN, pass = 0).  Rounds 1-3 tied the longest read to that
+// number (len + 1 <= rows, so that the fallback always covers); round 4: the kernels never cared about the length itself, a
+// long read of moderate quality needs few rows, so the longest read is what the 16-bit counters of ambiguous bases hold.
 #define MPB_TILE_MAX_ROWS 1024
 #define MPB_WIDE_WAVES 16
 #define MPB_MAX_ROWS (MPB_TILE_MAX_ROWS * MPB_WIDE_WAVES)
-#define MPB_MAX_LEN (MPB_MAX_ROWS - 1)     // longest read: rows needed <= len + 1
-#define MPB_MAX_STRIDE MPB_MAX_ROWS       // widest quality-matrix row (bytes)
+#define MPB_MAX_LEN 65535                 // longest read (perm_ns and the prepass' marker counts are 16 bits wide)
+#define MPB_MAX_STRIDE 65536              // widest quality-matrix row (bytes)
+#define MPB_SMALL_MAX_STRIDE 16384        // widest row of the one-read-per-wave kernel (a lane peels at most 256 bytes of markers)
 
 struct MpbClass { int cap, G, R; };
 

@@ -30,7 +30,7 @@ int mpbi_check_one_read(const char *contig, const int32_t *q, int32_t len, doubl
     if (!ee || !ns) return mpbi_fail(MPB_E_INVALID, "NULL output");
     if (!(alpha > 0 && alpha < 1)) return mpbi_fail(MPB_E_INVALID, "Alpha must be between 0 and 1");
     if (contig && (int32_t)strlen(contig) != len) return mpbi_fail(MPB_E_INVALID, "contig and contig_quals must have the same length");
-    if (len > 16383) return mpbi_fail(MPB_E_INVALID, "reads longer than 16383 bases are not supported");
+    if (len > 65535) return mpbi_fail(MPB_E_INVALID, "reads longer than 65535 bases are not supported");
     return MPB_OK;
 }
 

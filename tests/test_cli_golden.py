@@ -288,7 +288,7 @@ def test_config1_plumbing_gpu(tmp_path):
 
 @pytest.mark.parametrize("line_parser", [False, True])
 def test_over_long_read_fails_cleanly_before_filtering(tmp_path, oracle, monkeypatch, line_parser):
-    """a read longer than the Poisson-binomial kernels cover (16383 bases since round 3; 1023 before) used to
+    """a read longer than the Poisson-binomial kernels cover (65535 bases since round 4; 16383 in round 3; 1023 before) used to
     abort the run from inside the library after earlier chunks had been written.  It now stops before the chunk is
     filtered, says which read and what to do, returns 1 and leaves no partial output files; --error_calc poisson has
     no such limit."""
@@ -297,14 +297,14 @@ def test_over_long_read_fails_cleanly_before_filtering(tmp_path, oracle, monkeyp
         monkeypatch.setenv("MOIRA_NO_FASTIO", "1")
     fq = tmp_path / "long.fastq"
     with open(fq, "w") as f:
-        for k, n in enumerate((300, 16500, 250)):
+        for k, n in enumerate((300, 66000, 250)):
             f.write("@r%d\n%s\n+\n%s\n" % (k, "ACGT" * (n // 4) + "A" * (n % 4), "I" * n))
     out = str(tmp_path / "o")
     msg = io.StringIO()
     a = reference_args(paired=False, forward_fastq=str(fq), output_prefix=out, collapse=False, silent=True)
     assert cli.main(a, backend=oracle_backend(oracle), out=msg, _no_fastio=line_parser) == 1
     text = msg.getvalue()
-    assert "r1" in text and "16500 bases" in text and "--error_calc poisson" in text and "--truncate" in text
+    assert "r1" in text and "66000 bases" in text and "--error_calc poisson" in text and "--truncate" in text
     assert not [p for p in os.listdir(tmp_path) if p.startswith("o.")]
     # with --truncate the same file goes through
     a = reference_args(paired=False, forward_fastq=str(fq), output_prefix=out, collapse=False, truncate=200)

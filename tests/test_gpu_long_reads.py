@@ -133,13 +133,35 @@ def test_per_read_entry_long(eng, oracle):
         assert eng.calculate_errors_PB(seq, quals, 0.005) == (want[0], want[1])
 
 
+def test_reads_beyond_16383_bases(eng, oracle):
+    """Round 4: the length limit is 65535 bases (rounds 1-3: 16383, because the fallback had to cover len + 1 rows).  What a
+    read may NEED is still 16384 DP rows: good and middling long reads (a handful to a few thousand rows: tile classes on
+    long rows, k_wide) are bit-exact against the oracle, with ambiguous bases and in a batch with short reads; a read that
+    needs more rows than 16 waves hold has no result (NaN, rejected) -- never a wrong one."""
+    q, lens = _batch([(20000, 30, 41, 2), (40000, 25, 41, 1), (65535, 33, 41, 1), (30000, 9, 14, 1), (50000, 12, 20, 1),
+                      (65535, 10, 12, 1), (300, 2, 41, 3), (1500, 1, 3, 1), (24000, 1, 2, 1), (65535, 2, 3, 1)], 65536, 29)
+    q[0, 19000] = 0; q[0, 150] = 255; q[3, 29999] = 0; q[5, 40000:40100] = 0
+    ee, ns, ps, rows = oracle.filter_batch(q, lens=lens, threads=8)
+    need = rows > 16384
+    assert need.sum() == 2 and rows[~need].max() > 6000 and (rows < 40).sum() >= 5     # Q1 x 24000 and Q2 x 65535 need too much
+    r = eng.filter(q, lens=lens, batched_only=True)
+    assert same(r.ee[~need], ee[~need]) and np.array_equal(r.ns, ns)
+    assert np.array_equal(r.passed[~need], ps[~need].astype(bool))
+    assert np.isnan(r.ee[need]).all() and not r.passed[need].any()
+    assert not np.isnan(r.ee[~need]).any()
+    # the per-read entry takes them too (through the pipeline: the one-read-per-wave kernel stops at 16384-byte rows)
+    seq = "".join("N" if v == 0 else "n" if v == 255 else "A" for v in q[0, :lens[0]])
+    quals = [int(v) if v not in (0, 255) else 30 for v in q[0, :lens[0]]]
+    assert eng.calculate_errors_PB(seq, quals, 0.005) == oracle.ee_rowwise(seq, quals, 0.005)[:2]
+
+
 def test_too_long_is_refused_not_truncated(eng):
     from moira_amd import _lib as L
     prm = eng.params()
-    q = np.full((2, 16400), 30, np.uint8)
+    q = np.full((2, 65600), 30, np.uint8)
     ee, ns, ps = np.zeros(2), np.zeros(2, np.int32), np.zeros(2, np.uint8)
-    rc = eng.lib.mpb_filter_host(eng.ctx, q.ctypes.data, 2, 16400 // 16 * 16, None, 16390, C.byref(prm),
+    rc = eng.lib.mpb_filter_host(eng.ctx, q.ctypes.data, 2, 65600 // 16 * 16, None, 65590, C.byref(prm),
                                  ee.ctypes.data, ns.ctypes.data, ps.ctypes.data, None)
     assert rc == L.E_INVALID
-    with pytest.raises(ValueError, match="16383"):
-        eng.calculate_errors_PB("A" * 16384, [30] * 16384, 0.005)
+    with pytest.raises(ValueError, match="65535"):
+        eng.calculate_errors_PB("A" * 65536, [30] * 65536, 0.005)
