@@ -249,6 +249,7 @@ int mpb_filter_device(mpb_ctx *ctx,
  * mpb_decode_ascii_device + mpb_filter_device.  Any other filter call on the context in between invalidates the
  * classification (mpb_filter_device_classified then fails with MPB_E_INVALID; nothing stale is ever consumed).
  * Both are asynchronous on the context's stream (unless `counts` is given).
+ * Rows of up to 16384 bytes (the fused pass parks whole rows in LDS); longer text: mpb_decode_ascii_device + mpb_filter_device.
  */
 int mpb_decode_classify_device(mpb_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual_ascii, int64_t n,
                                int64_t row_stride, const int32_t *d_len, int32_t fixed_len, int32_t fastq_offset,

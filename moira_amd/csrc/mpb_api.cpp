@@ -688,6 +688,11 @@ int mpb_decode_classify_device(mpb_ctx *c, const uint8_t *d_seq, const uint8_t *
     if ((rc = check_device_batch(d_q_out, n, row_stride, d_len, fixed_len, d_ee, d_ns, d_pass, &max_len))) return rc;
     if ((((uintptr_t)d_seq | (uintptr_t)d_qual) & 15) != 0) return fail(MPB_E_INVALID, "matrices must be 16-byte aligned");
     if (n > 0 && (!d_seq || !d_qual)) return fail(MPB_E_INVALID, "NULL device buffer");
+    // the fused pass parks a tile of WHOLE rows in LDS (k_classify_linear: 1,280 chunks): a row of more than 16384 bytes does not
+    // fit one -- such text goes through mpb_decode_ascii_device + mpb_filter_device, which take rows of up to 65536 bytes
+    if (row_stride > MPB_SMALL_MAX_STRIDE)
+        return fail(MPB_E_INVALID, "row_stride %lld: the classify-at-source pass takes rows of up to %d bytes (decode with "
+                    "mpb_decode_ascii_device, then mpb_filter_device)", (long long)row_stride, MPB_SMALL_MAX_STRIDE);
     c->classified.valid = false;
     if (n == 0) return MPB_OK;
     if ((rc = prepare_batch(c, n, max_len))) return rc;
@@ -997,7 +1002,12 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
     // is large enough for a chunk to be worth a launch sequence (overlap needs more than one chunk)
     int64_t chunk = (int64_t)MPB_HOST_CHUNK_BYTES / row_stride;
     if (chunk > (n + 3) / 4) chunk = (n + 3) / 4;
-    if (chunk < 16384) chunk = 16384;
+    {   // ... but not below 16384 reads (a launch sequence's worth), nor -- rows of up to 64 KiB -- above 256 MiB for that floor
+        int64_t floor_reads = (256ll << 20) / row_stride;
+        if (floor_reads > 16384) floor_reads = 16384;
+        if (floor_reads < 256) floor_reads = 256;
+        if (chunk < floor_reads) chunk = floor_reads;
+    }
     if (chunk > n) chunk = n;
     const ChunkLayout L = chunk_layout(chunk, row_stride);
     const bool q_pinned = is_pinned_host(q, (size_t)(n * row_stride));

@@ -150,3 +150,16 @@ class DeviceSlice:
         out = np.empty(self.nbytes, np.uint8)
         L.check(self.eng.lib.mpb_memcpy_d2h(self.eng.ctx, out.ctypes.data, self.ptr, self.nbytes))
         return out
+
+
+def test_rows_longer_than_a_tile_are_refused_by_the_fused_pass():
+    """Round 4: mpb_filter_device takes rows of up to 65536 bytes; the classify-at-source pass parks whole rows in LDS and keeps
+    its 16384-byte limit -- by name, not by computing on part of a row."""
+    from moira_amd.engine import Engine
+    with Engine(0) as eng:
+        n, stride = 4, 32768
+        bufs = [eng.alloc(n * stride) for _ in range(3)] + [eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)]
+        with pytest.raises(ValueError, match="classify-at-source pass takes rows of up to 16384"):
+            eng.filter_ascii_device(bufs[0], bufs[1], n, stride, bufs[2], fixed_len=30000, d_ee=bufs[3], d_ns=bufs[4], d_pass=bufs[5])
+        for b in bufs:
+            b.free()

@@ -106,7 +106,7 @@ with Engine(0) as eng:
             ok = ok and np.array_equal(np.isnan(r.ee), np.isnan(ee)) and (rel.size == 0 or rel.max() <= 1e-9)
         else:
             ok = ok and np.array_equal(r.ee, ee, equal_nan=True)
-        if rng.random() < 0.3 and int(q[(q != 255)].max(initial=0)) <= 222:
+        if rng.random() < 0.3 and int(q[(q != 255)].max(initial=0)) <= 222 and stride <= 16384:      # (the fused pass: rows of <= 16384 bytes)
             # classified at source (round 3): the same reads as FASTQ text resident in HBM, decoded and classified by one
             # pass (k_classify_linear), the filter starting at the scan -- same oracle results, and the packed matrix back
             seq = np.where(q == 0, ord("N"), np.where(q == 255, ord("n"), ord("A"))).astype(np.uint8)
