@@ -84,12 +84,17 @@ MAX_PB_LEN = 65535       # MPB_MAX_LEN of the HIP library (a read may NEED at mo
 
 
 class ReturnedNaNError(Exception):
-    def __init__(self, header):
-        self.header = header
+    def __init__(self, header, length=None):
+        self.header, self.length = header, length
 
     def __str__(self):
-        return ("Error calculation returned NaN for sequence %s. If using a C implementation, "
-                "try switching to the python one instead." % self.header)
+        msg = ("Error calculation returned NaN for sequence %s. If using a C implementation, "
+               "try switching to the python one instead." % self.header)          # the reference's words (moira/moira.py:973-979)
+        if self.length is not None and self.length > 16383:
+            # the one way this build produces a NaN under the Poisson-binomial methods: more rows than 16 waves hold
+            msg += (" (This build: the read has %d bases and needs more than 16384 rows of the error table, i.e. about 16,000 "
+                    "expected errors; --error_calc poisson has no such limit.)" % self.length)
+        return msg
 
 
 class UnpairedFilesError(Exception):
@@ -1163,7 +1168,7 @@ def _run_fast_fastq(args, backend, o, say, t0):
                 has_n[sel] = fl
             nan = np.isnan(ee)
             if nan.any():
-                raise ReturnedNaNError(F.header_of(buf, idx[int(np.argmax(nan))]))
+                raise ReturnedNaNError(F.header_of(buf, idx[int(np.argmax(nan))]), int(lens[int(np.argmax(nan))]))
             if args.collapse:
                 emit.submit(lambda buf=buf, idx=idx, ee=ee, has_n=has_n, aux=aux: groups.add(buf, idx, ee, has_n, T, aux))
             else:
@@ -1317,7 +1322,7 @@ def main(args, backend=None, out=None, _no_fastio=False):
             nonlocal processed, disc_err, disc_len, disc_ov
             for header, contig, cquals, ee, ov, gaps, mism in process_chunk(chunk, args, backend):
                 if isinstance(ee, float) and math.isnan(ee):
-                    raise ReturnedNaNError(header)
+                    raise ReturnedNaNError(header, len(contig))
                 if args.collapse:
                     if contig not in uniques:
                         uniques[contig] = {"rep_header": header, "rep_errors": ee, "rep_quals": cquals,
