@@ -373,7 +373,8 @@ def test_long_reads_run_with_the_poisson_binomial_method_gpu(tmp_path, oracle, l
     fq = tmp_path / "long.fastq"
     rng = np.random.default_rng(8)
     recs = []
-    for k, (n, lo, hi) in enumerate(((300, 25, 41), (1100, 30, 41), (2500, 33, 41), (2500, 1, 4), (4000, 35, 41), (700, 2, 41))):
+    for k, (n, lo, hi) in enumerate(((300, 25, 41), (1100, 30, 41), (2500, 33, 41), (2500, 1, 4), (4000, 35, 41), (700, 2, 41),
+                                     (30000, 36, 41))):          # round 4: beyond 16383 bases
         q = "".join(chr(33 + int(v)) for v in rng.integers(lo, hi, n))
         s = "".join(rng.choice(list("ACGT"), n))
         recs.append((s, q))
