@@ -120,3 +120,61 @@ def test_reference_pipeline_on_the_dropin_bernoulli_module(case, reference_with_
         p.join(10)
         if p.is_alive():
             p.kill()
+
+
+def test_dropin_survives_a_broker_that_dies(oracle, tmp_path_factory, monkeypatch):
+    """The broker is killed (SIGKILL: no cleanup, its segment stays behind, still marked 'serving') while a worker is
+    attached.  The worker's next call finds out within about a second (the broker's pid is gone), drops the attachment,
+    attaches to the broker that now serves under the same name, and the call is answered -- once.  (On a GPU box the drop-in
+    module would start that new broker itself; here, without a GPU, the test starts the CPU stand-in.)"""
+    import ctypes as C
+    import multiprocessing as mp
+    import signal
+    import subprocess
+    import time
+    out = str(tmp_path_factory.mktemp("stub2") / "libbroker_test.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-Wl,-Bsymbolic", os.path.join(ROOT, "moira_amd", "csrc", "mpb_broker.cpp"),
+                           os.path.join(ROOT, "tests", "helpers", "broker_stub.cpp"), oracle._LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(oracle._LIB_PATH), "-o", out])
+    from moira_amd import broker
+    name = "dies_%d" % os.getpid()
+    ctx = mp.get_context("spawn")
+    monkeypatch.setenv("MOIRA_PB_BROKER", "1")
+    monkeypatch.setenv("MOIRA_PB_BROKER_NAME", name)
+
+    def serving():
+        st = broker.stats(name)
+        return st is not None and st["pid"] > 0
+
+    def start():
+        p = ctx.Process(target=_serve_stub, args=(out, name))
+        p.start()
+        t0 = time.time()
+        while not serving():
+            assert p.is_alive() and time.time() - t0 < 30
+            time.sleep(0.01)
+        return p
+    a = start()
+    spec_ = importlib.util.spec_from_file_location("bernoulli_dropin_dies", os.path.join(ROOT, "moira_amd", "dropin", "bernoulli.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    read = ("ACGTNACGTA" * 9, [2 + (i * 5) % 39 for i in range(90)], 0.005)
+    want = oracle.ee_rowwise(*read)[:2]
+    assert mod.calculate_errors_PB(*read) == want
+    os.kill(a.pid, signal.SIGKILL)
+    a.join()
+    assert not serving()                                  # the segment is still there, its broker is not
+    b = start()                                           # (replaces the dead broker's segment under the same name)
+    try:
+        t0 = time.time()
+        assert mod.calculate_errors_PB(*read) == want     # notices, re-attaches, is answered
+        assert 0.5 < time.time() - t0 < 10
+        assert mod.calculate_errors_PB(*read) == want and broker.stats(name)["served"] >= 2
+    finally:
+        lib = C.CDLL(out)
+        lib.mpb_broker_shutdown.argtypes = [C.c_char_p]
+        lib.mpb_broker_shutdown(name.encode())
+        b.join(10)
+        if b.is_alive():
+            b.kill()
