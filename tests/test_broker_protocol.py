@@ -224,13 +224,13 @@ def test_shutdown_is_seen_by_an_attached_client(stub_lib):
 def test_idle_exit_waits_for_attached_processes(stub_lib):
     ctx = mp.get_context("spawn")
     name = "i%d" % os.getpid()
-    p = ctx.Process(target=_serve, args=(stub_lib, name, 4, 300))       # leaves 0.3 s after the last attached process
-    p.start()
+    p = ctx.Process(target=_serve, args=(stub_lib, name, 4, 1500))      # leaves 1.5 s after the last attached process
+    p.start()                                             # (long enough for a loaded box to get its attach in first)
     lib = _load(stub_lib)
     h = C.c_void_p()
     assert lib.mpb_broker_attach(name.encode(), 20000, C.byref(h)) == 0
-    time.sleep(1.0)
-    assert p.is_alive()                                   # attached and quiet: stays
+    time.sleep(3.0)
+    assert p.is_alive()                                   # attached and quiet for twice the idle time: stays
     lib.mpb_broker_detach(h)
-    p.join(10)
+    p.join(20)
     assert p.exitcode == 0 and _stats(lib, name) is None
