@@ -39,9 +39,10 @@ struct MpbClass { int cap, G, R; };
     X(29, 12, 32) X(30, 16, 32) X(31, 16, 64)
 
 // Latency bodies of the one-read-per-wave kernel (k_small): X(id, R, G) with cap = R * G = 2^(id + 1); a read of `rows` rows takes
-// id = ceil(log2(rows)) - 1.  (2, 1) and (16, 64) are tile classes as well; the others exist only here.
+// id = ceil(log2(rows)) - 1.  ONE row per lane up to 64 rows (7 instructions of the wave's dependent chain per base), then 2, 4,
+// 8, 16 rows per lane.  (16, 64) is a tile class as well; the others exist only here.
 #define MPB_THIN_CLASSES(X)                                                                  \
-    X(0, 2, 1) X(1, 2, 2) X(2, 2, 4) X(3, 2, 8) X(4, 2, 16) X(5, 2, 32) X(6, 2, 64)          \
+    X(0, 1, 2) X(1, 1, 4) X(2, 1, 8) X(3, 1, 16) X(4, 1, 32) X(5, 1, 64) X(6, 2, 64)         \
     X(7, 4, 64) X(8, 8, 64) X(9, 16, 64)
 
 #define MPB_CLASS_ENTRY(ID, RR, GG) {(RR) * (GG), GG, RR},

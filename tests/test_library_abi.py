@@ -105,7 +105,7 @@ def test_no_fma_in_exact_dp_kernel():
     shapes = lambda macro: {(int(r), int(g)) for _, r, g in re.findall(r"X\((\d+), (\d+), (\d+)\)", re.search(
         r"#define %s\(X\)((?:.*\\\n)*.*)" % macro, hdr).group(1))}
     tile, thin = shapes("MPB_CLASSES"), shapes("MPB_THIN_CLASSES")       # thin: the latency bodies of k_small (round 4)
-    assert len(tile) == ncls and len(thin) == 10 and len(thin - tile) == 8
+    assert len(tile) == ncls and len(thin) == 10 and len(thin - tile) == 9
     nbodies = len(tile | thin)
     assert len(exact) == nbodies and len(fast) == nbodies
     for b in exact:
