@@ -57,6 +57,30 @@ int main()
     mpb_filter_params q0 = {1.5, 0.01, NAN, 0, 0};
     bad += mpb_poisson_finish_host(lam.data(), ns.data(), nullptr, 300, n, &q0, ee.data(), ps.data()) != MPB_E_INVALID;
     bad += std::strstr(mpb_last_error(), "Alpha must be between 0 and 1") == nullptr;
+    // round 4: the coded batch packer (scores above 254 get spare byte codes), incl. truncation, the full-table refusal, n = 0
+    {
+        const char *sq = "ACNTnGGGACGTACGT";
+        int32_t ql[16] = {30, 300, 30, 0, 7, 5000, 300, 254, 253, 2147483647, 1, 2, 3, 4, 5, 6};
+        int64_t off2[4] = {0, 5, 8, 16};
+        std::vector<uint8_t> qo(3 * 16, 0xCD);
+        int32_t ln[3], codes[256];
+        bad += mpb_pack_batch_coded(sq, ql, off2, 3, 0, 16, qo.data(), ln, codes) != MPB_OK;
+        bad += !(ln[0] == 5 && ln[1] == 3 && ln[2] == 8 && codes[252] == 300 && codes[251] == 5000 && codes[250] == 2147483647);
+        bad += !(qo[0] == 30 && qo[1] == 252 && qo[2] == 0 && qo[3] == 1 && qo[4] == 255 && qo[5] == 0);
+        bad += mpb_pack_batch_coded(nullptr, ql, off2, 3, 2, 16, qo.data(), ln, codes) != MPB_OK;
+        bad += !(ln[0] == 2 && ln[1] == 2 && ln[2] == 2);
+        bad += mpb_pack_batch_coded(sq, ql, off2, 0, 0, 16, qo.data(), ln, codes) != MPB_OK;
+        std::vector<int32_t> full(255);
+        for (int i = 0; i < 254; i++) full[i] = i + 1;
+        full[254] = 300;
+        int64_t off3[2] = {0, 255};
+        std::vector<uint8_t> wide(256);
+        bad += mpb_pack_batch_coded(nullptr, full.data(), off3, 1, 0, 256, wide.data(), ln, codes) != MPB_E_RANGE;
+        int32_t negq[2] = {3, -1};
+        int64_t off4[2] = {0, 2};
+        bad += mpb_pack_batch_coded(nullptr, negq, off4, 1, 0, 16, qo.data(), ln, codes) != MPB_E_RANGE;
+        bad += mpb_pack_batch_coded(nullptr, ql, off2, 3, 0, 8, qo.data(), ln, codes) != MPB_E_INVALID;      // stride not a multiple of 16
+    }
     std::printf("asan_api: %d failed checks, version %s\n", bad, mpb_version());
     return bad != 0;
 }

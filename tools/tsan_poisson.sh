@@ -11,7 +11,7 @@ cat > $D/stubs.cpp <<'CPP'
 #include <cstdlib>
 #define STUB { abort(); }
 void mpb_launch_prepass(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int32_t *, double *, uint8_t *, hipStream_t) STUB
-void mpb_launch_small(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int32_t *, double *, uint8_t *, hipStream_t) STUB
+void mpb_launch_small(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int32_t *, double *, uint8_t *, hipStream_t, const MpbSmallHost *) STUB
 void mpb_launch_scan(int64_t, const int32_t *, const MpbWorkspace &, hipStream_t) STUB
 void mpb_launch_scatter(int64_t, const int32_t *, const int32_t *, const MpbDevParams &, const MpbWorkspace &, hipStream_t) STUB
 void mpb_launch_dp(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, const int32_t *, double *, uint8_t *, hipStream_t) STUB
