@@ -86,6 +86,13 @@ extern "C" {
                                      read per wave (latency: what a per-read caller sees) instead of the sorted,
                                      tiled pipeline; this flag forces the pipeline.  Results are identical. */
 
+#define MPB_FLAG_NO_NARROW 64u   /* never take the natural-order narrow pass (below): the call runs the sorted, tiled pipeline whatever
+                                    the batch looks like.  For callers of the introspection entries that describe that pipeline
+                                    (mpb_last_class_histogram, mpb_last_read_budgets, MPB_FLAG_COUNT_CELLS).  Results are identical. */
+#define MPB_FLAG_NARROW_ROWS(r) (((uint32_t)(r) & 15u) << 8)   /* test / measurement hook: take the narrow pass with r rows (2..4)
+                                    whatever the sample says and however small the batch; reads it cannot finish still go through the
+                                    sorted pipeline, so results are identical. */
+
 /* kernel ids for mpb_kernel_time() */
 #define MPB_K_PREPASS   0   /* lambda/sigma/Ns estimate + row classing        */
 #define MPB_K_SCAN      1   /* class histogram scan / tile table              */
@@ -94,7 +101,10 @@ extern "C" {
 #define MPB_K_OVERFLOW  4   /* re-run of reads whose predicted row count was too small */
 #define MPB_K_LAMBDA    5   /* Poisson approximation: per-read sum of error probabilities */
 #define MPB_K_WIDE      6   /* reads that need more than 1024 DP rows: one workgroup per read */
-#define MPB_K_COUNT     7
+#define MPB_K_NARROW    7   /* natural-order narrow pass: one read per lane, 2..4 DP rows, the matrix read once */
+#define MPB_K_FALLBACK  8   /* ... its list compaction, the gather of the unfinished reads and the scatter of their results */
+#define MPB_K_SAMPLE    9   /* ... the batch sample that picks the pass */
+#define MPB_K_COUNT     10
 
 typedef struct mpb_ctx mpb_ctx;
 
@@ -419,6 +429,11 @@ int mpb_calculate_errors_poisson(mpb_ctx *ctx, const char *sequence,
 int mpb_synth_fill_device(mpb_ctx *ctx, uint8_t *d_q, int64_t n, int64_t row_stride,
                           int32_t fixed_len, int32_t min_len, int32_t max_len,
                           int32_t *d_len, uint64_t seed, int64_t first_read);
+/* The same for a named quality profile of include/mpb_synth.h: 0 = the model above (BASELINE's configs), 1 = a clean run
+ * (Q33..Q40, 0.003 % ambiguous bases: the HBM-bound regime, bench.py extras.high_quality_300). */
+int mpb_synth_fill_device_profile(mpb_ctx *ctx, uint8_t *d_q, int64_t n, int64_t row_stride,
+                                  int32_t fixed_len, int32_t min_len, int32_t max_len,
+                                  int32_t *d_len, uint64_t seed, int64_t first_read, int32_t profile);
 
 /* ---- measurement ----------------------------------------------------------- */
 /* When enabled, every launch of kernel `MPB_K_*` is bracketed by HIP events on
@@ -438,6 +453,31 @@ int mpb_last_class_histogram(mpb_ctx *ctx, int32_t *caps, int64_t *counts, int32
 int mpb_last_read_budgets(mpb_ctx *ctx, int32_t *caps_out, int64_t n);
 /* Algorithmic DP cells of the last mpb_filter_device call made with MPB_FLAG_COUNT_CELLS (0 without it).  Synchronises. */
 int mpb_last_algorithmic_cells(mpb_ctx *ctx, int64_t *cells);
+
+/*
+ * Which pass the last mpb_filter_device call took (round 5).
+ * A batch of GOOD reads -- nearly every read's CDF crosses 1 - alpha within its first 2..4 rows of the table
+ * (ref: moira/bernoullimodule.c:152-166,219-251: rows 0..j depend on no later row) and hardly any read has an ambiguous base --
+ * is bound by HBM, not by FP64 issue, and the sorted pipeline would read the matrix twice.  Such a batch (fixed length,
+ * >= 262144 reads, default table, none of the opt-in flags) takes the NARROW PASS instead: the matrix is read once, in natural
+ * order, one read per lane with narrow_rows rows in registers; reads it cannot finish (more rows needed, or an ambiguous base)
+ * are gathered into a dense sub-batch and run through the sorted pipeline, and their results are scattered back.  The choice is
+ * made from a sample of at most 0.1 % of the reads (the prepass' row prediction on 256..4096 reads spread over the batch), is
+ * reused while the batches of a context keep their shape and parameters (re-sampled when a pass had to hand back more reads
+ * than the sample promised, and every 64 calls), and steers speed only: every read's result is the reference's bit for bit
+ * whichever pass computed it.
+ *   narrow_rows  0: the sorted pipeline; 2..4: the narrow pass with that many rows
+ *   sampled      1 when this call drew a sample (sample_hist is then its histogram: [0] reads with an ambiguous base, [r] reads
+ *                predicted to need r rows (r = 1..14), [15] more), 0 when it reused the previous decision
+ *   n_fallback   reads the narrow pass handed to the sorted pipeline
+ */
+typedef struct mpb_path_info {
+    int32_t narrow_rows;
+    int32_t sampled;
+    int64_t n_fallback;
+    int32_t sample_hist[16];
+} mpb_path_info;
+int mpb_last_path(mpb_ctx *ctx, mpb_path_info *out);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

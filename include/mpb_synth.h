@@ -18,6 +18,11 @@
  *            Q     = clamp(38 - drop - noise, 2, 40)
  *            with probability 66/65536 (~0.1 %) the base is 'N' (byte 0)
  * Output byte uses the packed-qscore encoding of moira_pb.h.
+ *
+ * Profile 1 (MPB_SYNTH_PROFILE_HQ, round 5: the HBM-bound regime of VERDICT r4): a clean run -- every base
+ * Q = 33 + uniform {0..7} (Q33..Q40: 0.077 expected errors in 300 bases, so every read's CDF crosses 1 - 0.005
+ * on the second row of the table), and a base is 'N' with probability 2/65536 (0.9 % of 300-base reads carry one;
+ * the reference's own test1.fastq has none in 1,000 reads).  Same hashes, same draws, only the score formula differs.
  */
 #ifndef MPB_SYNTH_H
 #define MPB_SYNTH_H
@@ -31,6 +36,9 @@
 #endif
 
 #define MPB_SYNTH_N_THRESH 66u      /* of 65536: ~0.1 % ambiguous bases */
+#define MPB_SYNTH_PROFILE_DEFAULT 0
+#define MPB_SYNTH_PROFILE_HQ 1
+#define MPB_SYNTH_HQ_N_THRESH 2u    /* of 65536: ~0.003 % ambiguous bases in the clean profile */
 #define MPB_SYNTH_DEGRADED 7864u    /* of 65536: 12 % degraded reads */
 
 MPB_HD uint64_t mpb_mix64(uint64_t x)
@@ -72,6 +80,16 @@ MPB_HD uint8_t mpb_synth_byte(uint64_t hread, uint32_t pos, uint32_t len)
     if (q < 2) q = 2;
     if (q > 40) q = 40;
     return nflag < MPB_SYNTH_N_THRESH ? (uint8_t)0 : (uint8_t)q;
+}
+
+/* the same for a named profile (0: the model above) */
+MPB_HD uint8_t mpb_synth_byte_profile(uint64_t hread, uint32_t pos, uint32_t len, int32_t profile)
+{
+    if (profile != MPB_SYNTH_PROFILE_HQ) return mpb_synth_byte(hread, pos, len);
+    uint64_t h = mpb_mix64(hread + 0x632BE59BD9B4E019ull * (uint64_t)(pos + 1));
+    uint32_t nflag = (uint32_t)((h >> 16) & 0xFFFFu);
+    uint32_t q = 33u + (uint32_t)(((h & 0xFFFFu) * 8u) >> 16);
+    return nflag < MPB_SYNTH_HQ_N_THRESH ? (uint8_t)0 : (uint8_t)q;
 }
 
 #endif /* MPB_SYNTH_H */

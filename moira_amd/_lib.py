@@ -14,9 +14,17 @@ MAX_LEN = 65535     # MPB_MAX_LEN (csrc/mpb_internal.h): longest read; a read ma
 OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_RANGE = 0, -1, -2, -3, -4, -5
 AMBIG = {"treat_as_errors": 0, "ignore": 1, "disallow": 2}
 FLAG_ROUND, FLAG_FAST_FMA, FLAG_TEST_UNDERPREDICT, FLAG_DECISION_ONLY, FLAG_BATCHED_ONLY, FLAG_COUNT_CELLS = 1, 2, 4, 8, 16, 32
-K_PREPASS, K_SCAN, K_SCATTER, K_DP, K_OVERFLOW, K_LAMBDA, K_WIDE = 0, 1, 2, 3, 4, 5, 6
+FLAG_NO_NARROW = 64
+
+
+def FLAG_NARROW_ROWS(r):
+    """Test / measurement hook (MPB_FLAG_NARROW_ROWS): force the natural-order narrow pass with r rows (2..4)."""
+    return (int(r) & 15) << 8
+
+
+K_PREPASS, K_SCAN, K_SCATTER, K_DP, K_OVERFLOW, K_LAMBDA, K_WIDE, K_NARROW, K_FALLBACK, K_SAMPLE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 KERNEL_NAMES = {K_PREPASS: "prepass", K_SCAN: "scan", K_SCATTER: "scatter", K_DP: "dp", K_OVERFLOW: "overflow", K_LAMBDA: "lambda",
-                K_WIDE: "wide"}
+                K_WIDE: "wide", K_NARROW: "narrow", K_FALLBACK: "fallback", K_SAMPLE: "sample"}
 
 
 class MoiraPBError(RuntimeError):
@@ -30,6 +38,11 @@ class NoDeviceError(MoiraPBError):
 class FilterParams(C.Structure):
     _fields_ = [("alpha", C.c_double), ("uncert", C.c_double), ("maxerrors", C.c_double),
                 ("ambig_mode", C.c_int32), ("flags", C.c_uint32)]
+
+
+class PathInfo(C.Structure):
+    _fields_ = [("narrow_rows", C.c_int32), ("sampled", C.c_int32), ("n_fallback", C.c_int64),
+                ("sample_hist", C.c_int32 * 16)]
 
 
 class FilterCounts(C.Structure):
@@ -93,12 +106,15 @@ PROTOTYPES = {
                                           C.POINTER(FilterParams), _VP, _VP, _VP, C.POINTER(FilterCounts)]),
     "mpb_synth_fill_device": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                         C.c_int32, _VP, C.c_uint64, C.c_int64]),
+    "mpb_synth_fill_device_profile": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                                C.c_int32, _VP, C.c_uint64, C.c_int64, C.c_int32]),
     "mpb_timing_enable": (C.c_int, [_VP, C.c_int]),
     "mpb_timing_reset": (C.c_int, [_VP]),
     "mpb_kernel_time": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mpb_last_class_histogram": (C.c_int, [_VP, _VP, _VP, C.c_int32]),
     "mpb_last_read_budgets": (C.c_int, [_VP, _VP, C.c_int64]),
     "mpb_last_algorithmic_cells": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
+    "mpb_last_path": (C.c_int, [_VP, C.POINTER(PathInfo)]),
 }
 
 _lib = None

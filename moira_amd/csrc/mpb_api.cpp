@@ -94,6 +94,20 @@ struct mpb_ctx {
     void *pin_host = nullptr;
     int64_t pin_cap = 0;
     uint32_t small_token = 0;            // completion token of the last zero-copy k_small launch (never 0)
+    // ---- natural-order narrow pass (round 5) ----
+    int n_cu = 0;                        // compute units of the device (the persistent grid of k_narrow)
+    bool narrow_ok = false;              // the default table satisfies a == 1 - b for every score (checked by mpb_create)
+    void *ws_nar = nullptr;              // wave segments + dense list + per-wave counts / offsets
+    int64_t ws_nar_cap = 0;
+    void *fb_block = nullptr;            // the sub-batch the narrow pass could not finish: rows | ee | ns | pass
+    int64_t fb_cap = 0;                  // ... reads it holds
+    int64_t fb_stride = 0;
+    int32_t *pin_words = nullptr;        // pinned host words: [0] list count, [16..32) the sample histogram
+    struct NarrowChoice {                // the last decision, reused while the batches keep their shape (it steers speed only)
+        bool valid = false; int64_t n = 0, stride = 0; int32_t fixed_len = 0; double alpha = 0; uint32_t flags = 0;
+        int rows0 = 0; int calls = 0;
+    } nar_choice;
+    mpb_path_info last_path{};
 };
 
 // Threads that copy a pageable input chunk into its pinned staging block: half of the CPUs this process is
@@ -209,8 +223,21 @@ int mpb_create(int device_id, mpb_ctx **out)
     if (e == hipSuccess) {
         double2 h[256];
         build_lut(h);
+        // the narrow pass keeps {p'} alone and recomputes 1 - p' on the device: only sound if the table's a IS that difference
+        // (it is: p' == p bit for bit for every encodable score, tests/test_oracle_golden.py::test_lut_pins)
+        c->narrow_ok = true;
+        for (int qq = 1; qq < 255; qq++) {
+            volatile double d = 1.0 - h[qq].y;
+            if (memcmp((const void *)&d, &h[qq].x, sizeof(double)) != 0) c->narrow_ok = false;
+        }
         e = hipMemcpyAsync(c->d_lut, h, sizeof(h), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // h is on this frame
+    }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->pin_words, 64 * sizeof(int32_t), hipHostMallocDefault);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device_id);
+        if (e == hipSuccess) c->n_cu = prop.multiProcessorCount;
     }
     if (e != hipSuccess) {
         int rc = fail(MPB_E_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -244,6 +271,9 @@ int mpb_destroy(mpb_ctx *c)
     if (c->one_dev) (void)hipFree(c->one_dev);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     if (c->pin_host) (void)hipHostFree(c->pin_host);
+    if (c->pin_words) (void)hipHostFree(c->pin_words);
+    if (c->ws_nar) (void)hipFree(c->ws_nar);
+    if (c->fb_block) (void)hipFree(c->fb_block);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_lut_private) (void)hipFree(c->d_lut_private);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -401,7 +431,7 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
 {
     if (!c->ws_small) {
         // tables (2), overflow counter, bad-length counter, pass counter, overflow total of a host-pipeline call
-        const size_t bytes = 2 * align_up(sizeof(MpbTables), 256) + 512;
+        const size_t bytes = 2 * align_up(sizeof(MpbTables), 256) + 1024;
         HIPCHK(hipMalloc(&c->ws_small, bytes));
         // on the context's stream, not the null stream: the stream is non-blocking, so a null-stream
         // memset is unordered with the kernels below and can land after they have written the tables
@@ -415,6 +445,8 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
         c->ws.ovf_total = (long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 320);
         c->ws.wide_count = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256) + 384);
         c->ws.alg_cells = (unsigned long long *)(p + 2 * align_up(sizeof(MpbTables), 256) + 448);
+        c->ws.nar_count = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256) + 512);
+        c->ws.nar_sample = (int32_t *)(p + 2 * align_up(sizeof(MpbTables), 256) + 576);      // MPB_NAR_BUCKETS ints
         c->ws.lut = c->d_lut;
     }
     if (n <= c->ws_cap) return MPB_OK;
@@ -639,6 +671,164 @@ static int filter_device_tail(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t
     return MPB_OK;
 }
 
+// ---- the natural-order narrow pass (round 5; mpb_internal.h, include/moira_pb.h: mpb_path_info) ---------------------------
+
+static int ensure_narrow_workspace(mpb_ctx *c, int64_t n)
+{
+    if (n <= c->ws_nar_cap) return MPB_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->ws_nar) { HIPCHK(hipFree(c->ws_nar)); c->ws_nar = nullptr; c->ws_nar_cap = 0; }
+    const int64_t cap = n + n / 8 + 1024;
+    const int64_t b_list = align_up((cap + 64) * 4, 256), b_waves = align_up((int64_t)MPB_NAR_MAX_WAVES * 4, 256);
+    HIPCHK(hipMalloc(&c->ws_nar, (size_t)(2 * b_list + 2 * b_waves)));
+    char *p = (char *)c->ws_nar;
+    c->ws.nar_seg = (int32_t *)p; p += b_list;
+    c->ws.nar_list = (int32_t *)p; p += b_list;
+    c->ws.nar_wave_count = (int32_t *)p; p += b_waves;
+    c->ws.nar_wave_off = (int32_t *)p;
+    c->ws_nar_cap = cap;
+    return MPB_OK;
+}
+
+// the dense sub-batch of the reads a narrow pass handed back: m rows of `stride` bytes + their results
+struct FallbackBlock { uint8_t *q; double *ee; int32_t *ns; uint8_t *pass; };
+static int ensure_fallback_block(mpb_ctx *c, int64_t m, int64_t stride, FallbackBlock *out)
+{
+    if (m > c->fb_cap || stride > c->fb_stride) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->fb_block) { HIPCHK(hipFree(c->fb_block)); c->fb_block = nullptr; c->fb_cap = 0; }
+        const int64_t cap = m + m / 4 + 4096;
+        const int64_t st = stride > c->fb_stride ? stride : c->fb_stride;
+        HIPCHK(hipMalloc(&c->fb_block, (size_t)(align_up(cap * st, 256) + align_up(cap * 8, 256) + align_up(cap * 4, 256) + align_up(cap, 256))));
+        c->fb_cap = cap;
+        c->fb_stride = st;
+    }
+    char *p = (char *)c->fb_block;
+    out->q = (uint8_t *)p; p += align_up(c->fb_cap * c->fb_stride, 256);
+    out->ee = (double *)p; p += align_up(c->fb_cap * 8, 256);
+    out->ns = (int32_t *)p; p += align_up(c->fb_cap * 4, 256);
+    out->pass = (uint8_t *)p;
+    return MPB_OK;
+}
+
+// The choice, from the sample's histogram of predicted rows.  Costs in vector instructions per base and read -- what bounds each
+// pass in the regime where the choice is close: the narrow pass issues 3 R per base whatever the read needs (address, 1 - p,
+// 3 R - 2 cell operations); the sorted pipeline costs about 8 for classification + sort (bound by its second read of the matrix)
+// plus 3 per row of the read's class; a read the narrow pass hands back pays the sorted pipeline on top, plus its gather and
+// scatter.  The pass must also finish at least 90 % of the sample: below that the sub-batch's own launches and the doubled
+// traffic eat the gain.  Checked against measured times on five quality mixes: profiles/r05_narrow_choice.txt.
+static int narrow_rows_from_sample(const int32_t *hist, int n_sample)
+{
+    if (n_sample <= 0) return 0;
+    auto sorted_cost = [](int r) { return 8.0 + 3.0 * (r < 2 ? 2 : r == MPB_NAR_BUCKETS - 1 ? 24 : r); };
+    const double amb_cost = 8.0 + 3.0 * 6;                   // a read with an ambiguous base: rows unknown here, a middling class
+    double general = hist[0] * amb_cost;
+    for (int r = 1; r < MPB_NAR_BUCKETS; r++) general += hist[r] * sorted_cost(r);
+    int best = 0;
+    double best_cost = 0.9 * general;                        // a narrow pass must promise at least 10 %
+    for (int R = MPB_NAR_MIN_ROWS; R <= MPB_NAR_MAX_ROWS; R++) {
+        int64_t done = 0;
+        for (int r = 1; r <= R; r++) done += hist[r];
+        if ((double)done < 0.90 * n_sample) continue;
+        double cost = (double)n_sample * 3.0 * R + hist[0] * (amb_cost + 2.0);
+        for (int r = R + 1; r < MPB_NAR_BUCKETS; r++) cost += hist[r] * (sorted_cost(r) + 2.0);
+        if (cost < best_cost) { best = R; best_cost = cost; }
+    }
+    return best;
+}
+
+static bool narrow_eligible(const mpb_ctx *c, int64_t n, const int32_t *d_len, int32_t fixed_len, const mpb_filter_params *p)
+{
+    const uint32_t forbidden = MPB_FLAG_FAST_FMA | MPB_FLAG_TEST_UNDERPREDICT | MPB_FLAG_DECISION_ONLY | MPB_FLAG_COUNT_CELLS | MPB_FLAG_NO_NARROW;
+    return c->narrow_ok && !d_len && fixed_len >= 1 && n >= 1 && !(p->flags & forbidden) && c->ws.lut == c->d_lut;
+}
+
+static int filter_device_general(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len,
+                                 int32_t fixed_len, int32_t max_len, const mpb_filter_params *params,
+                                 double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
+{
+    int rc;
+    if ((rc = prepare_batch(c, n, max_len))) return rc;
+    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
+    if (params->flags & MPB_FLAG_COUNT_CELLS) HIPCHK(hipMemsetAsync(c->ws.alg_cells, 0, sizeof(unsigned long long), c->stream));
+    { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
+    return filter_device_tail(c, d_q, n, row_stride, d_len, prm, d_ee, d_ns, d_pass, counts);
+}
+
+// 0: the sorted pipeline; 2..4: the narrow pass with that many rows.  May draw a sample (one small launch + a synchronisation).
+static int narrow_choose(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,
+                         const mpb_filter_params *params, const MpbDevParams &prm, int *rows0)
+{
+    *rows0 = 0;
+    c->last_path.sampled = 0;
+    const int forced = (int)((params->flags >> 8) & 15u);
+    if (forced) { *rows0 = forced < MPB_NAR_MIN_ROWS ? MPB_NAR_MIN_ROWS : forced > MPB_NAR_MAX_ROWS ? MPB_NAR_MAX_ROWS : forced; return MPB_OK; }
+    if (n < MPB_NAR_AUTO_MIN_READS) return MPB_OK;
+    auto &ch = c->nar_choice;
+    const bool same = ch.valid && ch.n == n && ch.stride == row_stride && ch.fixed_len == fixed_len &&
+                      memcmp(&ch.alpha, &params->alpha, sizeof(double)) == 0 && ch.flags == params->flags;
+    if (same && ch.calls < 64) { ch.calls++; *rows0 = ch.rows0; return MPB_OK; }
+    // a sample of <= 0.1 % of the reads: the prepass' row prediction on 256 .. 4096 reads spread over the batch
+    int n_sample = (int)(n / 1024 < 256 ? 256 : n / 1024 > 4096 ? 4096 : n / 1024);
+    { Span t(c, MPB_K_SAMPLE); mpb_launch_sample(d_q, n, row_stride, fixed_len, prm, c->ws, n_sample, c->stream); }
+    HIPCHK(hipMemcpyAsync(c->pin_words + 16, c->ws.nar_sample, MPB_NAR_BUCKETS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->last_path.sampled = 1;
+    for (int k = 0; k < MPB_NAR_BUCKETS; k++) c->last_path.sample_hist[k] = c->pin_words[16 + k];
+    *rows0 = narrow_rows_from_sample(c->pin_words + 16, n_sample);
+    ch.valid = true; ch.n = n; ch.stride = row_stride; ch.fixed_len = fixed_len; ch.alpha = params->alpha; ch.flags = params->flags;
+    ch.rows0 = *rows0; ch.calls = 0;
+    return MPB_OK;
+}
+
+static int filter_device_narrow(mpb_ctx *c, int rows0, const uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,
+                                const mpb_filter_params *params, const MpbDevParams &prm,
+                                double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
+{
+    int rc;
+    hipStream_t s = c->stream;
+    if ((rc = ensure_narrow_workspace(c, n))) return rc;
+    // persistent grid: as many workgroups as fit the CUs' LDS at once
+    const int per_cu = (160 * 1024) / mpb_narrow_lds_bytes();
+    const int grid = (c->n_cu > 0 ? c->n_cu : 256) * (per_cu > 0 ? per_cu : 1);
+    { Span t(c, MPB_K_NARROW);
+      mpb_launch_narrow(rows0, d_q, n, row_stride, fixed_len, prm, c->ws, d_ee, d_ns, d_pass, c->ws.nar_list, grid, s); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->pin_words, c->ws.nar_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int64_t m = c->pin_words[0];
+    c->last_path.narrow_rows = rows0;
+    c->last_path.n_fallback = m;
+    int64_t novf = 0;
+    if (m > 0) {
+        FallbackBlock fb;
+        if ((rc = ensure_fallback_block(c, m, row_stride, &fb))) return rc;
+        { Span t(c, MPB_K_FALLBACK); mpb_launch_gather_rows(d_q, row_stride, c->ws.nar_list, m, fb.q, s); }
+        mpb_filter_params sub = *params;
+        sub.flags = (sub.flags & ~(15u << 8)) | MPB_FLAG_NO_NARROW;
+        mpb_filter_counts sc;
+        // the sub-batch's counts are only fetched (a synchronisation) when the caller wants counts
+        if ((rc = filter_device_general(c, fb.q, m, row_stride, nullptr, fixed_len, fixed_len, &sub, fb.ee, fb.ns, fb.pass, counts ? &sc : nullptr))) return rc;
+        if (counts) novf = sc.n_overflow;
+        { Span t(c, MPB_K_FALLBACK); mpb_launch_scatter_back(c->ws.nar_list, m, fb.ee, fb.ns, fb.pass, d_ee, d_ns, d_pass, s); }
+        HIPCHK(hipGetLastError());
+    }
+    // a pass that hands back far more than its sample promised: look again next time
+    if (!((params->flags >> 8) & 15u) && m > n / 8) c->nar_choice.valid = false;
+    if (counts) {
+        if ((rc = ensure_workspace(c, 1))) return rc;
+        HIPCHK(hipMemsetAsync(c->ws.pass_count, 0, sizeof(unsigned long long), s));
+        mpb_launch_count(d_pass, n, c->ws, s);
+        unsigned long long np = 0;
+        HIPCHK(hipMemcpyAsync(&np, c->ws.pass_count, sizeof(np), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        counts->n_pass = (int64_t)np;
+        counts->n_fail = n - (int64_t)np;
+        counts->n_overflow = novf;
+    }
+    return MPB_OK;
+}
+
 int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride,
                       const int32_t *d_len, int32_t fixed_len, const mpb_filter_params *params,
                       double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
@@ -651,11 +841,23 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     if (counts) { counts->n_reads = n; counts->n_pass = 0; counts->n_fail = 0; counts->n_overflow = 0; }
     if (n == 0) return MPB_OK;
     c->classified.valid = false;                     // the workspace now describes THIS batch
-    if ((rc = prepare_batch(c, n, max_len))) return rc;
-    const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
-    if (params->flags & MPB_FLAG_COUNT_CELLS) HIPCHK(hipMemsetAsync(c->ws.alg_cells, 0, sizeof(unsigned long long), c->stream));
-    { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
-    return filter_device_tail(c, d_q, n, row_stride, d_len, prm, d_ee, d_ns, d_pass, counts);
+    c->last_path = mpb_path_info{};
+    if ((rc = ensure_workspace(c, 1))) return rc;    // the small block (tables, counters) exists from here on
+    if (narrow_eligible(c, n, d_len, fixed_len, params)) {
+        const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
+        int rows0 = 0;
+        if ((rc = narrow_choose(c, d_q, n, row_stride, fixed_len, params, prm, &rows0))) return rc;
+        if (rows0) return filter_device_narrow(c, rows0, d_q, n, row_stride, fixed_len, params, prm, d_ee, d_ns, d_pass, counts);
+    }
+    return filter_device_general(c, d_q, n, row_stride, d_len, fixed_len, max_len, params, d_ee, d_ns, d_pass, counts);
+}
+
+int mpb_last_path(mpb_ctx *c, mpb_path_info *out)
+{
+    CTXCHK(c);
+    if (!out) return fail(MPB_E_INVALID, "NULL output");
+    *out = c->last_path;
+    return MPB_OK;
 }
 
 int mpb_last_algorithmic_cells(mpb_ctx *c, int64_t *cells)
@@ -1621,14 +1823,22 @@ int mpb_filter_host_multi(mpb_ctx *const *ctxs, int32_t n_ctx, const uint8_t *q,
 int mpb_synth_fill_device(mpb_ctx *c, uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,
                           int32_t min_len, int32_t max_len, int32_t *d_len, uint64_t seed, int64_t first_read)
 {
+    return mpb_synth_fill_device_profile(c, d_q, n, row_stride, fixed_len, min_len, max_len, d_len, seed, first_read, 0);
+}
+
+int mpb_synth_fill_device_profile(mpb_ctx *c, uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,
+                                  int32_t min_len, int32_t max_len, int32_t *d_len, uint64_t seed, int64_t first_read,
+                                  int32_t profile)
+{
     CTXCHK(c);
+    if (profile != 0 && profile != 1) return fail(MPB_E_INVALID, "unknown synthetic profile %d", profile);
     if (n < 0 || row_stride <= 0 || row_stride % 16 != 0) return fail(MPB_E_INVALID, "bad matrix shape");
     if (fixed_len > 0) { if (fixed_len > row_stride) return fail(MPB_E_INVALID, "fixed_len exceeds row_stride"); }
     else if (min_len < 1 || max_len < min_len || max_len > row_stride || !d_len)
         return fail(MPB_E_INVALID, "ragged fill needs 1 <= min_len <= max_len <= row_stride and d_len");
     if (n == 0) return MPB_OK;
     if (n * (row_stride / 16) / 256 > 0x7fffffffll) return fail(MPB_E_INVALID, "fill too large for one launch; split it");
-    mpb_launch_synth(d_q, n, row_stride, fixed_len, min_len, max_len, d_len, seed, first_read, c->stream);
+    mpb_launch_synth(d_q, n, row_stride, fixed_len, min_len, max_len, d_len, seed, first_read, c->stream, profile);
     HIPCHK(hipGetLastError());
     return MPB_OK;
 }

@@ -114,7 +114,25 @@ struct MpbWorkspace {
     unsigned long long *pass_count;  // [1]
     unsigned long long *alg_cells;   // [1] MPB_FLAG_COUNT_CELLS: algorithmic DP cells of the last mpb_filter_device call
     const double2 *lut;    // [256] {1-p, p'} on device
+    int32_t  *nar_count;   // [1] reads the natural-order narrow pass (k_narrow) could not finish
+    int32_t  *nar_seg;     // [n + 64] ... as the waves of k_narrow listed them, a segment per wave
+    int32_t  *nar_list;    // [n + 64] ... compacted: the dense list the sub-batch is gathered by
+    int32_t  *nar_wave_count, *nar_wave_off;   // [MPB_NAR_MAX_WAVES] entries of each wave's segment / where it goes in nar_list
+    int32_t  *nar_sample;  // [MPB_NAR_BUCKETS] histogram of the batch sample that picks the pass (k_sample)
 };
+
+// ---- natural-order narrow pass (round 5) -------------------------------------------------------
+// A batch of GOOD reads (nearly every read needs <= R0 rows of the DP table, R0 = 2..4) is bound by HBM, not by FP64 issue, and
+// the two-pass pipeline (classify, sort, DP in class order) then moves 2.7x the algorithmic bytes.  k_narrow<R0> instead walks
+// the matrix ONCE, in natural order, one read per lane with R0 rows in registers: rows 0..R0-1 of the table are exact whatever
+// the read turns out to need, so every read whose CDF crosses inside them is finished bit for bit; the others -- and every read
+// with an ambiguous base, whose table entry is a NaN in this pass -- go on a list, are gathered into a dense sub-batch and run
+// through the ordinary pipeline.  The choice is made per batch from a sample of <= 0.1 % of the reads.
+#define MPB_NAR_MIN_ROWS 2
+#define MPB_NAR_MAX_ROWS 4
+#define MPB_NAR_BUCKETS 16                // k_sample: [0] reads with an ambiguous base, [r] reads predicted to need r rows (r = 1..14), [15] more
+#define MPB_NAR_MAX_WAVES 8192            // waves of the persistent k_narrow grid (256 CUs x 3 workgroups x 4 waves = 3072 on MI355X)
+#define MPB_NAR_AUTO_MIN_READS (1 << 18)  // below this a batch always takes the ordinary pipeline (unless the path is forced)
 
 #define MPB_LUT_BYTES   (256 * 16)
 #define MPB_LAMBDA_MAX_STRIDE (1 << 24)     // k_lambda addresses the 64 rows of a wave with 32-bit byte offsets
@@ -155,8 +173,20 @@ void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_
 void mpb_launch_decode(const uint8_t *seq, const uint8_t *qual, int64_t n, int64_t stride, const int32_t *len,
                        int32_t fixed_len, int32_t offset, uint8_t *out, int32_t *err, hipStream_t s);
 void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hipStream_t s);
+// the natural-order narrow pass (fixed-length batches, the context's default table): rows0 in MPB_NAR_MIN_ROWS..MPB_NAR_MAX_ROWS.
+// Finished reads get ee / ns (= 0) / pass; the others end up in `list` (dense, in wave order; their number in ws.nar_count).
+void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
+                       const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks, hipStream_t s);
+int mpb_narrow_lds_bytes();               // static LDS of one k_narrow workgroup (the host sizes the persistent grid from it)
+// predicted row budgets of `n_sample` reads spread over the batch -> ws.nar_sample (zeroed here)
+void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
+                       const MpbWorkspace &ws, int n_sample, hipStream_t s);
+// rows list[0..m) of q -> the dense matrix q2 (m rows of `stride` bytes), and results back: ee[list[k]] = ee2[k] ...
+void mpb_launch_gather_rows(const uint8_t *q, int64_t stride, const int32_t *list, int64_t m, uint8_t *q2, hipStream_t s);
+void mpb_launch_scatter_back(const int32_t *list, int64_t m, const double *ee2, const int32_t *ns2, const uint8_t *pass2,
+                             double *ee, int32_t *ns, uint8_t *pass, hipStream_t s);
 void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, int32_t min_len,
                       int32_t max_len, int32_t *len, uint64_t seed, int64_t first_read,
-                      hipStream_t s);
+                      hipStream_t s, int32_t profile = 0);
 
 #endif

@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_encode_ascii(const uint8_t *__restrict_
 __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t n, int64_t stride,
                                                int32_t fixed_len, int32_t min_len, int32_t max_len,
                                                int32_t *__restrict__ len, uint64_t seed,
-                                               int64_t first_read)
+                                               int64_t first_read, int32_t profile)
 {
     const int64_t cpr = stride / 16;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1527,11 +1527,394 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t 
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         const int pos = c * 16 + t;
-        const uint32_t b = pos < li ? (uint32_t)mpb_synth_byte(h, (uint32_t)pos, (uint32_t)li) : 0u;
+        const uint32_t b = pos < li ? (uint32_t)mpb_synth_byte_profile(h, (uint32_t)pos, (uint32_t)li, profile) : 0u;
         w[t >> 2] |= b << (8 * (t & 3));
     }
     *reinterpret_cast<uint4 *>(q + i * stride + (int64_t)c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     if (len && c == 0) len[i] = li;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_narrow<R>: the natural-order pass for batches of GOOD reads (round 5; mpb_internal.h "natural-order narrow pass").
+//
+// Where it applies the step is bound by HBM, so the matrix is read exactly once, in the order it lies in memory, and nothing
+// else of size n is read or written except the results.  One read per lane, R rows of the running vector in registers
+// (R = 2..4): rows 0..R-1 of the reference's table depend on no later row, so they are exact whatever the read needs, and a read
+// whose CDF crosses 1 - alpha inside them is finished here with the reference's own three-rounding cell, sequential CDF and
+// interpolation (ref: moira/bernoullimodule.c:152-166,219-251).  Every other read -- more rows needed, or an ambiguous base,
+// whose table entry in THIS pass is a NaN that poisons the read's vector and so keeps its CDF from ever crossing: no
+// instruction per base is spent on looking for them -- is appended to `list` for the ordinary pipeline.
+//
+// A lane per row read straight from HBM is 64 rows per load instruction and every cache line revisited by eight instructions.
+// So a wave moves its 64 rows through LDS in 64-byte panels by LDS-DMA (global_load_lds_dwordx4, no register staging): one
+// instruction covers 64 consecutive bytes of each of 16 rows (the prepass' shape) and lands as [4 chunk columns][16 rows] x 16 B,
+// so the 16 lanes an LDS b128 read groups together hit 16 different bank quads; a private ring of MPB_NAR_DEPTH panels per
+// wave keeps DEPTH - 1 panels (4 KiB each) in flight across row-block boundaries -- the grid is persistent, a wave walks row
+// blocks gw, gw + W, ... as one continuous stream of panels.  The table is {p} alone, 8 bytes (ds_read_b64: half the LDS cycles
+// of the {1-p, p'} pair), and 1 - p is recomputed by the same IEEE subtraction the host used; p' == p bit for bit for every
+// encodable score (tests/test_oracle_golden.py::test_lut_pins, re-checked by mpb_create before this pass is ever chosen).
+// Per base: 1 address op + 1 subtraction + 3R - 2 cell operations = 6 / 9 / 12 vector instructions for R = 2 / 3 / 4.
+// ------------------------------------------------------------------------------------------
+#ifndef MPB_NAR_DEPTH
+#define MPB_NAR_DEPTH 3
+#endif
+#define MPB_NAR_PANEL 4096                  // 64 rows x 64 bytes
+
+// One LDS-DMA instruction: 16 bytes per lane from `base + voff` (wave-uniform 64-bit base, per-lane 32-bit offset) to LDS at
+// lds + 16 * lane.  Written as inline assembly on purpose: the compiler orders every LDS read behind every LDS-DMA that it
+// cannot prove independent -- a wave's ring slots are one array indexed at run time, so it drains the whole prefetch stream
+// (s_waitcnt vmcnt(0)) before each panel is read.  Here the waits are counted by hand instead (nar_wait): every panel is four
+// of these, requests complete in issue order, and anything else the wave has in flight (the results' stores, the list's
+// atomic) only makes a counted wait stricter.  M0 = LDS address; one wait state between the M0 write and the DMA.
+__device__ __forceinline__ void nar_dma16(const uint8_t *base, uint32_t voff, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds), "v"(voff), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void nar_wait()                  // until at most N vector-memory operations are outstanding
+{
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_offset(const void *p)      // a __shared__ object's address inside the workgroup's LDS
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+template <int R>
+__device__ __forceinline__ void nar_step(double (&v)[R], const double p)
+{
+    const double a = 1.0 - p;                 // the table's 1 - p
+#pragma unroll
+    for (int r = R - 1; r >= 1; r--) v[r] = cell<false>(a, v[r], p, v[r - 1]);
+    v[0] = a * v[0];
+}
+
+template <int R>
+__device__ __forceinline__ void nar_dword(double (&v)[R], const double *tab, uint32_t w)
+{
+#pragma unroll
+    for (int t = 0; t < 4; t++) nar_step<R>(v, tab[(w >> (8 * t)) & 0xffu]);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, int64_t n, int64_t stride, int32_t li,
+                                                MpbDevParams prm, const double2 *__restrict__ lut_g,
+                                                double *__restrict__ ee, int32_t *__restrict__ ns, uint8_t *__restrict__ pass,
+                                                int32_t *__restrict__ seg, int32_t *__restrict__ wave_count)
+{
+    // seg / wave_count: the reads this pass cannot finish.  A wave appends them to a segment of its own -- wave gw owns the
+    // slots of the row blocks it walks, which start at 64 * (blocks owned by the waves before it) -- and leaves its count in
+    // wave_count[gw]: no atomic (a returned atomic would drain the prefetch stream: vmcnt counts everything), and a list whose
+    // order does not depend on timing.  k_nar_offsets / k_nar_compact then make the dense list.
+    constexpr int D = MPB_NAR_DEPTH;
+    static_assert(D >= 2 && D <= 4, "ring depth");
+    __shared__ double s_p[256];
+    // one array per ring slot: a read of slot k is then provably independent of a DMA into slot k + 1 (the compiler orders
+    // LDS reads behind LDS-DMA by what may alias)
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring0[4][MPB_NAR_PANEL];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring1[4][MPB_NAR_PANEL];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring2[D > 2 ? 4 : 1][D > 2 ? MPB_NAR_PANEL : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring3[D > 3 ? 4 : 1][D > 3 ? MPB_NAR_PANEL : 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    s_p[tid] = (tid == 0 || tid == 255) ? __builtin_nan("") : lut_g[tid].y;
+    __syncthreads();                                          // the only block barrier
+    const int64_t nblk = (n + 63) >> 6;                       // row blocks of 64 reads
+    const int ncq = (li + 63) >> 6;                           // 64-byte panels per row block (li >= 1)
+    const int64_t gw = (int64_t)blockIdx.x * 4 + w, W = (int64_t)gridDim.x * 4;
+    if (gw >= nblk) {
+        if (lane == 0) wave_count[gw] = 0;
+        return;
+    }
+    const int64_t total = ((nblk - gw + W - 1) / W) * ncq;    // panels this wave walks
+    int32_t *const my_seg = seg + 64 * (gw * (nblk / W) + min(gw, nblk % W));
+    int nlist = 0;                                            // wave-uniform
+    const int r16 = lane & 15, cl = lane >> 4;
+    const int row_chunks = __builtin_amdgcn_readfirstlane((int)(stride >> 4));
+    uint32_t voff[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) voff[rg] = (uint32_t)((rg * 16 + r16) * (int)stride + cl * 16);
+    uint8_t *const ring[4] = {s_ring0[w], s_ring1[w], s_ring2[D > 2 ? w : 0], s_ring3[D > 3 ? w : 0]};
+    const uint32_t ring_lds[4] = {lds_offset(s_ring0[w]), lds_offset(s_ring1[w]), lds_offset(s_ring2[D > 2 ? w : 0]),
+                                  lds_offset(s_ring3[D > 3 ? w : 0])};
+
+    // one panel = four DMA instructions, always four (the waits below count them)
+    auto issue = [&](const int64_t b, const int c, const uint32_t slot) {
+        const uint8_t *base = q + b * 64 * stride + c * 64;                        // wave-uniform
+        const bool edge = (b * 64 + 64 > n) || (c * 4 + 4 > row_chunks);          // wave-uniform
+        if (!edge) {
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) nar_dma16(base, voff[rg], slot + rg * 1024);
+        } else {
+            // last row block of the batch / last chunk column of a row whose stride is not a multiple of 64: rows and chunks
+            // clamped into the matrix (what they deliver is never looked at)
+            const int last_row = (int)(n - 1 - b * 64);                            // >= 0: the block holds at least one read
+            const int ch = min(cl, row_chunks - 1 - c * 4);                        // >= 0: the panel starts inside the row
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++)
+                nar_dma16(base, (uint32_t)(min(rg * 16 + r16, last_row) * (int)stride + ch * 16), slot + rg * 1024);
+        }
+    };
+
+    int64_t pf_b = gw, cur_b = gw;            // row block of the next panel to request / being computed
+    int pf_c = 0, cur_c = 0;
+    int64_t pf = 0;                           // panels requested so far
+    auto request = [&](const uint32_t slot) {
+        if (pf < total) {
+            issue(pf_b, pf_c, slot);
+            pf++;
+            if (++pf_c == ncq) { pf_c = 0; pf_b += W; }
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < D - 1; k++) request(ring_lds[k]);
+
+    double v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = r == 0 ? 1.0 : 0.0;
+    const uint32_t tl = (uint32_t)((lane >> 4) * 1024 + (lane & 15) * 16);      // this lane's row inside a panel
+    const double thr = prm.thr;
+
+    auto step = [&](const int S, const int64_t s) {
+        (void)s;
+        request(ring_lds[(S + D - 1) % D]);                 // the slot the step before has just finished with
+        // the panel of this step has landed when at most the requests made after it are still out
+        const int64_t younger = pf - (s + 1);               // 0 .. D-1 panels (wave-uniform)
+        if (younger >= 3) nar_wait<12>();
+        else if (younger == 2) nar_wait<8>();
+        else if (younger == 1) nar_wait<4>();
+        else nar_wait<0>();
+        const uint8_t *mine = ring[S] + tl;
+        const int nbases = min(64, li - cur_c * 64);        // wave-uniform
+        if (nbases == 64) {
+            // all four chunks of the panel at once, then the table one dword (four bases) ahead of the arithmetic
+            uint32_t wd[16];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
+                wd[4 * k] = x.x; wd[4 * k + 1] = x.y; wd[4 * k + 2] = x.z; wd[4 * k + 3] = x.w;
+            }
+            double pc[4], pn[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) pc[t] = s_p[(wd[0] >> (8 * t)) & 0xffu];
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+                if (d < 15) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) pn[t] = s_p[(wd[d + 1] >> (8 * t)) & 0xffu];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; t++) nar_step<R>(v, pc[t]);
+#pragma unroll
+                for (int t = 0; t < 4; t++) pc[t] = pn[t];
+            }
+        } else {
+            for (int k = 0; k * 16 < nbases; k++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
+                uint32_t w0 = x.x, w1 = x.y, w2 = x.z, w3 = x.w;
+                const int nb = min(16, nbases - k * 16);
+                int d = 0;
+#pragma unroll 1
+                for (; d * 4 + 4 <= nb; d++) {
+                    nar_dword<R>(v, s_p, w0);
+                    w0 = w1; w1 = w2; w2 = w3;
+                }
+                for (int t = d * 4; t < nb; t++) {          // a length that is not a multiple of 4: its last 1..3 bases
+                    nar_step<R>(v, s_p[w0 & 0xffu]);
+                    w0 >>= 8;
+                }
+            }
+        }
+        if (++cur_c == ncq) {
+            // ---- a row block is done: sequential CDF, interpolation, predicate (as the tile classes' epilogue) ----
+            const int64_t i = cur_b * 64 + lane;
+            const bool valid = i < n;
+            double acc = 0.0, lo = 0.0, hi = 0.0;
+            int js = -1;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const double na = acc + v[r];
+                const bool hit = (js < 0) && (na > thr);
+                lo = hit ? acc : lo;
+                hi = hit ? na : hi;
+                js = hit ? r : js;
+                acc = na;
+            }
+            const bool done = valid && js >= 0;
+            if (done) {
+                double e = (double)(js - 1) + ((thr - lo) / (hi - lo));     // ref: bernoullimodule.c:170-178
+                if (e < 0) e = 0;
+                if (prm.ambig_mode == 0) e = e + 0.0;                        // moira.py:827-828 with Ns == 0
+                const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
+                if (prm.flags & 1u) e = floor(e);
+                ee[i] = e;
+                ns[i] = 0;                                                   // a read with an ambiguous base never gets here
+                pass[i] = (uint8_t)(e <= limit ? 1 : 0);
+            }
+            const unsigned long long todo = __ballot(valid && js < 0);
+            if (todo) {
+                if (valid && js < 0) my_seg[nlist + __popcll(todo & ((1ull << lane) - 1ull))] = (int32_t)i;
+                nlist += __popcll(todo);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) v[r] = r == 0 ? 1.0 : 0.0;
+            cur_c = 0;
+            cur_b += W;
+        }
+    };
+    for (int64_t s = 0; s < total; s += D) {
+        step(0, s);
+        if (D > 1 && s + 1 < total) step(1 % D, s + 1);
+        if (D > 2 && s + 2 < total) step(2 % D, s + 2);
+        if (D > 3 && s + 3 < total) step(3 % D, s + 3);
+    }
+    if (lane == 0) wave_count[gw] = nlist;
+}
+
+// exclusive prefix of the waves' list counts (one block); total -> *count
+__global__ __launch_bounds__(1024) void k_nar_offsets(const int32_t *__restrict__ wave_count, int nwaves,
+                                                      int32_t *__restrict__ wave_off, int32_t *__restrict__ count)
+{
+    __shared__ int s_sum[1024];
+    const int tid = threadIdx.x;
+    const int per = (nwaves + 1023) / 1024;
+    const int g0 = tid * per, g1 = min(nwaves, g0 + per);
+    int sum = 0;
+    for (int g = g0; g < g1; g++) sum += wave_count[g];
+    s_sum[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int x = tid >= off ? s_sum[tid - off] : 0;
+        __syncthreads();
+        s_sum[tid] += x;
+        __syncthreads();
+    }
+    int run = s_sum[tid] - sum;
+    for (int g = g0; g < g1; g++) { wave_off[g] = run; run += wave_count[g]; }
+    if (tid == 1023) *count = s_sum[1023];
+}
+
+// segment of wave g -> list[wave_off[g] ...): one block per wave
+__global__ __launch_bounds__(256) void k_nar_compact(const int32_t *__restrict__ seg, const int32_t *__restrict__ wave_count,
+                                                     const int32_t *__restrict__ wave_off, int64_t nblk, int nwaves,
+                                                     int32_t *__restrict__ list)
+{
+    const int64_t g = blockIdx.x;
+    const int cnt = wave_count[g];
+    const int32_t *src = seg + 64 * (g * (nblk / nwaves) + min(g, nblk % nwaves));
+    int32_t *dst = list + wave_off[g];
+    for (int k = threadIdx.x; k < cnt; k += 256) dst[k] = src[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sample: which pass does this batch take?  `n_sample` reads spread evenly (with a hashed offset inside each stride) over
+// the batch, one wave per read.  Whether a read's CDF crosses 1 - alpha within its first 2, 3 or 4 rows is what the choice
+// hangs on, and there the prepass' Cornish-Fisher quantile is at its worst (a clean 300-base read has 0.08 expected errors:
+// it predicts 3 rows where 2 do).  So the first rows are computed, not predicted: with r = p / (1 - p) the probability of
+// exactly k errors is P0 * e_k(r_1 .. r_L), P0 = prod (1 - p_i), e_k the elementary symmetric polynomials, which come from
+// the power sums T1 = sum r, T2 = sum r^2, T3 = sum r^3 by Newton's identities -- four fp32 sums per read (log P0, T1, T2, T3).
+// A read that needs more than 4 rows is binned by the prepass' prediction (it only feeds the cost estimate of the sorted
+// pipeline).  fp32 throughout: the sample steers speed, never a result.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, int64_t n, int64_t stride, int32_t li,
+                                                MpbDevParams prm, int n_sample, int32_t *__restrict__ hist)
+{
+    __shared__ float2 s_tab[256];
+    __shared__ float4 s_pow[256];                 // {log(1 - p), r, r^2, r^3}; ambiguous bases: zeros
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    {
+        const bool amb = tid == 0 || tid == 255;
+        float p = __builtin_amdgcn_exp2f(-0.33219281f * (float)tid);      // 10^(-q/10)
+        p = amb ? 0.0f : p;
+        s_tab[tid] = make_float2(p, tid == 0 ? MPB_MARK_UPPER : tid == 255 ? MPB_MARK_LOWER : p * (1.0f - p));
+        const float r = p / (1.0f - p);
+        s_pow[tid] = make_float4(log1pf(-p), r, r * r, r * r * r);
+    }
+    __syncthreads();
+    const int k = blockIdx.x * 4 + w;
+    if (k >= n_sample) return;
+    const int64_t step = n / n_sample;                                     // >= 1 (the host sees to it)
+    const int64_t i = min(n - 1, (int64_t)k * step + (int64_t)(mpb_mix64((uint64_t)k) % (uint64_t)step));
+    float mu = 0.f, var = 0.f, k3 = 0.f;
+    float lp0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int ambi = 0;
+    for (int c0 = 0; c0 * 16 < li; c0 += 64 * 15) {                        // panels of 15 chunks per lane: the markers peel exactly
+        f32x2 a01 = {0.f, 0.f};
+        float s3 = 0.f;
+        for (int c = c0 + lane; c * 16 < li && c < c0 + 64 * 15; c += 64) {
+            uint4 y = *reinterpret_cast<const uint4 *>(q + i * stride + (int64_t)c * 16);
+            const int nv = li - c * 16;
+            y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
+            y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
+            pre_chunk(s_tab, y, a01, s3);
+            const uint32_t ww[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float4 e = s_pow[(ww[d] >> (8 * t)) & 0xffu];    // the fill byte (Q254) contributes 4e-26: nothing
+                    lp0 += e.x; t1 += e.y; t2 += e.z; t3 += e.w;
+                }
+        }
+        const float n255 = floorf(a01.y * (1.0f / MPB_MARK_LOWER));
+        const float rem = a01.y - MPB_MARK_LOWER * n255;
+        const float nzero = floorf(rem * (1.0f / MPB_MARK_UPPER));
+        const float pvar = rem - MPB_MARK_UPPER * nzero;
+        mu += a01.x; var += pvar; k3 += pvar - 2.0f * s3;
+        ambi += (int)nzero + (int)n255;
+    }
+#pragma unroll
+    for (int off = 1; off <= 32; off <<= 1) {
+        mu += __shfl_xor(mu, off); var += __shfl_xor(var, off);
+        k3 += __shfl_xor(k3, off); ambi += __shfl_xor(ambi, off);
+        lp0 += __shfl_xor(lp0, off); t1 += __shfl_xor(t1, off);
+        t2 += __shfl_xor(t2, off); t3 += __shfl_xor(t3, off);
+    }
+    if (lane == 0) {
+        const float vv = fmaxf(var, 1e-12f);
+        const float x = mu + prm.z * sqrtf(vv) + (k3 / vv) * prm.zq;      // as class_read
+        int rows = (int)floorf(fminf(x, 1e9f) + 0.5f) + 1;
+        rows = max(rows, 5);                                               // rows 1..4 are decided below
+        // the first four rows of the CDF from the power sums
+        const float thr = (float)prm.thr;
+        const float p0 = __expf(lp0);
+        const float e1 = t1, e2 = 0.5f * (t1 * t1 - t2), e3 = (t1 * t1 * t1 - 3.0f * t1 * t2 + 2.0f * t3) * (1.0f / 6.0f);
+        float cdf = p0;
+        if (cdf > thr) rows = 1;
+        else if ((cdf += p0 * e1) > thr) rows = 2;
+        else if ((cdf += p0 * e2) > thr) rows = 3;
+        else if ((cdf += p0 * e3) > thr) rows = 4;
+        rows = max(min(rows, li - ambi + 1), 1);
+        atomicAdd(hist + (ambi > 0 ? 0 : min(rows, MPB_NAR_BUCKETS - 1)), 1);
+    }
+}
+
+// the listed rows as a dense matrix: thread per 16-byte chunk
+__global__ __launch_bounds__(256) void k_gather_rows(const uint8_t *__restrict__ q, int64_t stride,
+                                                     const int32_t *__restrict__ list, int64_t m, uint8_t *__restrict__ q2)
+{
+    const int64_t cpr = stride >> 4;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= m * cpr) return;
+    const int64_t k = g / cpr;
+    const int64_t c = g - k * cpr;
+    const int64_t i = list[k];
+    *reinterpret_cast<uint4 *>(q2 + k * stride + c * 16) = *reinterpret_cast<const uint4 *>(q + i * stride + c * 16);
+}
+
+__global__ __launch_bounds__(256) void k_scatter_back(const int32_t *__restrict__ list, int64_t m,
+                                                      const double *__restrict__ ee2, const int32_t *__restrict__ ns2,
+                                                      const uint8_t *__restrict__ pass2, double *__restrict__ ee,
+                                                      int32_t *__restrict__ ns, uint8_t *__restrict__ pass)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    const int64_t i = list[k];
+    ee[i] = ee2[k];
+    ns[i] = ns2[k];
+    pass[i] = pass2[k];
 }
 
 }  // namespace
@@ -1719,12 +2102,12 @@ void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hi
 
 void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, int32_t min_len,
                       int32_t max_len, int32_t *len, uint64_t seed, int64_t first_read,
-                      hipStream_t s)
+                      hipStream_t s, int32_t profile)
 {
     const int64_t chunks = n * (stride / 16);
     const int64_t blocks = (chunks + 255) / 256;
     hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len,
-                       min_len, max_len, len, seed, first_read);
+                       min_len, max_len, len, seed, first_read, profile);
 }
 
 // Small batches: one launch, one read per wave (k_small).  Overflow is reported through pass == 2.
@@ -1742,4 +2125,47 @@ void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t
         hipLaunchKernelGGL((k_small<true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage, done, token);
     else
         hipLaunchKernelGGL((k_small<false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage, done, token);
+}
+
+// ---- natural-order narrow pass ----------------------------------------------------------------------------------------
+int mpb_narrow_lds_bytes() { return 256 * 8 + MPB_NAR_DEPTH * 4 * MPB_NAR_PANEL; }
+
+void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
+                       const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks, hipStream_t s)
+{
+    const int64_t nblk = (n + 63) / 64;
+    int64_t blocks = (nblk + 3) / 4;
+    if (blocks > grid_blocks) blocks = grid_blocks;         // persistent: a wave walks row blocks gw, gw + W, ...
+    if (blocks > MPB_NAR_MAX_WAVES / 4) blocks = MPB_NAR_MAX_WAVES / 4;
+    if (blocks < 1) blocks = 1;
+    const int nwaves = (int)blocks * 4;
+#define MPB_NAR_LAUNCH(RR) \
+    hipLaunchKernelGGL((k_narrow<RR>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
+    switch (rows0) {
+    case 2: MPB_NAR_LAUNCH(2); break;
+    case 3: MPB_NAR_LAUNCH(3); break;
+    default: MPB_NAR_LAUNCH(4); break;
+    }
+#undef MPB_NAR_LAUNCH
+    hipLaunchKernelGGL(k_nar_offsets, dim3(1), dim3(1024), 0, s, ws.nar_wave_count, nwaves, ws.nar_wave_off, ws.nar_count);
+    hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, ws.nar_wave_off, nblk, nwaves, list);
+}
+
+void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
+                       const MpbWorkspace &ws, int n_sample, hipStream_t s)
+{
+    (void)hipMemsetAsync(ws.nar_sample, 0, MPB_NAR_BUCKETS * sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)((n_sample + 3) / 4)), dim3(256), 0, s, q, n, stride, fixed_len, prm, n_sample, ws.nar_sample);
+}
+
+void mpb_launch_gather_rows(const uint8_t *q, int64_t stride, const int32_t *list, int64_t m, uint8_t *q2, hipStream_t s)
+{
+    const int64_t chunks = m * (stride / 16);
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, q, stride, list, m, q2);
+}
+
+void mpb_launch_scatter_back(const int32_t *list, int64_t m, const double *ee2, const int32_t *ns2, const uint8_t *pass2,
+                             double *ee, int32_t *ns, uint8_t *pass, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scatter_back, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, list, m, ee2, ns2, pass2, ee, ns, pass);
 }

@@ -56,6 +56,9 @@ def lib():
         L.pbo_synth_fill.restype = None
         L.pbo_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_void_p, C.c_uint64, C.c_int64]
+        L.pbo_synth_fill_profile.restype = None
+        L.pbo_synth_fill_profile.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_void_p, C.c_uint64, C.c_int64, C.c_int32]
         L.pbo_pack_read.restype = C.c_int
         L.pbo_pack_read.argtypes = [C.c_char_p, i32p, C.c_int32, u8p, C.c_int32]
         L.pbo_build_lut.restype = None
@@ -126,12 +129,13 @@ def filter_batch(q, lens=None, fixed_len=None, shape=0, threads=1, **kw):
     return ee, ns, ps, rows
 
 
-def synth_fill(n, stride, fixed_len=0, min_len=0, max_len=0, seed=1, first_read=0):
-    """Host twin of the device synthetic generator -> (q, lens)."""
+def synth_fill(n, stride, fixed_len=0, min_len=0, max_len=0, seed=1, first_read=0, profile=0):
+    """Host twin of the device synthetic generator -> (q, lens).  profile: include/mpb_synth.h (0 = BASELINE's model,
+    1 = the clean run, Q33..Q40)."""
     q = np.empty((n, stride), np.uint8)
     lens = np.empty(n, np.int32)
-    lib().pbo_synth_fill(q.ctypes.data, n, stride, fixed_len, min_len, max_len,
-                         lens.ctypes.data, seed, first_read)
+    lib().pbo_synth_fill_profile(q.ctypes.data, n, stride, fixed_len, min_len, max_len,
+                                 lens.ctypes.data, seed, first_read, profile)
     return q, lens
 
 
