@@ -457,18 +457,18 @@ int mpb_last_algorithmic_cells(mpb_ctx *ctx, int64_t *cells);
 /*
  * Which pass the last mpb_filter_device call took (round 5).
  * A batch of GOOD reads -- nearly every read's CDF crosses 1 - alpha within its first 2..4 rows of the table
- * (ref: moira/bernoullimodule.c:152-166,219-251: rows 0..j depend on no later row) and hardly any read has an ambiguous base --
+ * (ref: moira/bernoullimodule.c:152-166,219-251: rows 0..j depend on no later row) --
  * is bound by HBM, not by FP64 issue, and the sorted pipeline would read the matrix twice.  Such a batch (fixed length,
  * >= 262144 reads, default table, none of the opt-in flags) takes the NARROW PASS instead: the matrix is read once, in natural
- * order, one read per lane with narrow_rows rows in registers; reads it cannot finish (more rows needed, or an ambiguous base)
+ * order, one read per lane with narrow_rows rows in registers; reads it cannot finish (more rows needed, or a lower-case 'n')
  * are gathered into a dense sub-batch and run through the sorted pipeline, and their results are scattered back.  The choice is
  * made from a sample of at most 0.1 % of the reads (the prepass' row prediction on 256..4096 reads spread over the batch), is
  * reused while the batches of a context keep their shape and parameters (re-sampled when a pass had to hand back more reads
  * than the sample promised, and every 64 calls), and steers speed only: every read's result is the reference's bit for bit
  * whichever pass computed it.
  *   narrow_rows  0: the sorted pipeline; 2..4: the narrow pass with that many rows
- *   sampled      1 when this call drew a sample (sample_hist is then its histogram: [0] reads with an ambiguous base, [r] reads
- *                predicted to need r rows (r = 1..14), [15] more), 0 when it reused the previous decision
+ *   sampled      1 when this call drew a sample (sample_hist is then its histogram: [0] reads with a lower-case 'n', [r] reads
+ *                that need r rows (r = 1..14), [15] more), 0 when it reused the previous decision
  *   n_fallback   reads the narrow pass handed to the sorted pipeline
  */
 typedef struct mpb_path_info {

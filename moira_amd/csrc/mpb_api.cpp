@@ -721,7 +721,7 @@ static int narrow_rows_from_sample(const int32_t *hist, int n_sample)
 {
     if (n_sample <= 0) return 0;
     auto sorted_cost = [](int r) { return 8.0 + 3.0 * (r < 2 ? 2 : r == MPB_NAR_BUCKETS - 1 ? 24 : r); };
-    const double amb_cost = 8.0 + 3.0 * 6;                   // a read with an ambiguous base: rows unknown here, a middling class
+    const double amb_cost = 8.0 + 3.0 * 6;                   // a read with a lower-case 'n' (handed back by the pass): a middling class
     double general = hist[0] * amb_cost;
     for (int r = 1; r < MPB_NAR_BUCKETS; r++) general += hist[r] * sorted_cost(r);
     int best = 0;

@@ -126,11 +126,11 @@ struct MpbWorkspace {
 // the two-pass pipeline (classify, sort, DP in class order) then moves 2.7x the algorithmic bytes.  k_narrow<R0> instead walks
 // the matrix ONCE, in natural order, one read per lane with R0 rows in registers: rows 0..R0-1 of the table are exact whatever
 // the read turns out to need, so every read whose CDF crosses inside them is finished bit for bit; the others -- and every read
-// with an ambiguous base, whose table entry is a NaN in this pass -- go on a list, are gathered into a dense sub-batch and run
+// with a lower-case 'n', whose table entry is a NaN in this pass -- go on a list, are gathered into a dense sub-batch and run
 // through the ordinary pipeline.  The choice is made per batch from a sample of <= 0.1 % of the reads.
 #define MPB_NAR_MIN_ROWS 2
 #define MPB_NAR_MAX_ROWS 4
-#define MPB_NAR_BUCKETS 16                // k_sample: [0] reads with an ambiguous base, [r] reads predicted to need r rows (r = 1..14), [15] more
+#define MPB_NAR_BUCKETS 16                // k_sample: [0] reads with a lower-case 'n', [r] reads that need r rows (r = 1..14), [15] more
 #define MPB_NAR_MAX_WAVES 8192            // waves of the persistent k_narrow grid (256 CUs x 3 workgroups x 4 waves = 3072 on MI355X)
 #define MPB_NAR_AUTO_MIN_READS (1 << 18)  // below this a batch always takes the ordinary pipeline (unless the path is forced)
 

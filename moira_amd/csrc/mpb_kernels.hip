@@ -28,6 +28,7 @@
 
 #include "mpb_internal.h"
 #include <cstdlib>
+#include <cstdio>
 #include "../../include/mpb_synth.h"
 
 #pragma clang fp contract(off)
@@ -1541,9 +1542,10 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t 
 // else of size n is read or written except the results.  One read per lane, R rows of the running vector in registers
 // (R = 2..4): rows 0..R-1 of the reference's table depend on no later row, so they are exact whatever the read needs, and a read
 // whose CDF crosses 1 - alpha inside them is finished here with the reference's own three-rounding cell, sequential CDF and
-// interpolation (ref: moira/bernoullimodule.c:152-166,219-251).  Every other read -- more rows needed, or an ambiguous base,
-// whose table entry in THIS pass is a NaN that poisons the read's vector and so keeps its CDF from ever crossing: no
-// instruction per base is spent on looking for them -- is appended to `list` for the ordinary pipeline.
+// interpolation (ref: moira/bernoullimodule.c:152-166,219-251).  'N' bases are the identity step, as everywhere, and are counted
+// four bytes per instruction (v_msad_u8, below).  Every other read -- more rows needed, or a lower-case 'n' (byte 255), whose
+// table entry in THIS pass is a NaN that poisons the read's vector and so keeps its CDF from ever crossing: nothing is spent
+// on looking for them -- is appended to a list for the ordinary pipeline.
 //
 // A lane per row read straight from HBM is 64 rows per load instruction and every cache line revisited by eight instructions.
 // So a wave moves its 64 rows through LDS in 64-byte panels by LDS-DMA (global_load_lds_dwordx4, no register staging): one
@@ -1553,7 +1555,8 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t 
 // blocks gw, gw + W, ... as one continuous stream of panels.  The table is {p} alone, 8 bytes (ds_read_b64: half the LDS cycles
 // of the {1-p, p'} pair), and 1 - p is recomputed by the same IEEE subtraction the host used; p' == p bit for bit for every
 // encodable score (tests/test_oracle_golden.py::test_lut_pins, re-checked by mpb_create before this pass is ever chosen).
-// Per base: 1 address op + 1 subtraction + 3R - 2 cell operations = 6 / 9 / 12 vector instructions for R = 2 / 3 / 4.
+// Per base: 1 address op + 1 subtraction + 3R - 2 cell operations + half an instruction of 'N' counting = 6.5 / 9.5 / 12.5
+// vector instructions for R = 2 / 3 / 4.
 // ------------------------------------------------------------------------------------------
 #ifndef MPB_NAR_DEPTH
 #define MPB_NAR_DEPTH 3
@@ -1568,8 +1571,13 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t 
 // atomic) only makes a counted wait stricter.  M0 = LDS address; one wait state between the M0 write and the DMA.
 __device__ __forceinline__ void nar_dma16(const uint8_t *base, uint32_t voff, uint32_t lds)
 {
+#ifdef MPB_NAR_NT                              // experiment: non-temporal requests (profiles/r05_narrow_variants.txt)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
+                 :: "s"(lds), "v"(voff), "s"(base) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                  :: "s"(lds), "v"(voff), "s"(base) : "memory");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void nar_wait()                  // until at most N vector-memory operations are outstanding
@@ -1581,21 +1589,40 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p)      // a __shared
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
+#ifdef MPB_NAR_LUT128                          // experiment: the {1 - p, p'} pair from the table (5 instead of 6 instructions per base
+typedef double2 nar_entry_t;                  // at R = 2, twice the LDS cycles): profiles/r05_narrow_variants.txt
+#define NAR_P(e) ((e).y)
+#define NAR_A(e) ((e).x)
+#else
+typedef double nar_entry_t;
+#define NAR_P(e) (e)
+#define NAR_A(e) (1.0 - (e))                  // the table's own 1 - p
+#endif
+
 template <int R>
-__device__ __forceinline__ void nar_step(double (&v)[R], const double p)
+__device__ __forceinline__ void nar_step(double (&v)[R], const nar_entry_t e)
 {
-    const double a = 1.0 - p;                 // the table's 1 - p
+    const double a = NAR_A(e), p = NAR_P(e);
 #pragma unroll
     for (int r = R - 1; r >= 1; r--) v[r] = cell<false>(a, v[r], p, v[r - 1]);
     v[0] = a * v[0];
 }
 
 template <int R>
-__device__ __forceinline__ void nar_dword(double (&v)[R], const double *tab, uint32_t w)
+__device__ __forceinline__ void nar_dword(double (&v)[R], const nar_entry_t *tab, uint32_t w)
 {
 #pragma unroll
     for (int t = 0; t < 4; t++) nar_step<R>(v, tab[(w >> (8 * t)) & 0xffu]);
 }
+
+#ifdef MPB_NAR_STAMPS                          // experiment: where a wave's cycles go (request / wait / arithmetic / epilogue)
+__device__ unsigned long long g_nar_stamps[4];
+#define NAR_T0() const long long t_s = __builtin_readcyclecounter()
+#define NAR_T1(k) st[k] += __builtin_readcyclecounter() - t_s
+#else
+#define NAR_T0()
+#define NAR_T1(k)
+#endif
 
 template <int R>
 __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, int64_t n, int64_t stride, int32_t li,
@@ -1609,7 +1636,7 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     // order does not depend on timing.  k_nar_offsets / k_nar_compact then make the dense list.
     constexpr int D = MPB_NAR_DEPTH;
     static_assert(D >= 2 && D <= 4, "ring depth");
-    __shared__ double s_p[256];
+    __shared__ nar_entry_t s_p[256];
     // one array per ring slot: a read of slot k is then provably independent of a DMA into slot k + 1 (the compiler orders
     // LDS reads behind LDS-DMA by what may alias)
     __shared__ __attribute__((aligned(16))) uint8_t s_ring0[4][MPB_NAR_PANEL];
@@ -1618,7 +1645,12 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     __shared__ __attribute__((aligned(16))) uint8_t s_ring3[D > 3 ? 4 : 1][D > 3 ? MPB_NAR_PANEL : 16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_p[tid] = (tid == 0 || tid == 255) ? __builtin_nan("") : lut_g[tid].y;
+    // byte 0 ('N'): the identity step {1, 0} the table holds anyway (counted below); byte 255 ('n'): a NaN -- the read is handed back
+#ifdef MPB_NAR_LUT128
+    s_p[tid] = tid == 255 ? make_double2(__builtin_nan(""), __builtin_nan("")) : lut_g[tid];
+#else
+    s_p[tid] = tid == 255 ? __builtin_nan("") : lut_g[tid].y;
+#endif
     __syncthreads();                                          // the only block barrier
     const int64_t nblk = (n + 63) >> 6;                       // row blocks of 64 reads
     const int ncq = (li + 63) >> 6;                           // 64-byte panels per row block (li >= 1)
@@ -1657,11 +1689,17 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
         }
     };
 
+#ifdef MPB_NAR_STAMPS
+    long long st[4] = {0, 0, 0, 0};
+#endif
     int64_t pf_b = gw, cur_b = gw;            // row block of the next panel to request / being computed
     int pf_c = 0, cur_c = 0;
     int64_t pf = 0;                           // panels requested so far
     auto request = [&](const uint32_t slot) {
         if (pf < total) {
+#ifdef MPB_NAR_NODMA                           // timing experiment: the arithmetic alone (stale panels after the first)
+            if (pf < D - 1)
+#endif
             issue(pf_b, pf_c, slot);
             pf++;
             if (++pf_c == ncq) { pf_c = 0; pf_b += W; }
@@ -1675,19 +1713,80 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     for (int r = 0; r < R; r++) v[r] = r == 0 ? 1.0 : 0.0;
     const uint32_t tl = (uint32_t)((lane >> 4) * 1024 + (lane & 15) * 16);      // this lane's row inside a panel
     const double thr = prm.thr;
+    // 'N' bases of the lane's read: the bytes that are NOT zero are counted, four per instruction -- v_msad_u8 adds |a - b| over the
+    // bytes whose reference byte b is non-zero, and a = b ^ 1 differs from b by exactly one -- which costs half an instruction
+    // per base where looking for zero bytes would cost one
+    uint32_t nonzero = 0;
+    const int ndw = (li + 3) >> 2;                            // dwords counted per read (bytes past its end are made non-zero)
 
     auto step = [&](const int S, const int64_t s) {
         (void)s;
-        request(ring_lds[(S + D - 1) % D]);                 // the slot the step before has just finished with
+        { NAR_T0(); request(ring_lds[(S + D - 1) % D]); NAR_T1(0); }   // the slot the step before has just finished with
         // the panel of this step has landed when at most the requests made after it are still out
         const int64_t younger = pf - (s + 1);               // 0 .. D-1 panels (wave-uniform)
+        { NAR_T0();
+#ifdef MPB_NAR_NODMA
+        nar_wait<0>();
+#endif
         if (younger >= 3) nar_wait<12>();
         else if (younger == 2) nar_wait<8>();
         else if (younger == 1) nar_wait<4>();
         else nar_wait<0>();
+        NAR_T1(1); }
+#ifdef MPB_NAR_STAMPS
+        const long long t_c = __builtin_readcyclecounter();
+#endif
         const uint8_t *mine = ring[S] + tl;
+#ifdef MPB_NAR_NOARITH                         // timing experiment: the panel stream alone
+        const int nbases = 0;
+#else
         const int nbases = min(64, li - cur_c * 64);        // wave-uniform
+#endif
         if (nbases == 64) {
+#ifndef MPB_NAR_PLAIN_ORDER
+            // All four chunks of the panel at once; the table two dwords (eight bases) ahead of the arithmetic; 1 - p one dword
+            // ahead; and inside a base the operations in an order that keeps dependent FP64 instructions three issue slots apart
+            // (a dependent v_mul_f64 / v_add_f64 issues 8-9 cycles after its producer, tools/experiments/fp64_latency.hip: back
+            // to back it costs a slot): every product first, then the sums, then the next dword's 1 - p and the table address of
+            // the base eight ahead.  The fences pin that order (the machine scheduler otherwise puts each sum right behind its
+            // product).  Fully unrolled, so the rotating register roles cost no copies.
+            uint32_t wd[16];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
+                wd[4 * k] = x.x; wd[4 * k + 1] = x.y; wd[4 * k + 2] = x.z; wd[4 * k + 3] = x.w;
+            }
+            nar_entry_t P[18][4];                       // P[d]: table entries of dword d (static indices only)
+            double A[17][4];                            // A[d]: their 1 - p
+#pragma unroll
+            for (int t = 0; t < 4; t++) P[0][t] = s_p[(wd[0] >> (8 * t)) & 0xffu];
+#pragma unroll
+            for (int t = 0; t < 4; t++) P[1][t] = s_p[(wd[1] >> (8 * t)) & 0xffu];
+#pragma unroll
+            for (int t = 0; t < 4; t++) A[0][t] = NAR_A(P[0][t]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const double a = A[d][t], p = NAR_P(P[d][t]);
+                    double x[R], y[R];
+#pragma unroll
+                    for (int r = R - 1; r >= 1; r--) x[r] = a * v[r];
+#pragma unroll
+                    for (int r = R - 1; r >= 1; r--) y[r] = p * v[r - 1];
+                    v[0] = a * v[0];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = R - 1; r >= 1; r--) v[r] = x[r] + y[r];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (d < 15) A[d + 1][t] = NAR_A(P[d + 1][t]);
+                    if (d < 14) P[d + 2][t] = s_p[(wd[d + 2] >> (8 * t)) & 0xffu];
+                    if (t == 0) nonzero = __builtin_amdgcn_msad_u8(wd[d] ^ 0x01010101u, wd[d], nonzero);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
             // all four chunks of the panel at once, then the table one dword (four bases) ahead of the arithmetic
             uint32_t wd[16];
 #pragma unroll
@@ -1695,7 +1794,7 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
                 const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
                 wd[4 * k] = x.x; wd[4 * k + 1] = x.y; wd[4 * k + 2] = x.z; wd[4 * k + 3] = x.w;
             }
-            double pc[4], pn[4];
+            nar_entry_t pc[4], pn[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) pc[t] = s_p[(wd[0] >> (8 * t)) & 0xffu];
 #pragma unroll
@@ -1704,12 +1803,14 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
 #pragma unroll
                     for (int t = 0; t < 4; t++) pn[t] = s_p[(wd[d + 1] >> (8 * t)) & 0xffu];
                 }
+                nonzero = __builtin_amdgcn_msad_u8(wd[d] ^ 0x01010101u, wd[d], nonzero);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 4; t++) nar_step<R>(v, pc[t]);
 #pragma unroll
                 for (int t = 0; t < 4; t++) pc[t] = pn[t];
             }
+#endif
         } else {
             for (int k = 0; k * 16 < nbases; k++) {
                 const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
@@ -1718,15 +1819,24 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
                 int d = 0;
 #pragma unroll 1
                 for (; d * 4 + 4 <= nb; d++) {
+                    nonzero = __builtin_amdgcn_msad_u8(w0 ^ 0x01010101u, w0, nonzero);
                     nar_dword<R>(v, s_p, w0);
                     w0 = w1; w1 = w2; w2 = w3;
                 }
-                for (int t = d * 4; t < nb; t++) {          // a length that is not a multiple of 4: its last 1..3 bases
-                    nar_step<R>(v, s_p[w0 & 0xffu]);
-                    w0 >>= 8;
+                if (d * 4 < nb) {                           // a length that is not a multiple of 4: its last 1..3 bases
+                    const uint32_t wf = w0 | (0x01010101u << (8 * (nb - d * 4)));     // bytes past the end: non-zero
+                    nonzero = __builtin_amdgcn_msad_u8(wf ^ 0x01010101u, wf, nonzero);
+                    for (int t = d * 4; t < nb; t++) {
+                        nar_step<R>(v, s_p[w0 & 0xffu]);
+                        w0 >>= 8;
+                    }
                 }
             }
         }
+#ifdef MPB_NAR_STAMPS
+        st[2] += __builtin_readcyclecounter() - t_c;
+        const long long t_e = __builtin_readcyclecounter();
+#endif
         if (++cur_c == ncq) {
             // ---- a row block is done: sequential CDF, interpolation, predicate (as the tile classes' epilogue) ----
             const int64_t i = cur_b * 64 + lane;
@@ -1746,12 +1856,14 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
             if (done) {
                 double e = (double)(js - 1) + ((thr - lo) / (hi - lo));     // ref: bernoullimodule.c:170-178
                 if (e < 0) e = 0;
-                if (prm.ambig_mode == 0) e = e + 0.0;                        // moira.py:827-828 with Ns == 0
-                const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
-                if (prm.flags & 1u) e = floor(e);
+                const int nsv = 4 * ndw - (int)nonzero;                      // 'N' bases (a read with an 'n' never gets here)
+                if (prm.ambig_mode == 0) e = e + (double)nsv;                // moira.py:827-828
+                const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors            // moira.py:925-926
+                                                                      : (double)li * prm.uncert; // moira.py:949-950
+                if (prm.flags & 1u) e = floor(e);                            // moira.py:830-831
                 ee[i] = e;
-                ns[i] = 0;                                                   // a read with an ambiguous base never gets here
-                pass[i] = (uint8_t)(e <= limit ? 1 : 0);
+                ns[i] = nsv;
+                pass[i] = (uint8_t)((prm.ambig_mode == 2 && nsv > 0) ? 0 : (e <= limit ? 1 : 0));   // moira.py:911
             }
             const unsigned long long todo = __ballot(valid && js < 0);
             if (todo) {
@@ -1760,9 +1872,13 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
             }
 #pragma unroll
             for (int r = 0; r < R; r++) v[r] = r == 0 ? 1.0 : 0.0;
+            nonzero = 0;
             cur_c = 0;
             cur_b += W;
         }
+#ifdef MPB_NAR_STAMPS
+        st[3] += __builtin_readcyclecounter() - t_e;
+#endif
     };
     for (int64_t s = 0; s < total; s += D) {
         step(0, s);
@@ -1771,6 +1887,9 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
         if (D > 3 && s + 3 < total) step(3 % D, s + 3);
     }
     if (lane == 0) wave_count[gw] = nlist;
+#ifdef MPB_NAR_STAMPS
+    if (lane == 0) for (int k = 0; k < 4; k++) atomicAdd(&g_nar_stamps[k], (unsigned long long)st[k]);
+#endif
 }
 
 // exclusive prefix of the waves' list counts (one block); total -> *count
@@ -1839,7 +1958,7 @@ __global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, i
     const int64_t i = min(n - 1, (int64_t)k * step + (int64_t)(mpb_mix64((uint64_t)k) % (uint64_t)step));
     float mu = 0.f, var = 0.f, k3 = 0.f;
     float lp0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    int ambi = 0;
+    int ambi = 0, lower = 0;                                               // ambiguous bases in all / lower-case 'n' among them
     for (int c0 = 0; c0 * 16 < li; c0 += 64 * 15) {                        // panels of 15 chunks per lane: the markers peel exactly
         f32x2 a01 = {0.f, 0.f};
         float s3 = 0.f;
@@ -1864,11 +1983,12 @@ __global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, i
         const float pvar = rem - MPB_MARK_UPPER * nzero;
         mu += a01.x; var += pvar; k3 += pvar - 2.0f * s3;
         ambi += (int)nzero + (int)n255;
+        lower += (int)n255;
     }
 #pragma unroll
     for (int off = 1; off <= 32; off <<= 1) {
         mu += __shfl_xor(mu, off); var += __shfl_xor(var, off);
-        k3 += __shfl_xor(k3, off); ambi += __shfl_xor(ambi, off);
+        k3 += __shfl_xor(k3, off); ambi += __shfl_xor(ambi, off); lower += __shfl_xor(lower, off);
         lp0 += __shfl_xor(lp0, off); t1 += __shfl_xor(t1, off);
         t2 += __shfl_xor(t2, off); t3 += __shfl_xor(t3, off);
     }
@@ -1887,7 +2007,7 @@ __global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, i
         else if ((cdf += p0 * e2) > thr) rows = 3;
         else if ((cdf += p0 * e3) > thr) rows = 4;
         rows = max(min(rows, li - ambi + 1), 1);
-        atomicAdd(hist + (ambi > 0 ? 0 : min(rows, MPB_NAR_BUCKETS - 1)), 1);
+        atomicAdd(hist + (lower > 0 ? 0 : min(rows, MPB_NAR_BUCKETS - 1)), 1);      // an 'n' is what the narrow pass hands back
     }
 }
 
@@ -2011,7 +2131,9 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
     static const int chunk_tiles = getenv("MPB_DP_CHUNK") ? atoi(getenv("MPB_DP_CHUNK")) : MPB_DP_CHUNK;
     static const int grid_cap = getenv("MPB_DP_GRID") ? atoi(getenv("MPB_DP_GRID")) : MPB_DP_GRID;
 #else
-    constexpr int chunk_tiles = MPB_DP_CHUNK;
+    // a small batch (the sub-batch a narrow pass hands back, a short file's last chunk) is latency: fewer tiles per wave so that
+    // every SIMD gets one -- 8 tiles per class-body call only pay where there are tens of thousands of tiles
+    const int chunk_tiles = tiles >= 32768 ? MPB_DP_CHUNK : tiles >= 16384 ? 4 : tiles >= 8192 ? 2 : 1;
     constexpr int grid_cap = MPB_DP_GRID;
 #endif
     int64_t want = (tiles + 4 * chunk_tiles - 1) / (4 * chunk_tiles);   // blocks if every wave took one chunk
@@ -2128,13 +2250,16 @@ void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t
 }
 
 // ---- natural-order narrow pass ----------------------------------------------------------------------------------------
-int mpb_narrow_lds_bytes() { return 256 * 8 + MPB_NAR_DEPTH * 4 * MPB_NAR_PANEL; }
+int mpb_narrow_lds_bytes() { return 256 * (int)sizeof(nar_entry_t) + MPB_NAR_DEPTH * 4 * MPB_NAR_PANEL; }
 
 void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
                        const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks, hipStream_t s)
 {
     const int64_t nblk = (n + 63) / 64;
     int64_t blocks = (nblk + 3) / 4;
+#ifdef MPB_TUNING_KNOBS          // experiment builds only (tools/): never in the shipped library
+    if (getenv("MPB_NAR_GRID")) grid_blocks = atoi(getenv("MPB_NAR_GRID"));
+#endif
     if (blocks > grid_blocks) blocks = grid_blocks;         // persistent: a wave walks row blocks gw, gw + W, ...
     if (blocks > MPB_NAR_MAX_WAVES / 4) blocks = MPB_NAR_MAX_WAVES / 4;
     if (blocks < 1) blocks = 1;
@@ -2147,6 +2272,16 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
     default: MPB_NAR_LAUNCH(4); break;
     }
 #undef MPB_NAR_LAUNCH
+#ifdef MPB_NAR_STAMPS
+    if (getenv("MPB_NAR_STAMPS_PRINT")) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nar_stamps), sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nar_stamps), z, sizeof(z));
+        fprintf(stderr, "[k_narrow stamps, cycles per wave] request %.0f  wait %.0f  arithmetic %.0f  epilogue %.0f  (%d waves)\n",
+                (double)h[0] / nwaves, (double)h[1] / nwaves, (double)h[2] / nwaves, (double)h[3] / nwaves, nwaves);
+    }
+#endif
     hipLaunchKernelGGL(k_nar_offsets, dim3(1), dim3(1024), 0, s, ws.nar_wave_count, nwaves, ws.nar_wave_off, ws.nar_count);
     hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, ws.nar_wave_off, nblk, nwaves, list);
 }
