@@ -604,6 +604,9 @@ def main():
             if n != CONFIG4_SHARD:
                 extras["config4_shard"] = config4_shard_rate(eng, L, stride, args.seed, params)
         extras["poisson_error_calc"] = poisson_rate(eng, d_q, n, stride, L, d_ee, d_ns)
+        if world == 1:
+            extras["high_quality_300"] = high_quality_rate(eng, min(n, CONFIG2_READS), stride, L, args.seed, d_ee, d_ns, d_pass)
+            extras["real_profile"] = real_profile_rate(eng)
 
     if rank == 0:
         total_reads = n * world * steps
@@ -953,6 +956,150 @@ def config4_shard_rate(eng, L, stride, seed, params, n=CONFIG4_SHARD, rank=3):
             b.free()
         except Exception:
             pass
+    return out
+
+
+def _wall_rate(eng, run, seconds=0.6, settle_s=0.5):
+    """ms per call of `run` (asynchronous calls back to back, one synchronisation at the end) after `settle_s` of untimed calls."""
+    run(); eng.synchronize()
+    t = time.perf_counter(); run(); eng.synchronize()
+    one = max(time.perf_counter() - t, 1e-5)
+    for _ in range(max(3, int(settle_s / one))):
+        run()
+    eng.synchronize()
+    k = max(5, int(seconds / one))
+    t = time.perf_counter()
+    for _ in range(k):
+        run()
+    eng.synchronize()
+    return (time.perf_counter() - t) / k * 1e3, k
+
+
+def high_quality_rate(eng, n, stride, L, seed, d_ee, d_ns, d_pass):
+    """VERDICT r4 #1: the HBM-bound regime.  The same shape as configs[1] (n x 300 bp, stride 320, resident) with the clean
+    quality profile of include/mpb_synth.h (profile 1: Q33..Q40, 0.003 % ambiguous bases: every read's CDF crosses 1 - alpha
+    on the second row of the table).  The library picks its pass from a sample of <= 0.1 % of the reads (mpb_path_info): here
+    the natural-order narrow pass (k_narrow, the matrix read once) -- timed against the sorted pipeline on the same batch
+    (MPB_FLAG_NO_NARROW).  Algorithmic bytes per read = L + 13 as everywhere (SURVEY 8d).  NOT the headline."""
+    out = {"note": "10 M x 300 bp of the CLEAN synthetic profile (Q33..Q40; include/mpb_synth.h profile 1), resident; the pass "
+                   "is the library's own choice; roofline as for the headline: (L + 13) x reads / time / 8 TB/s; NOT the headline",
+           "reads": n, "read_length": L, "row_stride": stride, "profile": 1, "seed": seed}
+    d_q = None
+    try:
+        d_q = eng.alloc(n * stride)
+        eng.synth_fill(d_q, n, stride, fixed_len=L, seed=seed, profile=1)
+        alg = n * (L + 13)
+        prm = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors")
+        run = lambda p=prm, c=False: eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass,
+                                                      params=p, want_counts=c)
+        run()
+        first = eng.last_path()
+        ms, k = _wall_rate(eng, run)
+        path = eng.last_path()
+        c = run(c=True)
+        eng.timing(True); eng.timing_reset()
+        for _ in range(10):
+            run()
+        kt = {name: v[0] / 10 for name, v in eng.kernel_times().items() if v[1]}
+        eng.timing(False)
+        nar_ms = kt.get("narrow")
+        out.update({"ms_per_step": ms, "steps": k, "reads_per_s": n / ms * 1e3,
+                    "pass_taken": {"narrow_rows": path["narrow_rows"], "reads_handed_to_the_sorted_pipeline": path["n_fallback"],
+                                   "sample_rows_histogram": {str(r): v for r, v in enumerate(first["sample_hist"]) if v},
+                                   "sample_reads": sum(first["sample_hist"])},
+                    "kernels_ms_per_step": kt,
+                    "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": alg,
+                                 "whole_step": {"achieved": alg / ms / 1e6, "frac": alg / ms / 1e6 / HBM_PEAK_GBS},
+                                 "kernel": "k_narrow", "avg_launch_ms": nar_ms,
+                                 "achieved": (alg / nar_ms / 1e6) if nar_ms else None,
+                                 "frac": (alg / nar_ms / 1e6 / HBM_PEAK_GBS) if nar_ms else None},
+                    "outcome": {"pass": c.n_pass, "fail": c.n_fail, "overflow_reruns": c.n_overflow}})
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_hq.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            w = t.get("workload", {})
+            if (w.get("reads"), w.get("length"), w.get("seed"), w.get("profile")) == (n, L, seed, 1):
+                out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = t.get("source")
+                out["valu_busy_pmc"] = t.get("valu")
+        # the same batch through the sorted pipeline (what round 4 did with it)
+        prm_s = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", no_narrow=True)
+        ms_s, k_s = _wall_rate(eng, lambda: run(prm_s), seconds=0.3, settle_s=0.2)
+        hist = eng.class_histogram()
+        out["sorted_pipeline_on_the_same_batch"] = {"ms_per_step": ms_s, "steps": k_s, "frac_whole_step": alg / ms_s / 1e6 / HBM_PEAK_GBS,
+                                                    "row_budget_histogram": {str(a): b for a, b in hist.items() if b}}
+    except Exception as e:                                  # an extra must never cost the headline line
+        out["error"] = repr(e)
+    if d_q is not None:
+        try:
+            d_q.free()
+        except Exception:
+            pass
+    return out
+
+
+def real_profile_batches(eng, rows_fixed=10_000_000, rows_ragged=5_000_000, seed=7):
+    """The reference's OWN reads as resident batches (VERDICT r4 #3): (a) the 1,000 reads of moira/test/test1.fastq (251 bp;
+    tests/golden/test1.fastq.gz is that file) and (b) the 400 representative contigs of its paired golden run
+    (tests/golden/reference_test_results/paired.qc.{good,bad}: 241-502 bp), each tiled to millions of rows in a random order
+    (a read's copies are never adjacent on purpose: the order is a seeded permutation of the tiling).
+    -> [(label, q uint8[n, stride], lens or None, fixed_len, source_index int32[n], unique_q, unique_lens)]"""
+    import gzip
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_io as G
+    rng = np.random.default_rng(seed)
+    out = []
+    lines = gzip.open(os.path.join(ROOT, "tests", "golden", "test1.fastq.gz"), "rt").read().split("\n")
+    seqs, quals = [lines[i + 1] for i in range(0, len(lines) - 3, 4)], [lines[i + 3] for i in range(0, len(lines) - 3, 4)]
+    uq, ul = eng.pack_batch_ascii(seqs, quals, fastq_offset=33, stride=256)
+    idx = rng.permutation(np.arange(rows_fixed, dtype=np.int64) % len(seqs)).astype(np.int32)
+    out.append(("test1.fastq (1,000 reads x 251 bp)", uq[idx], None, int(ul[0]), idx, uq, ul))
+    recs = []
+    for kind in ("good", "bad"):
+        recs += G.read_fasta_qual(os.path.join(ROOT, "tests", "golden", "reference_test_results", "paired.qc." + kind))
+    cq, cl = eng.pack([r[2] for r in recs], [r[3] for r in recs], stride=512)
+    idx = rng.permutation(np.arange(rows_ragged, dtype=np.int64) % len(recs)).astype(np.int32)
+    out.append(("paired golden contigs (400 representatives, 241-502 bp)", cq[idx], cl[idx], 0, idx, cq, cl))
+    return out
+
+
+def real_profile_rate(eng):
+    """Throughput on the reference's own quality profiles (VERDICT r4 #3), next to the synthetic headline.  NOT the headline."""
+    import numpy as np
+    out = {"note": "the reference's own reads (moira/test/test1.fastq; the contigs of its paired golden run) tiled in a seeded "
+                   "random order to resident batches; bit-exact mode, the library's own choice of pass; NOT the headline"}
+    try:
+        for label, q, lens, fixed_len, _idx, _uq, _ul in real_profile_batches(eng):
+            n, stride = q.shape
+            bufs = [eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)] + ([eng.alloc(n * 4)] if lens is not None else [])
+            try:
+                bufs[0].upload(q)
+                if lens is not None:
+                    bufs[4].upload(lens)
+                run = lambda c=False: eng.filter_device(bufs[0], n, stride, d_len=bufs[4] if lens is not None else None,
+                                                        fixed_len=fixed_len, d_ee=bufs[1], d_ns=bufs[2], d_pass=bufs[3], want_counts=c)
+                ms, k = _wall_rate(eng, run, seconds=0.4, settle_s=0.3)
+                path = eng.last_path()
+                c = run(True)
+                hist = eng.class_histogram() if path["narrow_rows"] == 0 else {}
+                eng.timing(True); eng.timing_reset()
+                for _ in range(5):
+                    run()
+                kt = {name: v[0] / 5 for name, v in eng.kernel_times().items() if v[1]}
+                eng.timing(False)
+                L = fixed_len if lens is None else float(lens.mean())
+                out[label] = {"reads": n, "row_stride": stride, "mean_length": L, "ms_per_step": ms, "steps": k,
+                              "reads_per_s": n / ms * 1e3, "bases_per_s": n * L / ms * 1e3,
+                              "pass_taken": {"narrow_rows": path["narrow_rows"], "handed_back": path["n_fallback"]},
+                              "kernels_ms_per_step": kt, "row_budget_histogram": {str(a): b for a, b in hist.items() if b},
+                              "outcome": {"pass": c.n_pass, "fail": c.n_fail, "overflow_reruns": c.n_overflow}}
+            finally:
+                for b in bufs:
+                    b.free()
+            del q
+    except Exception as e:                                  # an extra must never cost the headline line
+        out["error"] = repr(e)
     return out
 
 
