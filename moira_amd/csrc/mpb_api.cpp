@@ -1437,6 +1437,7 @@ int mpb_pack_batch_coded(const char *seq_cat, const int32_t *qual_cat, const int
         if (L < 0) return fail(MPB_E_INVALID, "offsets must not decrease");
         if (max_len > 0 && L > max_len) L = max_len;
         if (L > row_stride) return fail(MPB_E_INVALID, "read %lld (%lld bases) does not fit row_stride %lld", (long long)i, (long long)L, (long long)row_stride);
+        if (L > MPB_MAX_LEN) return fail(MPB_E_INVALID, "read %lld has %lld bases: reads longer than %d bases are not supported", (long long)i, (long long)L, MPB_MAX_LEN);
         for (int64_t k = 0; k < L; k++) {
             const int32_t q = qual_cat[off[i] + k];
             if (q < 0) return fail(MPB_E_RANGE, "Qualities must have positive values.");
@@ -1446,11 +1447,13 @@ int mpb_pack_batch_coded(const char *seq_cat, const int32_t *qual_cat, const int
     }
     for (int c = 0; c < 256; c++) code_scores[c] = c;
     int next = 254;
+    size_t assigned = 0;
     for (int32_t q : big) {
         while (next >= 1 && used[next]) next--;
         if (next < 1)
             return fail(MPB_E_RANGE, "the batch holds %zu distinct scores above 254 but uses all but %zu of the 254 byte codes: "
-                        "split it (or score such reads through mpb_calculate_errors_PB)", big.size(), (size_t)(&q - big.data()));
+                        "split it (or score such reads through mpb_calculate_errors_PB)", big.size(), assigned);
+        assigned++;
         used[next] = true;
         code_of[q] = next;
         code_scores[next] = q;

@@ -236,10 +236,10 @@ struct PreOut {
 // One read's statistics -> row budget -> class byte, Ns, histogram count (or: settled / wide / bad length).
 // mu, var, k3: fp32 sums of p, p(1-p), p(1-p)(1-2p) over the scored bases; ambi = 'N' count | 'n' count << 16;
 // li = the (clamped) length, bad = the caller-supplied length did not fit the row.
-__device__ __forceinline__ void class_read(int64_t i, float mu, float var, float k3, int ambi, int li, bool bad, bool ragged,
+__device__ __forceinline__ void class_read(int64_t i, float mu, float var, float k3, uint32_t ambi, int li, bool bad, bool ragged,
                                            const MpbDevParams &prm, const PreOut &o, int *s_hist, int nb)
 {
-    const int nzero = ambi & 0xffff, n255 = ambi >> 16;
+    const int nzero = (int)(ambi & 0xffffu), n255 = (int)(ambi >> 16);      // unsigned: a read may hold more than 32767 'n'
     // Cornish-Fisher estimate of the (1-alpha) quantile of the error count; the DP needs
     // rows 0..j* where j* is the first row whose CDF exceeds 1-alpha.
     const float v = fmaxf(var, 1e-12f);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         nfull = __builtin_amdgcn_readfirstlane(nfull);
         const uint8_t *src = q + (live ? i : (int64_t)0) * stride + cl * 16;
         float mu = 0.f, var = 0.f, k3 = 0.f;
-        int ambi = 0;                              // 'N' count | 'n' count << 16
+        uint32_t ambi = 0;                         // 'N' count | 'n' count << 16 (unsigned: up to 65535 of either)
         // A panel = 3 * MPB_PRE_NB column quads = at most 240 bytes per lane, so that the ambiguity markers come off
         // the panel's sum exactly.  Rows of up to 960 bytes are one panel (and one set of sums, as before).
         auto panel = [&](const int pb, const int pend) {
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
 #else
         k3 += pvar - 2.0f * s3;                                           // sum p(1-p)(1-2p)
 #endif
-        ambi += (int)nzero + ((int)n255 << 16);
+        ambi += (uint32_t)nzero + ((uint32_t)n255 << 16);
         };  // panel
         if (LONG) { for (int pb = 0; pb < ncol; pb += 12 * MPB_PRE_NB) panel(pb, min(ncol, pb + 12 * MPB_PRE_NB)); }
         else panel(0, ncol);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
             k3 += __shfl_xor(k3, off);
             ambi += __shfl_xor(ambi, off);
         }
-        const float amb = __int_as_float(ambi);
+        const float amb = __uint_as_float(ambi);
         if (cl == 0) s_row[w][rb + r16] = make_float4(mu, var, k3, amb);
     }
     wave_lds_fence();          // s_row[w] is private to this wave: no block barrier
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         if (i < n) {
             const float4 e = s_row[w][lane];
             const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
-            class_read(i, e.x, e.y, e.z, __float_as_int(e.w), li, RAGGED && li != len[i], RAGGED, prm, o, s_hist, nb);
+            class_read(i, e.x, e.y, e.z, __float_as_uint(e.w), li, RAGGED && li != len[i], RAGGED, prm, o, s_hist, nb);
         }
     }
     wave_lds_fence();                             // s_row[w] is reused by the next round
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void k_classify_linear(const uint8_t *__restri
                 const float rem = a01.y - MPB_MARK_LOWER * n255;
                 const float nzero = floorf(rem * (1.0f / MPB_MARK_UPPER));
                 const float pvar = rem - MPB_MARK_UPPER * nzero;
-                part = make_float4(a01.x, pvar, pvar - 2.0f * s3, __int_as_float((int)nzero + ((int)n255 << 16)));
+                part = make_float4(a01.x, pvar, pvar - 2.0f * s3, __uint_as_float((uint32_t)nzero + ((uint32_t)n255 << 16)));
             }
             s_part[c] = part;
         }
@@ -509,10 +509,10 @@ __global__ __launch_bounds__(256) void k_classify_linear(const uint8_t *__restri
         const int sub = tid & (lpr - 1);
         for (int r = tid / lpr; r < nr; r += 256 / lpr) {                 // (256 / lpr) rows per sweep; wave-uniform trip count not needed
             float mu = 0.f, var = 0.f, k3 = 0.f;
-            int ambi = 0;
+            uint32_t ambi = 0;
             for (int j = sub; j < cpr; j += lpr) {
                 const float4 e = s_part[r * cpr + j];
-                mu += e.x; var += e.y; k3 += e.z; ambi += __float_as_int(e.w);
+                mu += e.x; var += e.y; k3 += e.z; ambi += __float_as_uint(e.w);
             }
             for (int off = 1; off < lpr; off <<= 1) {
                 mu += __shfl_xor(mu, off); var += __shfl_xor(var, off);
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
     const float nzero_f = floorf(rem * (1.0f / MPB_MARK_UPPER));
     float mu = a01.x, var = rem - MPB_MARK_UPPER * nzero_f;
     float k3 = var - 2.0f * s3;
-    int ambi = (int)nzero_f + ((int)n255 << 16);
+    uint32_t ambi = (uint32_t)nzero_f + ((uint32_t)n255 << 16);
 #pragma unroll
     for (int off = 1; off <= 32; off <<= 1) {
         mu += __shfl_xor(mu, off);
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
         k3 += __shfl_xor(k3, off);
         ambi += __shfl_xor(ambi, off);
     }
-    const int nzero = ambi & 0xffff, n_lower = ambi >> 16;
+    const int nzero = (int)(ambi & 0xffffu), n_lower = (int)(ambi >> 16);
     const float v = fmaxf(var, 1e-12f);
     const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;           // as k_prepass
     int rows = (int)floorf(fminf(x, 1e9f) + 0.5f) + 1;

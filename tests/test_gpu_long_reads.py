@@ -155,6 +155,31 @@ def test_reads_beyond_16383_bases(eng, oracle):
     assert eng.calculate_errors_PB(seq, quals, 0.005) == oracle.ee_rowwise(seq, quals, 0.005)[:2]
 
 
+def test_reads_with_more_than_32767_lower_case_n(eng, oracle):
+    """the ambiguity counters are 'N' | 'n' << 16 in one word; unpacked with a signed shift, 32768 or more
+    lower-case n made the count negative and the result silently wrong.  A 40,000-base read of 'n' only, one that mixes 35,000
+    'n' with 20,000 'N' and scored bases, and a 65,535-base read of 'n' only."""
+    q = np.zeros((4, 65536), np.uint8)
+    lens = np.array([40000, 60000, 65535, 300], np.int32)
+    q[0, :40000] = 255
+    rng = np.random.default_rng(5)
+    q[1, :60000] = rng.integers(25, 41, 60000)
+    pos = rng.permutation(60000)
+    q[1, pos[:35000]] = 255
+    q[1, pos[35000:55000]] = 0
+    q[2, :65535] = 255
+    q[3, :300] = 30
+    ee, ns, ps, rows = oracle.filter_batch(q, lens=lens, threads=4)
+    assert list(ns) == [40000, 55000, 65535, 0]
+    for kw in (dict(ambigs="treat_as_errors"), dict(ambigs="ignore"), dict(ambigs="disallow")):
+        e2, n2, p2, _ = oracle.filter_batch(q, lens=lens, threads=4, **kw)
+        r = eng.filter(q, lens=lens, batched_only=True, **kw)
+        assert same(r.ee, e2) and np.array_equal(r.ns, n2) and np.array_equal(r.passed, p2.astype(bool)), kw
+    r = eng.filter(q[:, :16384], lens=np.minimum(lens, 16384))          # and through the one-read-per-wave kernel
+    e3, n3, p3, _ = oracle.filter_batch(q[:, :16384], lens=np.minimum(lens, 16384), threads=4)
+    assert same(r.ee, e3) and np.array_equal(r.ns, n3)
+
+
 def test_too_long_is_refused_not_truncated(eng):
     from moira_amd import _lib as L
     prm = eng.params()
