@@ -192,9 +192,12 @@ def visible_gpus():
         return 0
 
 
-def self_launch(n, rehearsal):
+def self_launch(n, rehearsal, fall_back_to_threads=False):
     """`python bench.py --gpus N` without torchrun: start the ranks as a child job and hand its exit code on.
-    Nothing in THIS process has initialised the GPU (no HIP call; at most a device count in a grandchild)."""
+    Nothing in THIS process has initialised the GPU (no HIP call; at most a device count in a grandchild).
+    fall_back_to_threads: when the process job ends non-zero WITHOUT having printed its JSON line (a rendezvous that never
+    forms, a launcher that is not there), the same measurement is started once more as `--launch threads` -- in another
+    fresh child: a process that has touched the GPU is never re-executed, and this one never touches it."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not rehearsal:
@@ -210,7 +213,30 @@ def self_launch(n, rehearsal):
             return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    if os.environ.get("BENCH_FAKE_LAUNCHER_FAILURE"):          # tests: a launcher that dies before any rank exists
+        cmd = [sys.executable, "-c", "import sys; sys.stderr.write('fake launcher failure\\n'); sys.exit(7)"]
+    if not fall_back_to_threads:
+        return subprocess.call(cmd, env=env)
+    # the child's stdout is passed through line by line; a line that parses as the result means the job got there
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    printed = False
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith("{") and '"metric"' in line:
+            printed = True
+    rc = proc.wait()
+    if rc == 0 or printed:
+        return rc
+    sys.stderr.write("bench.py: the %d-process job ended with code %d before it printed a result; running the same measurement "
+                     "as N contexts on N threads of one fresh process (--launch threads)\n" % (n, rc))
+    argv = [a for a in sys.argv[1:]]
+    if "--launch" in argv:
+        k = argv.index("--launch")
+        del argv[k:k + 2]
+    argv = [a for a in argv if not a.startswith("--launch=")]
+    env["BENCH_FELL_BACK_FROM"] = "processes (exit code %d)" % rc
+    return subprocess.call([sys.executable, os.path.abspath(__file__)] + argv + ["--launch", "threads"], env=env)
 
 
 COLLECTIVE_TIMEOUT_S = 120          # rendezvous and every gloo collective; the RCCL attempt has its own deadline below
@@ -391,6 +417,193 @@ class StubEngine:
         self.pending = 0
 
 
+class ClockSampler:
+    """The shader clock a GPU HOLDS while it works, read from sysfs (pp_dpm_sclk of the device's PCI function: the line with
+    the asterisk) every 25 ms by a host thread: a throttled GPU shows here and in its kernel times, not only in the total."""
+
+    def __init__(self, pci_bus_id):
+        import threading
+        self.path = "/sys/bus/pci/devices/%s/pp_dpm_sclk" % pci_bus_id.lower() if pci_bus_id else None
+        self.mhz = []
+        self._stop = threading.Event()
+        self._th = None
+
+    @staticmethod
+    def parse(text):
+        for line in text.splitlines():
+            if line.rstrip().endswith("*"):
+                digits = "".join(ch for ch in line.split(":", 1)[-1] if ch.isdigit())
+                return int(digits) if digits else None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                v = self.parse(open(self.path).read())
+                if v:
+                    self.mhz.append(v)
+            except OSError:
+                return
+            self._stop.wait(0.025)
+
+    def start(self):
+        import threading
+        if self.path and os.path.exists(self.path):
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._th:
+            self._th.join(1.0)
+        if not self.mhz:
+            return None
+        return {"mean_mhz": sum(self.mhz) / len(self.mhz), "min_mhz": min(self.mhz), "max_mhz": max(self.mhz),
+                "samples": len(self.mhz), "source": self.path}
+
+
+def pci_bus_id_of(device):
+    """'0000:c1:00.0' of HIP device `device`, through the runtime the library is linked against (no torch)."""
+    import ctypes as C
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0:
+            return buf.value.decode()
+    except OSError:
+        pass
+    return None
+
+
+def threads_main(args):
+    """--launch threads: the N > 1 measurement without a launcher and without any collective.  ONE process,
+    N contexts (one per GPU) on N host threads: each thread owns its device-resident shard (read ids r*R .., generated on its
+    own device), runs the same warm-up / settle / timed steps behind a thread barrier on both sides, and the line carries the
+    max over the threads, every thread's own rate, per-device kernel times (HIP events) and the clock each device held.
+    ctypes releases the GIL in every library call, and a step is asynchronous, so the threads never wait for each other
+    outside the two barriers.  Replaces moira/moira.py:398-399 (`Pool(args.processors)`) the way SURVEY 8e puts it."""
+    import threading
+    from moira_amd import _lib as ML
+    from moira_amd.engine import Engine
+    world, L = args.gpus, args.length
+    n = args.reads or CONFIG4_SHARD
+    stride = args.stride or (L + 63) // 64 * 64
+    have = ML.load().mpb_device_count()
+    if have < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if not args.rehearse_on_one_gpu and have < world:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible on this node\n" % (world, have))
+        return 2
+    bar = threading.Barrier(world)
+    t_one, dts, res, errs = [0.0] * world, [0.0] * world, [None] * world, [None] * world
+    plan = {}
+
+    def work(r):
+        eng = None
+        try:
+            dev = 0 if args.rehearse_on_one_gpu else r
+            eng = Engine(dev)
+            bus = pci_bus_id_of(dev)
+            d_q, d_ee, d_ns, d_pass = eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
+            eng.synth_fill(d_q, n, stride, fixed_len=L, seed=args.seed, first_read=r * n)
+            params = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", fast_fma=args.fast_fma)
+            step = lambda c=False: eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass,
+                                                     params=params, want_counts=c)
+            t0 = time.perf_counter()
+            for _ in range(max(args.warmup, 1)):
+                step()
+            eng.synchronize()
+            t_warm = (time.perf_counter() - t0) / max(args.warmup, 1)
+            t1 = time.perf_counter(); step(); eng.synchronize()
+            t_one[r] = max(min(time.perf_counter() - t1, t_warm), 1e-5)
+            if bar.wait() == 0:                              # one thread turns the common step time into the common plan
+                plan["steps"], plan["settle"] = plan_steps(max(t_one), args.steps, args.warmup)
+                plan["t_step"] = max(t_one)
+            bar.wait()
+            steps, settle = plan["steps"], plan["settle"]
+            for _ in range(settle):
+                step()
+            eng.synchronize()
+            clock = ClockSampler(bus).start()
+            bar.wait()                                       # ---- the timed region ----
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            eng.synchronize()
+            dts[r] = time.perf_counter() - t0
+            bar.wait()
+            t_all = time.perf_counter() - t0                 # after the barrier: the slowest thread's end, as every thread saw it
+            held = clock.stop()
+            counts = step(True)
+            ev = min(steps, 10)
+            eng.timing(True); eng.timing_reset()
+            for _ in range(ev):
+                step()
+            eng.synchronize()
+            kt = {k: v[0] / max(v[1], 1) for k, v in eng.kernel_times().items() if v[1]}
+            eng.timing(False)
+            res[r] = {"device": dev, "pci_bus_id": bus, "t_all": t_all, "kernels_ms_per_step": kt, "held_clock": held,
+                      "pass": counts.n_pass, "fail": counts.n_fail, "overflow": counts.n_overflow,
+                      "path": eng.last_path()["narrow_rows"]}
+            for b in (d_q, d_ee, d_ns, d_pass):
+                b.free()
+        except BaseException as e:                           # noqa: BLE001 -- whatever it is, nobody waits for this thread
+            errs[r] = e
+            bar.abort()
+        finally:
+            if eng is not None:
+                try:
+                    eng.close()
+                except Exception:                            # noqa: BLE001
+                    pass
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    bad = [(r, e) for r, e in enumerate(errs) if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if bad or any(x is None for x in res):
+        for r, e in bad:
+            sys.stderr.write("bench.py --launch threads: device thread %d failed: %r\n" % (r, e))
+        return 1
+    steps, settle = plan["steps"], plan["settle"]
+    dt = max(x["t_all"] for x in res)
+    wl = ("BASELINE configs[3]: %d synthetic %d bp reads sharded host-side across %d x MI355X, %d reads (%.1f GB resident, "
+          "generated on device, read ids rank*R..) per GPU, poisson_binomial filter, alpha 0.005, uncert 0.01 (uint8 %d x %d "
+          "per GPU, seed %d)" % (n * world, L, world, n, n * stride / 1e9, n, stride, args.seed))
+    if args.rehearse_on_one_gpu:
+        wl = "REHEARSAL: %d contexts share GPU 0 -- exercises the threads launch, not a scaling number; " % world + wl
+    dp = [x["kernels_ms_per_step"].get("dp") for x in res]
+    line = {"metric": "reads/sec filtered (300 bp synthetic)", "value": n * world * steps / dt, "unit": "reads/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "settle_steps": settle, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "launch": "threads",
+            "fell_back_from": os.environ.get("BENCH_FELL_BACK_FROM"),
+            "config": {"workload": wl, "reads_per_gpu": n, "read_length": L, "row_stride": stride,
+                       "parallelism": "host-side split, %d device threads of one process, no data-path collective" % world,
+                       "collective_backend": "none (one process: the pass / fail totals are summed on the host)",
+                       "world_size": world, "mode": "fast_fma (NOT bit-exact)" if args.fast_fma else "bit-exact (no FMA)"},
+            "weak_scaling_anchor": "every GPU holds %d reads; the N = 1 point of this curve is `python bench.py --gpus 1 --reads %d` "
+                                   "(= extras.config4_shard of the plain N = 1 line)" % (n, n),
+            "devices": ["thread %d: GPU %d pci %s" % (r, x["device"], x["pci_bus_id"]) for r, x in enumerate(res)],
+            "timed_region_s": dt, "t_step_rank_uniform_s": plan["t_step"],
+            "reads_per_s_per_rank": [n * steps / t for t in dts],
+            "per_rank": [{"kernels_ms_per_step": x["kernels_ms_per_step"], "held_clock": x["held_clock"]} for x in res],
+            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "k_dp",
+                         "algorithmic_bytes_per_launch": (L + 13) * n,
+                         "avg_launch_ms": (sum(dp) / len(dp)) if all(dp) else None,
+                         "achieved": ((L + 13) * n / (sum(dp) / len(dp)) / 1e6) if all(dp) else None,
+                         "frac": ((L + 13) * n / (sum(dp) / len(dp)) / 1e6 / HBM_PEAK_GBS) if all(dp) else None,
+                         "frac_whole_step": (L + 13) * n * world / (dt / steps) / 1e9 / HBM_PEAK_GBS / world, "traffic": None},
+            "outcome": {"pass": sum(x["pass"] for x in res), "fail": sum(x["fail"] for x in res),
+                        "overflow_reruns": sum(x["overflow"] for x in res)}}
+    print(json.dumps(line))
+    sys.stdout.flush()
+    return 0
+
+
 def plan_steps(t_step_max, steps_arg, warmup):
     """(steps, settle) from the RANK-UNIFORM step time (the max over ranks) -- plain arithmetic, so that every rank
     takes the same branches and issues the same collectives (a collective under a rank-local condition
@@ -425,6 +638,11 @@ def main():
     ap.add_argument("--rehearse-on-cpu", action="store_true",
                     help="multi-rank dry run without any GPU: the step is a stub; exercises launch + collectives only")
     ap.add_argument("--no-rccl", action="store_true", help="do not try RCCL for the 24-byte totals (gloo only)")
+    ap.add_argument("--launch", choices=["auto", "processes", "threads"], default="auto",
+                    help="N > 1: `processes` = one rank per GPU under torch.distributed.run (the driver's shape); `threads` = N "
+                         "contexts on N host threads of ONE fresh process, no launcher, no collective (SURVEY 8e: 'one host "
+                         "thread (or process) + one HIP stream per device'); `auto` = processes, and threads when the "
+                         "process job ends non-zero without having printed its line")
     ap.add_argument("--rccl-selftest", action="store_true",
                     help="N = 1 only: before the run, bring up a ONE-rank gloo + RCCL group on this GPU and do the 24-byte "
                          "all-reduce on it (under the same deadline as an N > 1 run); reported as `rccl_selftest`")
@@ -434,10 +652,12 @@ def main():
     args = ap.parse_args()
     rehearsal = args.rehearse_on_one_gpu or args.rehearse_on_cpu
 
+    if args.launch == "threads" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return threads_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-            sys.exit(self_launch(args.gpus, rehearsal))
+            sys.exit(self_launch(args.gpus, rehearsal, fall_back_to_threads=(args.launch == "auto" and not args.rehearse_on_cpu)))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
@@ -503,7 +723,8 @@ def main():
     device_sync()
     if rank == args._die_rank:
         os._exit(3)                                      # tests: a rank that dies must fail the whole job, promptly
-    # ---- the timed region: no events, no host round trips ----
+    # ---- the timed region: no events, no host round trips (a host thread reads the device's clock from sysfs meanwhile) ----
+    clock = ClockSampler(pci_bus_id_of(local_rank) if use_gpu else None).start()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -512,6 +733,7 @@ def main():
     dt_rank = time.perf_counter() - t0                   # this rank's own time, before it waits for the others
     barrier()
     dt = coll.allmax(time.perf_counter() - t0)
+    held_clock = clock.stop()
     per_rank = [n * steps / t for t in coll.gather_floats(dt_rank)]
     counts = step(counts=True)
     n_pass, n_fail, n_ovf = coll.sum_totals((counts.n_pass, counts.n_fail, counts.n_overflow))
@@ -540,6 +762,10 @@ def main():
     eng.synchronize()
     times = eng.kernel_times()
     eng.timing(False)
+    # every rank's own kernel times and held clock, so that a throttled GPU shows in the line (fixed-width text, nothing pickled)
+    mine = {"k": {k: round(v[0] / max(v[1], 1), 4) for k, v in times.items() if v[1]},
+            "mhz": [round(held_clock[x]) for x in ("mean_mhz", "min_mhz", "max_mhz")] if held_clock else None}
+    per_rank_text = coll.gather_text(json.dumps(mine, separators=(",", ":")), width=480)
     hist = eng.class_histogram()
     # one more pass, untimed, that also sums the algorithmic DP cells on the device (fp64_valu.frac_algorithmic)
     prm_cells = eng.params(alpha=0.005, uncert=0.01, ambigs="treat_as_errors", fast_fma=args.fast_fma, count_cells=True)
@@ -675,6 +901,8 @@ def main():
             "timed_region_s": dt,
             "t_step_rank_uniform_s": t_step,
             "reads_per_s_per_rank": per_rank,
+            "launch": "processes" if world > 1 else "single process",
+            "per_rank": [_decode_rank(t) for t in per_rank_text],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "bytes per k_dp launch (PMC, profiles/pmc_traffic.json)",
@@ -959,6 +1187,17 @@ def config4_shard_rate(eng, L, stride, seed, params, n=CONFIG4_SHARD, rank=3):
     return out
 
 
+def _decode_rank(text):
+    """one rank's {"k": kernel ms per step, "mhz": [mean, min, max] held clock} as gathered by Collectives.gather_text"""
+    try:
+        d = json.loads(text)
+        mhz = d.get("mhz")
+        return {"kernels_ms_per_step": d.get("k"),
+                "held_clock": {"mean_mhz": mhz[0], "min_mhz": mhz[1], "max_mhz": mhz[2]} if mhz else None}
+    except ValueError:
+        return {"undecodable": text}
+
+
 def _wall_rate(eng, run, seconds=0.6, settle_s=0.5):
     """ms per call of `run` (asynchronous calls back to back, one synchronisation at the end) after `settle_s` of untimed calls."""
     run(); eng.synchronize()
@@ -1197,4 +1436,4 @@ def host_fed_rate(eng, L, stride, seed, n=8_000_000):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -380,6 +380,15 @@ int mpb_broker_detach(mpb_broker_client *client);
 int mpb_broker_shutdown(const char *name);
 int mpb_broker_stats(const char *name, int64_t *served, int64_t *batches, int64_t *solo, int32_t *pid, int32_t *attached);
 
+/* NUMA placement (round 5).  Each shard thread of mpb_filter_host_multi restricts itself, before its pipeline starts, to the
+ * CPUs of the NUMA node its GPU hangs off -- /sys/bus/pci/devices/<bus id>/numa_node, /sys/devices/system/node/node<k>/cpulist,
+ * intersected with what the process may use -- so that the pinned staging blocks it allocates and first touches, and the threads
+ * that copy a pageable input into them, are node-local (8 GPUs fed from one socket do not scale).  No NUMA information, or
+ * MOIRA_PB_NO_NUMA in the environment: threads stay where they are.  mpb_numa_cpulist_for_pci is that lookup, host-only
+ * (sysfs_root "" or NULL = the real tree; a directory holding a copy of the two files for tests): *node_out = the node or -1,
+ * cpulist_out = its CPU list as sysfs prints it ("0-47,96-143"). */
+int mpb_numa_cpulist_for_pci(const char *sysfs_root, const char *pci_bus_id, int32_t *node_out, char *cpulist_out, int32_t cpulist_len);
+
 /* ---- --error_calc poisson -------------------------------------- */
 /*
  * Poisson approximation, ref: moira/moira.py:1637-1679 (calculate_errors_poisson).

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "mpb_shard_bounds": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mpb_filter_host_multi": (C.c_int, [_VP, C.c_int32, _VP, C.c_int64, C.c_int64, _VP, C.c_int32,
                                         C.POINTER(FilterParams), _VP, _VP, _VP, C.POINTER(FilterCounts), C.c_int32]),
+    "mpb_numa_cpulist_for_pci": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_int32]),
     "mpb_calculate_errors_PB": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int32, C.c_double,
                                           C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mpb_calculate_errors_poisson": (C.c_int, [_VP, C.c_char_p, _VP, C.c_int32, C.c_double,

@@ -9,7 +9,9 @@
 #include "mpb_internal.h"
 #include "mpb_host_internal.h"
 
+#include <sched.h>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -1767,6 +1769,95 @@ int mpb_calculate_errors_poisson(mpb_ctx *c, const char *sequence, const int32_t
 // order with no copy and no exchange step.  Every context keeps its own streams, slots and workspace (contexts are
 // independent: tests/test_gpu_parity.py::test_two_contexts_from_two_threads); a host-fed caller thereby drives one
 // PCIe link per GPU from one process -- what moira's `Pool(args.processors)` (moira/moira.py:398-399) was for.
+// ---- NUMA placement of a shard's host thread (8 x 55 GB/s out of one socket does not scale) ------------------
+// The PCI device of a GPU says which NUMA node it hangs off (/sys/bus/pci/devices/<id>/numa_node) and the node says which CPUs
+// are its own (/sys/devices/system/node/node<k>/cpulist).  A shard thread of mpb_filter_host_multi restricts itself to those
+// CPUs before it starts its pipeline: the pinned staging blocks of its slots are then allocated and first touched from that
+// node, and the threads that copy a pageable input into them inherit the mask.  `sysfs_root` ("" = the real one) exists for
+// the parser's test.  node -1 (no NUMA information, one node, a container that hides it) leaves the thread where it is.
+static bool read_small_file(const char *path, char *buf, size_t len)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    const size_t k = fread(buf, 1, len - 1, f);
+    fclose(f);
+    buf[k] = 0;
+    return k > 0;
+}
+
+// "0-7,16-23,40" -> cpu_set; false on anything else
+static bool parse_cpulist(const char *s, cpu_set_t *set, int *count)
+{
+    CPU_ZERO(set);
+    int n = 0;
+    const char *p = s;
+    while (*p && *p != '\n') {
+        char *end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p || a < 0) return false;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            if (end == p + 1 || b < a) return false;
+            p = end;
+        }
+        for (long c = a; c <= b; c++)
+            if (c < CPU_SETSIZE) { CPU_SET((int)c, set); n++; }
+        if (*p == ',') p++;
+        else if (*p && *p != '\n') return false;
+    }
+    if (count) *count = n;
+    return n > 0;
+}
+
+int mpb_numa_cpulist_for_pci(const char *sysfs_root, const char *pci_bus_id, int32_t *node_out, char *cpulist_out, int32_t cpulist_len)
+{
+    if (!pci_bus_id || !node_out) return fail(MPB_E_INVALID, "mpb_numa_cpulist_for_pci: NULL argument");
+    const char *root = sysfs_root ? sysfs_root : "";
+    char path[512], buf[4096], id[64];
+    // HIP prints the bus id in upper-case hex ("0000:C1:00.0"); sysfs names are lower-case
+    size_t k = 0;
+    for (; pci_bus_id[k] && k + 1 < sizeof(id); k++) id[k] = (char)tolower((unsigned char)pci_bus_id[k]);
+    id[k] = 0;
+    *node_out = -1;
+    if (cpulist_out && cpulist_len > 0) cpulist_out[0] = 0;
+    snprintf(path, sizeof(path), "%s/sys/bus/pci/devices/%s/numa_node", root, id);
+    if (!read_small_file(path, buf, sizeof(buf))) return MPB_OK;          // no such file: no NUMA information
+    char *end = nullptr;
+    const long node = strtol(buf, &end, 10);
+    if (end == buf || node < 0) return MPB_OK;                               // "-1": the platform does not say
+    snprintf(path, sizeof(path), "%s/sys/devices/system/node/node%ld/cpulist", root, node);
+    if (!read_small_file(path, buf, sizeof(buf))) return MPB_OK;
+    cpu_set_t set;
+    int cnt = 0;
+    if (!parse_cpulist(buf, &set, &cnt)) return fail(MPB_E_INVALID, "cannot parse %s: '%s'", path, buf);
+    *node_out = (int32_t)node;
+    if (cpulist_out && cpulist_len > 0) {
+        snprintf(cpulist_out, (size_t)cpulist_len, "%s", buf);
+        for (char *q = cpulist_out; *q; q++) if (*q == '\n') *q = 0;
+    }
+    return MPB_OK;
+}
+
+// restrict the calling thread to the CPUs of `c`'s GPU's NUMA node that this process may use; returns the node or -1 (not moved)
+static int pin_thread_near_device(const mpb_ctx *c)
+{
+    if (getenv("MOIRA_PB_NO_NUMA")) return -1;
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c->device) != hipSuccess) return -1;
+    int32_t node = -1;
+    char list[4096];
+    if (mpb_numa_cpulist_for_pci("", bus, &node, list, (int32_t)sizeof(list)) != MPB_OK || node < 0) return -1;
+    cpu_set_t near, allowed, both;
+    if (!parse_cpulist(list, &near, nullptr)) return -1;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return -1;
+    CPU_AND(&both, &near, &allowed);
+    if (CPU_COUNT(&both) == 0) return -1;                                    // the cgroup grants nothing on that node: stay
+    if (sched_setaffinity(0, sizeof(both), &both) != 0) return -1;
+    return node;
+}
+
 int mpb_shard_bounds(int64_t n, int32_t world, int32_t rank, int64_t *lo, int64_t *hi)
 {
     if (n < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return fail(MPB_E_INVALID, "mpb_shard_bounds: bad arguments");
@@ -1794,6 +1885,11 @@ int mpb_filter_host_multi(mpb_ctx *const *ctxs, int32_t n_ctx, const uint8_t *q,
     auto work = [&](int r) {
         Shard &S = sh[(size_t)r];
         const int64_t m = S.hi - S.lo;
+        // the shard's thread (and the copy threads it starts, and the pinned blocks it first touches) next to its GPU; the
+        // calling thread (shard 0, and shards that got no thread) gets its own mask back afterwards
+        cpu_set_t before;
+        const bool have_before = n_ctx > 1 && sched_getaffinity(0, sizeof(before), &before) == 0;
+        if (n_ctx > 1) (void)pin_thread_near_device(ctxs[r]);
         const uint8_t *qs = q ? q + S.lo * row_stride : q;
         const int32_t *ls = len ? len + S.lo : nullptr;
         if (poisson)
@@ -1803,6 +1899,7 @@ int mpb_filter_host_multi(mpb_ctx *const *ctxs, int32_t n_ctx, const uint8_t *q,
             S.rc = mpb_filter_host(ctxs[r], qs, m, row_stride, ls, fixed_len, params, ee ? ee + S.lo : ee,
                                    ns ? ns + S.lo : ns, pass ? pass + S.lo : pass, &S.c);
         if (S.rc != MPB_OK) snprintf(S.err, sizeof(S.err), "%s", g_err);      // g_err is thread-local: carry it out
+        if (have_before) (void)sched_setaffinity(0, sizeof(before), &before);
     };
     std::vector<std::thread> th;
     int started = 1;                                   // shard 0 runs on the calling thread

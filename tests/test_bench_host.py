@@ -34,7 +34,7 @@ def test_plain_command_starts_its_ranks_as_a_child(monkeypatch):
     monkeypatch.setattr(bench.subprocess, "call", fake_call)
     monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: Probe())
     monkeypatch.delenv("WORLD_SIZE", raising=False)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5", "--launch", "processes"])
     torch_loaded_before = "torch" in sys.modules
     with pytest.raises(SystemExit) as e:
         bench.main()
@@ -43,7 +43,7 @@ def test_plain_command_starts_its_ranks_as_a_child(monkeypatch):
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
-    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert cmd[-9:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--launch", "processes"]
     assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
     if not torch_loaded_before:
         assert "torch" not in sys.modules                           # nothing GPU-capable was imported in the parent
@@ -166,3 +166,33 @@ def test_config3_extras_host_stages_run_without_a_gpu():
     assert NoGpu.calls == 1 + 1 + 3 + 3                                # warm-up of the slots, untimed chunk, two passes
     assert r["pipelined"]["pairs_per_s"] > 0 and r["projected_wall_s_for_100M_pairs"] > 0
     assert set(r["stage_pairs_per_s"]) == {"index_both_files", "contig_construction", "pack", "gpu_filter_incl_pcie"}
+
+
+def test_a_failed_process_launch_is_retried_as_threads_in_a_fresh_child():
+    """`python bench.py --gpus N` (launch auto).  The process job dies before printing anything (here: a launcher
+    that exits 7 at once) -> the SAME measurement is started once more as `--launch threads`, in another fresh child; the parent
+    never touches the GPU.  Without a GPU that second child can only say so -- which is what shows that it was started."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BENCH_FAKE_LAUNCHER_FAILURE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--reads", "1000",
+                        "--steps", "2", "--warmup", "1", "--no-extras"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert "fake launcher failure" in p.stderr
+    assert "ended with code 7 before it printed a result" in p.stderr and "--launch threads" in p.stderr
+    import moira_amd._lib as L
+    if L.load().mpb_device_count() == 0:
+        assert p.returncode != 0 and "needs an MI355X" in p.stderr          # the threads child ran, and has no GPU here
+    # with --launch processes nothing is retried
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--reads", "1000",
+                         "--launch", "processes"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p2.returncode == 7 and "--launch threads" not in p2.stderr
+
+
+def test_held_clock_is_read_from_the_line_with_the_asterisk():
+    bench = load_bench()
+    assert bench.ClockSampler.parse("0: 500Mhz \n1: 2396Mhz *\n2: 2400Mhz\n") == 2396
+    assert bench.ClockSampler.parse("S: 94Mhz *\n0: 500Mhz\n1: 2400Mhz\n") == 94
+    assert bench.ClockSampler.parse("0: 500Mhz\n") is None
+    s = bench.ClockSampler(None).start()
+    assert s.stop() is None                                  # no device path: nothing sampled, nothing raised
+    assert bench._decode_rank('{"k":{"dp":3.1},"mhz":[2010,1990,2100]}') == {
+        "kernels_ms_per_step": {"dp": 3.1}, "held_clock": {"mean_mhz": 2010, "min_mhz": 1990, "max_mhz": 2100}}

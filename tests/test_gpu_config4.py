@@ -157,6 +157,57 @@ def test_bench_four_rank_rehearsal_on_one_gpu():
     assert "--gpus 1 --reads 2000000" in line["weak_scaling_anchor"]      # which N = 1 run anchors this curve
 
 
+def test_bench_threads_mode_four_contexts_on_one_gpu():
+    """the launcher-free N > 1 measurement -- N contexts on N host threads of ONE process, device-resident
+    shards, no collective.  Four contexts share this box's one GPU; the line must carry what a reader of SCALE needs to spot
+    a slow GPU: every thread's own rate, per-device kernel times and the clock the device held."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch", "threads", "--rehearse-on-one-gpu",
+                        "--reads", "2000000", "--steps", "6", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["launch"] == "threads" and line["n_gpus"] == 4 and line["steps"] == 6 and line["scaling"] == "weak"
+    assert line["config"]["reads_per_gpu"] == 2000000 and "configs[3]" in line["config"]["workload"]
+    assert len(line["reads_per_s_per_rank"]) == 4 and all(v > 0 for v in line["reads_per_s_per_rank"])
+    assert line["outcome"]["pass"] + line["outcome"]["fail"] == 8_000_000
+    assert len(line["per_rank"]) == 4
+    for r in line["per_rank"]:
+        assert r["kernels_ms_per_step"]["dp"] > 0 and r["kernels_ms_per_step"]["prepass"] > 0
+        assert r["held_clock"] is None or 300 < r["held_clock"]["mean_mhz"] < 3000
+    assert any(r["held_clock"] for r in line["per_rank"]), "no clock samples from sysfs"
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0 and line["fell_back_from"] is None
+    # the four shards are the four read-id ranges of the process-per-GPU run: same totals
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch", "processes", "--rehearse-on-one-gpu",
+                        "--reads", "2000000", "--steps", "2", "--warmup", "1", "--no-extras"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert q.returncode == 0, q.stderr[-2000:]
+    line2 = json.loads([l for l in q.stdout.splitlines() if l.startswith("{")][-1])
+    assert line2["outcome"] == line["outcome"] and line2["launch"] == "processes"
+    assert len(line2["per_rank"]) == 4 and all(r["kernels_ms_per_step"]["dp"] > 0 for r in line2["per_rank"])
+
+
+def test_bench_falls_back_to_threads_when_the_process_launch_fails():
+    """... and `auto` takes it by itself when the process job ends non-zero before printing its line (here: a launcher that
+    dies at once): a fresh child, the same arguments, the same JSON line with "launch": "threads"."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BENCH_FAKE_LAUNCHER_FAILURE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--reads", "300000",
+                        "--steps", "3", "--warmup", "1", "--no-extras"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["launch"] == "threads" and "exit code 7" in line["fell_back_from"] and line["n_gpus"] == 2
+    assert line["outcome"]["pass"] + line["outcome"]["fail"] == 600000
+
+
 def test_config2_size_order_invariance(eng):
     """A size-independent property at BASELINE config 2's full size, with no oracle in the loop: a read's result
     does not depend on where it sits in the batch.  Batch B holds the same 10 M reads as batch A rotated by 3.7 M

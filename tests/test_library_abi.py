@@ -254,3 +254,34 @@ def test_python2_form_of_the_dropin_parses_as_python2_and_checks_its_arguments()
     with pytest.raises(ValueError, match="same length"):
         mod.calculate_errors_PB("AC", [30], 0.005)
     assert mod.calculate_errors is mod.calculate_errors_PB
+
+
+def test_numa_lookup_parses_the_sysfs_files(tmp_path):
+    """a shard thread of mpb_filter_host_multi pins itself to the CPUs of its GPU's NUMA node.  The lookup --
+    PCI bus id (upper-case hex, as HIP prints it) -> numa_node -> cpulist -- against a copy of the two sysfs files."""
+    lib = L.load()
+    root = tmp_path
+    for bus, node in (("0000:c1:00.0", "1\n"), ("0000:05:00.0", "0\n"), ("0000:85:00.0", "-1\n")):
+        d = root / "sys/bus/pci/devices" / bus
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(node)
+    for node, cpus in ((0, "0-47,96-143\n"), (1, "48-95,144-191\n")):
+        d = root / "sys/devices/system/node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus)
+
+    def look(bus, r=str(root)):
+        node, buf = C.c_int32(-7), C.create_string_buffer(256)
+        rc = lib.mpb_numa_cpulist_for_pci(r.encode(), bus.encode(), C.byref(node), buf, 256)
+        return rc, node.value, buf.value.decode()
+
+    assert look("0000:C1:00.0") == (0, 1, "48-95,144-191")
+    assert look("0000:05:00.0") == (0, 0, "0-47,96-143")
+    assert look("0000:85:00.0") == (0, -1, "")             # the platform does not say
+    assert look("0000:FF:00.0") == (0, -1, "")             # no such device: no information, not an error
+    (root / "sys/devices/system/node/node0/cpulist").write_text("0-47,x\n")
+    rc, node, _ = look("0000:05:00.0")
+    assert rc == L.E_INVALID and node == -1 and b"cannot parse" in lib.mpb_last_error()
+    # the real tree: never an error, whatever this machine exposes
+    rc, node, cpus = look("0000:00:00.0", "")
+    assert rc == 0 and node >= -1
