@@ -953,14 +953,16 @@ def main():
     coll.close()
 
 
-def config3_paired_rate(eng, pairs_per_chunk=1_000_000, chunks=4):
+def config3_paired_rate(eng, pairs_per_chunk=1_000_000, chunks=4, stage_chunks=None):
     """BASELINE configs[2] ("100M 2x300 bp paired reads, NW contig on CPU then GPU filter") at a size a bench run can
     afford: `chunks` x `pairs_per_chunk` synthetic 2 x 300-base pairs (450-base fragments: 150 bases of overlap) as FASTQ
     TEXT IN MEMORY -> record index -> contig construction on the host cores (mothur-style NW + consensus, the build's own
     libmoira_contig.so; north_star keeps it on the CPU; ref: moira/moira.py:789-801, moira/nw_align.pyx:49-201) -> pack ->
     GPU filter from host memory.  Stage rates from a pass with the stages one after the other; the end-to-end rate from a
     pass in which index + contigs of chunk k+1 run on a second thread while chunk k is packed and filtered (what the CLI
-    does).  The same chunk of text is processed `chunks` times (its content does not change what any stage costs)."""
+    does).  The same chunk of text is processed `chunks` times (its content does not change what any stage costs).
+    stage_chunks: chunks of the one-after-the-other pass (default: all of them; tools/config3_full.py streams 100 chunks through
+    the pipelined pass and takes the stage rates from 4)."""
     import threading
     import numpy as np
     from moira_amd import contig as CT, fastio as F
@@ -1016,7 +1018,8 @@ def config3_paired_rate(eng, pairs_per_chunk=1_000_000, chunks=4):
     t_index = t_contig = t_pack = t_filter = 0.0
     kept = 0
     t_all = time.perf_counter()
-    for k in range(chunks):
+    n_stage = chunks if stage_chunks is None else max(1, min(chunks, stage_chunks))
+    for k in range(n_stage):
         t0 = time.perf_counter()
         cb, t_c0 = front(k)
         t1 = time.perf_counter()
@@ -1045,20 +1048,21 @@ def config3_paired_rate(eng, pairs_per_chunk=1_000_000, chunks=4):
         kept2 += back(cb)[0]
     pipe_wall = time.perf_counter() - t_all
     total = n * chunks
-    assert kept2 == kept
+    stage_total = n * n_stage
+    assert kept2 * n_stage == kept * chunks
     rate = total / pipe_wall
     return {"note": "BASELINE configs[2] at bench size: synthetic 2 x 300-base pairs (150 bases of overlap) as FASTQ text in host "
                     "memory -> index -> NW + consensus on the host cores (north_star keeps contig construction on the CPU) -> "
                     "pack -> GPU filter from host memory; NOT the headline (it is bound by the host stages, not by the GPU)",
             "pairs": total, "chunks": chunks, "host_threads": threads, "mean_contig_length": mean_len,
-            "contigs_kept": kept,
-            "stage_pairs_per_s": {"index_both_files": total / t_index, "contig_construction": total / t_contig,
-                                  "pack": total / t_pack, "gpu_filter_incl_pcie": total / t_filter},
-            "stages_one_after_the_other": {"wall_s": seq_wall, "pairs_per_s": total / seq_wall},
+            "contigs_kept": kept2,
+            "stage_pairs_per_s": {"index_both_files": stage_total / t_index, "contig_construction": stage_total / t_contig,
+                                  "pack": stage_total / t_pack, "gpu_filter_incl_pcie": stage_total / t_filter},
+            "stages_one_after_the_other": {"wall_s": seq_wall, "pairs_per_s": stage_total / seq_wall, "pairs": stage_total},
             "pipelined": {"wall_s": pipe_wall, "pairs_per_s": rate,
                           "note": "index + contigs of chunk k+1 on a second thread while chunk k is packed and filtered"},
             "projected_wall_s_for_100M_pairs": 1e8 / rate,
-            "gpu_share_of_the_pipelined_wall": t_filter / pipe_wall}
+            "gpu_share_of_the_pipelined_wall": (t_filter / n_stage * chunks) / pipe_wall}
 
 
 def classified_rate(eng, d_q, n, stride, L, params, d_ee, d_ns, d_pass):

@@ -1,10 +1,11 @@
 """BASELINE configs[3]: "1 B synthetic 300 bp reads sharded host-side across 8 x MI355X" -- what ONE GPU of
 that job does: a 125 M-read shard (40 GB resident, generated on the device from the counter-based
-generator, read ids first_read..).  Round 4: EVERY read of the shard is compared bit for bit with the oracle (the
-matrix comes back from HBM 5 M rows at a time; about 25 s of oracle on the 16 cores a GPU box grants), next to the
-size-independent properties (determinism, pass count == sum of flags == threshold test on ee, no NaN) and 100
-windows regenerated on the host (the device generator wrote what the host generator writes); and the host-side
-split itself (a shard == the same slice of the unsplit batch) is checked at a size the oracle covers."""
+generator, read ids first_read..).  Round 5: all EIGHT shards of the 1 B-read job run on the one GPU, one after the other;
+shards 0 and 7 are compared with the oracle in full and 10 M contiguous reads of each of the others (the matrix comes back
+from HBM 5 M rows at a time), next to the size-independent properties (determinism, pass count == sum of flags ==
+threshold test on ee, no NaN) and windows regenerated on the host (the device generator wrote what the host generator
+writes); and the host-side split itself (a shard == the same slice of the unsplit batch) is checked at a size the oracle
+covers."""
 import numpy as np
 import pytest
 
@@ -23,36 +24,49 @@ def eng():
     e.close()
 
 
-def test_config4_one_shard_of_125M(eng, oracle):
+def test_config4_all_eight_shards_at_their_stated_size(eng, oracle):
+    """BASELINE configs[3] at its stated size, on one GPU: the EIGHT 125 M-read shards of the 1 B-read job
+    (read ids r * 125 M ..), generated and filtered one after the other in the same 40 GB of HBM.  Shards 0 and 7 are compared
+    with the oracle in full, 10 M contiguous reads of each of the other six (310 M reads in all); every shard also gets the
+    size-independent checks (pass count == sum of flags == threshold test on ee, no NaN) and host-regenerated windows
+    (the device generator wrote what the host generator writes for THOSE read ids); shard 0 is run twice (deterministic)."""
+    from test_gpu_parity import compare_every_read
+    from conftest import note_parity
     n, stride, L, seed = 125_000_000, 320, 300, 2
-    rank = 5                                              # any of the 8 shards: read ids 625 M .. 750 M
-    first = rank * n
     d_q, d_ee, d_ns, d_pass = eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
+    compared, passed = 0, 0
     try:
-        eng.synth_fill(d_q, n, stride, fixed_len=L, seed=seed, first_read=first)
-        c1 = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
-        ee1 = d_ee.download(np.float64, n)
-        ps1 = d_pass.download(np.uint8, n)
-        ns1 = d_ns.download(np.int32, n)
-        c2 = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
-        assert same(d_ee.download(np.float64, n), ee1)                      # deterministic
-        assert np.array_equal(d_pass.download(np.uint8, n), ps1)
-        assert (c1.n_reads, c1.n_pass, c1.n_overflow) == (n, c2.n_pass, c2.n_overflow)
-        assert c1.n_pass == int(ps1.sum(dtype=np.int64)) and c1.n_fail == n - c1.n_pass
-        assert not np.isnan(ee1).any()
-        assert np.array_equal(ps1.astype(bool), ee1 <= L * 0.01)            # the predicate, recomputed
-        from test_gpu_parity import compare_every_read
-        assert compare_every_read(eng, oracle, d_q, n, stride, ee1, ns1, ps1, fixed_len=L, step=5_000_000,
-                                  label="config 4, shard %d of 8 (125 M reads)" % rank) == n
         rng = np.random.default_rng(4)
-        starts = rng.integers(0, n - 64, 100)
-        starts[:2] = (0, n - 64)
-        for start in starts:
-            hq, _ = oracle.synth_fill(64, stride, fixed_len=L, seed=seed, first_read=first + int(start))
-            assert np.array_equal(d_q.download(np.uint8, 64 * stride, offset=int(start) * stride).reshape(64, stride), hq)
+        for rank in range(8):
+            first = rank * n
+            eng.synth_fill(d_q, n, stride, fixed_len=L, seed=seed, first_read=first)
+            c1 = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+            ee1, ps1, ns1 = d_ee.download(np.float64, n), d_pass.download(np.uint8, n), d_ns.download(np.int32, n)
+            assert c1.n_reads == n and c1.n_pass == int(ps1.sum(dtype=np.int64)) and c1.n_fail == n - c1.n_pass
+            assert not np.isnan(ee1).any()
+            assert np.array_equal(ps1.astype(bool), ee1 <= L * 0.01)            # the predicate, recomputed
+            passed += c1.n_pass
+            if rank == 0:
+                c2 = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+                assert same(d_ee.download(np.float64, n), ee1) and (c2.n_pass, c2.n_overflow) == (c1.n_pass, c1.n_overflow)
+            if rank in (0, 7):
+                row0, m = 0, n
+            else:
+                row0, m = int(rng.integers(0, n - 10_000_000)), 10_000_000
+            compared += compare_every_read(eng, oracle, d_q, m, stride, ee1, ns1, ps1, fixed_len=L, step=5_000_000, row0=row0,
+                                           label="config 4, shard %d of 8 (read ids %d ..), rows %d .. %d" % (rank, first, row0, row0 + m - 1))
+            starts = rng.integers(0, n - 64, 12)
+            starts[:2] = (0, n - 64)
+            for start in starts:
+                hq, _ = oracle.synth_fill(64, stride, fixed_len=L, seed=seed, first_read=first + int(start))
+                assert np.array_equal(d_q.download(np.uint8, 64 * stride, offset=int(start) * stride).reshape(64, stride), hq)
+            del ee1, ps1, ns1
     finally:
         for b in (d_q, d_ee, d_ns, d_pass):
             b.free()
+    assert compared == 2 * n + 6 * 10_000_000
+    note_parity("[config 4 at its stated size] 8 shards x 125 M reads generated and filtered on one GPU; %d reads compared bit for bit "
+                "with the oracle (shards 0 and 7 in full); %d of 1,000,000,000 reads pass" % (compared, passed))
 
 
 def test_shards_equal_slices_of_the_unsplit_batch(eng, oracle):

@@ -270,7 +270,7 @@ def test_device_synth_matches_host_and_device_resident_filter(eng, oracle):
         b.free()
 
 
-def compare_every_read(eng, oracle, d_q, n, stride, ee1, ns1, ps1, fixed_len=None, lens=None, step=4_000_000, label=""):
+def compare_every_read(eng, oracle, d_q, n, stride, ee1, ns1, ps1, fixed_len=None, lens=None, step=4_000_000, label="", row0=0):
     """Bit-for-bit comparison of ALL n reads of a resident batch with the oracle (no sampling).  The
     oracle reads the very bytes the GPU filtered: the matrix comes back from HBM a few million rows at a time (that the
     device generator writes what the host generator writes is checked on its own, by test_device_generator_* and by the
@@ -278,8 +278,8 @@ def compare_every_read(eng, oracle, d_q, n, stride, ee1, ns1, ps1, fixed_len=Non
     import time
     threads = oracle.lib().pbo_max_threads()
     t0, done = time.time(), 0
-    for start in range(0, n, step):
-        m = min(step, n - start)
+    for start in range(row0, row0 + n, step):              # rows row0 .. row0 + n - 1 of the resident batch (default: all of it)
+        m = min(step, row0 + n - start)
         hq = d_q.download(np.uint8, m * stride, offset=start * stride).reshape(m, stride)
         if lens is None:
             ee, ns, ps, _ = oracle.filter_batch(hq, fixed_len=fixed_len, threads=threads)
