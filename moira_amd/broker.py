@@ -17,8 +17,10 @@ import array
 import ctypes as C
 import fcntl
 import os
+import stat
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -58,6 +60,29 @@ def marshal_read(contig, contig_quals, alpha):
                 raise TypeError("an integer is required")
             qi[i] = ((v + 0x80000000) & 0xFFFFFFFF) - 0x80000000
         return contig.encode(), qi, qi.ctypes.data, alpha
+
+
+def runtime_dir():
+    """Where this user's start lock and broker log live: $XDG_RUNTIME_DIR when it is this user's own directory, else a 0700
+    directory of this user under /dev/shm (or the temp dir).  ADVICE r4: not a predictable name in a world-writable directory."""
+    d = os.environ.get("XDG_RUNTIME_DIR")
+    if d and os.path.isdir(d) and os.stat(d).st_uid == os.getuid():
+        return d
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    d = os.path.join(base, "moira_pb_%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise L.MoiraPBError("%s is not a private directory of this user" % d)
+    return d
+
+
+def open_private(path, flags):
+    """A file of this user only; a symbolic link in its place is an error, never followed."""
+    return os.open(path, flags | os.O_CREAT | os.O_NOFOLLOW | os.O_CLOEXEC, 0o600)
 
 
 class BrokerGone(L.MoiraPBError):
@@ -120,20 +145,18 @@ def shutdown(name, wait_s=10.0):
         if stats(name) is None:
             break
         time.sleep(0.02)
-    try:                                                   # the start lock of this name (a few bytes in /dev/shm)
-        os.unlink(os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "moira_pb_%s.lock" % name))
-    except OSError:
-        pass
+    # the start lock of this name stays where it is: unlinking it while another process waits on the old inode would give two
+    # starters "the lock" at once; it is an empty file in this user's runtime directory
 
 
 def start(device=0, name=None, slots=64, idle_exit=10.0, log=None):
     """Start `python -m moira_amd.broker` as a fresh child (new session, nothing inherited but the environment)."""
     name = name or default_name(device)
-    log = log or os.path.join(os.environ.get("TMPDIR", "/tmp"), "moira_pb_broker_%s.log" % name)
+    log = log or os.path.join(runtime_dir(), "broker_%s.log" % name)
     env = dict(os.environ)
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     env.pop("MOIRA_PB_BROKER", None)
-    with open(log, "ab") as lf:
+    with os.fdopen(open_private(log, os.O_WRONLY | os.O_APPEND), "ab") as lf:
         return subprocess.Popen([sys.executable, "-m", "moira_amd.broker", "--device", str(int(device)), "--name", name,
                                  "--slots", str(int(slots)), "--idle-exit", str(float(idle_exit))],
                                 cwd=ROOT, env=env, stdin=subprocess.DEVNULL, stdout=lf, stderr=lf,
@@ -148,8 +171,10 @@ def client(device=0, name=None, slots=64, idle_exit=10.0, start_timeout=120.0):
         return BrokerClient(name, 0)
     except (ValueError, L.MoiraPBError):
         pass
-    lock = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "moira_pb_%s.lock" % name)
-    with open(lock, "w") as lk:
+    # one starter at a time (a broker process builds a GPU context before it asks for the name: starting P of them to have
+    # P - 1 refused by mpb_broker_serve -- which IS race-free by itself -- would cost seconds)
+    lock = os.path.join(runtime_dir(), "start_%s.lock" % name)
+    with os.fdopen(open_private(lock, os.O_RDWR), "r+b") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         try:
             try:

@@ -33,10 +33,14 @@
 #include <fcntl.h>
 #include <linux/futex.h>
 #include <new>
+#include <sys/file.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -170,7 +174,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     char *pin_in = nullptr, *pin_out = nullptr, *dev = nullptr;
     size_t in_cap = 0, out_cap = 0, dev_cap = 0;
-    bool busy = false;
+    std::atomic<int> busy{0};   // 0: free (the launch thread may fill it), 1: a launch is out (the retire thread's, when there is one)
     int m = 0;
     int64_t stride = 0;
     int slots[BRK_MAX_SLOTS];
@@ -186,6 +190,31 @@ struct Broker {
     Lane lane[BRK_LANES];
     size_t off_q, off_ee, off_ns, off_pass, off_done, off_cls, off_ident, off_nsdev;   // offsets inside a lane's blocks (n_slots reads)
     bool zero_copy = true;                                             // MPB_BROKER_COPIES=1: stage through HBM with two async copies
+    // What a slot asked for, read ONCE when it goes SUBMITTED -> RUNNING and checked there (the segment is writable by
+    // every client; a worker killed in mid-write, or a buggy one, must not be able to send the one process that serves everybody
+    // into a wild memcpy): everything after that uses these copies, never the slot's own fields.
+    int32_t s_len[BRK_MAX_SLOTS];
+    int32_t s_priv[BRK_MAX_SLOTS];
+    double s_alpha[BRK_MAX_SLOTS];
+    // reads a finished micro-batch hands back (row budget missed): queued by whoever retires, run alone by the launch thread
+    // (calls on one context must not overlap)
+    std::atomic<int> solo_q[BRK_MAX_SLOTS];
+    std::atomic<uint32_t> solo_head{0}, solo_tail{0};
+
+    bool take(int si)                                                  // SUBMITTED -> RUNNING with a checked copy of the request
+    {
+        BrkSlot *s = map.slot(si);
+        const int32_t len = s->len, priv = s->priv;
+        const double alpha = s->alpha;
+        s->state.store(ST_RUNNING, std::memory_order_relaxed);
+        if (len < 0 || len > MPB_MAX_LEN || !(alpha > 0 && alpha < 1) || (priv != 0 && priv != 1)) {
+            mpbi_fail(MPB_E_INVALID, "malformed request in the broker slot (length, alpha or table flag out of range)");
+            finish(si, MPB_E_INVALID, 0, 0, mpb_last_error());
+            return false;
+        }
+        s_len[si] = len; s_priv[si] = priv; s_alpha[si] = alpha;
+        return true;
+    }
 
     int init_lanes()
     {
@@ -218,7 +247,7 @@ struct Broker {
             if (l.pin_in) (void)hipHostFree(l.pin_in);
             if (l.pin_out) (void)hipHostFree(l.pin_out);
             if (l.dev) (void)hipFree(l.dev);
-            l = Lane();
+            l.stream = nullptr; l.pin_in = l.pin_out = l.dev = nullptr;
         }
     }
 
@@ -238,8 +267,9 @@ struct Broker {
         BrkSlot *s = map.slot(si);
         double ee = 0;
         int32_t ns = 0;
-        const int32_t stride = (int32_t)(((s->len > 0 ? s->len : 1) + 15) & ~15);
-        const int rc = mpbi_run_packed_read(ctx, Mapping::row(s), s->len, stride, s->priv ? Mapping::lut(s) : nullptr, s->alpha, &ee, &ns);
+        const int32_t len = s_len[si];
+        const int32_t stride = (int32_t)(((len > 0 ? len : 1) + 15) & ~15);
+        const int rc = mpbi_run_packed_read(ctx, Mapping::row(s), len, stride, s_priv[si] ? Mapping::lut(s) : nullptr, s_alpha[si], &ee, &ns);
         map.hdr()->solo.fetch_add(1, std::memory_order_relaxed);
         finish(si, rc, ee, ns, rc ? mpb_last_error() : nullptr);
     }
@@ -247,14 +277,15 @@ struct Broker {
     int launch(Lane &l, const int *cand, int m, double alpha)
     {
         int32_t maxlen = 1;
-        for (int k = 0; k < m; k++) maxlen = std::max(maxlen, map.slot(cand[k])->len);
+        for (int k = 0; k < m; k++) maxlen = std::max(maxlen, s_len[cand[k]]);
         const int64_t stride = (maxlen + 15) & ~15;
         int32_t *h_len = (int32_t *)l.pin_in;
         uint8_t *h_q = (uint8_t *)l.pin_in + off_q;
         for (int k = 0; k < m; k++) {
             BrkSlot *s = map.slot(cand[k]);
-            h_len[k] = s->len;
-            memcpy(h_q + (size_t)k * stride, Mapping::row(s), (size_t)((s->len + 15) & ~15));     // bytes past len are never looked at
+            const int32_t len = s_len[cand[k]];                       // checked by take(): 0 .. MPB_SMALL_MAX_STRIDE - 1 here
+            h_len[k] = len;
+            memcpy(h_q + (size_t)k * stride, Mapping::row(s), (size_t)((len + 15) & ~15));     // bytes past len are never looked at
             l.slots[k] = cand[k];
         }
         l.m = m; l.stride = stride;
@@ -284,8 +315,8 @@ struct Broker {
             if (rc) return rc;
             BHIP(hipMemcpyAsync(l.pin_out, d_out, off_pass + (size_t)n_slots, hipMemcpyDeviceToHost, l.stream));
         }
-        l.busy = true;
         map.hdr()->batches.fetch_add(1, std::memory_order_relaxed);
+        l.busy.store(1, std::memory_order_release);                   // everything above is the retiring thread's from here on
         return MPB_OK;
     }
 
@@ -313,23 +344,101 @@ struct Broker {
         const double *ee = (const double *)(l.pin_out + off_ee);
         const int32_t *ns = (const int32_t *)(l.pin_out + off_ns);
         const uint8_t *pass = (const uint8_t *)(l.pin_out + off_pass);
-        l.busy = false;
         for (int k = 0; k < l.m; k++) {
-            if (pass[k] == 2) run_solo(l.slots[k]);            // row budget missed (or more than 1024 rows): the ordinary per-read path
-            else finish(l.slots[k], MPB_OK, ee[k], ns[k], nullptr);
+            if (pass[k] == 2) {                                // row budget missed (or more than 1024 rows): the ordinary per-read path,
+                const uint32_t t = solo_tail.load(std::memory_order_relaxed);      // on the launch thread
+                solo_q[t % BRK_MAX_SLOTS].store(l.slots[k], std::memory_order_relaxed);
+                solo_tail.store(t + 1, std::memory_order_release);
+            } else finish(l.slots[k], MPB_OK, ee[k], ns[k], nullptr);
+        }
+        l.busy.store(0, std::memory_order_release);
+    }
+
+    bool run_queued_solos()
+    {
+        bool any = false;
+        for (;;) {
+            const uint32_t h = solo_head.load(std::memory_order_relaxed);
+            if (h == solo_tail.load(std::memory_order_acquire)) return any;
+            run_solo(solo_q[h % BRK_MAX_SLOTS].load(std::memory_order_relaxed));
+            solo_head.store(h + 1, std::memory_order_release);
+            any = true;
         }
     }
 
     void fail_lane(Lane &l, int rc)
     {
-        l.busy = false;
         for (int k = 0; k < l.m; k++) finish(l.slots[k], rc, 0, 0, mpb_last_error());
+        l.busy.store(0, std::memory_order_release);
     }
 };
 
 }  // namespace
 
 extern "C" {
+
+// Same object?  (the name may have been unlinked and created again while somebody waited for a lock on the old one)
+static bool same_object(int fd, const char *path)
+{
+    struct stat a, b;
+    const int fd2 = shm_open(path, O_RDWR, 0600);
+    if (fd2 < 0) return false;
+    const bool same = fstat(fd, &a) == 0 && fstat(fd2, &b) == 0 && a.st_ino == b.st_ino && a.st_dev == b.st_dev;
+    close(fd2);
+    return same;
+}
+
+// The segment of `path`, ours: created, sized, header written (pid, BS_STARTING; magic still 0) -- all of it under an exclusive
+// flock on the object itself, so that of any number of brokers started at the same moment exactly one gets through (ADVICE r4,
+// the C entry no longer relies on the Python starter's lock file).  Whoever holds the lock and finds
+//   - a header whose pid is alive and whose state is not BS_EXITING (starting or serving): leaves it alone -> MPB_E_INVALID;
+//   - anything else of non-zero size (a dead broker's segment, one that is on its way out): unlinks the NAME and starts over
+//     with a fresh object -- processes still attached to the old one keep their mapping and find its pid dead;
+//   - an empty object: initialises it.
+// The descriptor stays open (and unlocked) for the broker's lifetime: leaving, it unlinks the name only if it still names this
+// object (a successor may have replaced it while this broker was on its way out).
+static int claim_segment(const char *path, size_t bytes, int32_t n_slots, int device, int *fd_out, void **base_out)
+{
+    for (int attempt = 0; attempt < 100; attempt++) {
+        const int fd = shm_open(path, O_RDWR | O_CREAT, 0600);
+        if (fd < 0) return mpbi_fail(MPB_E_INVALID, "cannot open or create the broker segment");
+        if (flock(fd, LOCK_EX) != 0) { close(fd); return mpbi_fail(MPB_E_INVALID, "cannot lock the broker segment"); }
+        if (!same_object(fd, path)) { close(fd); continue; }            // replaced while we waited: look again
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); return mpbi_fail(MPB_E_INVALID, "cannot stat the broker segment"); }
+        if ((size_t)st.st_size >= sizeof(BrkHeader)) {
+            void *p = mmap(nullptr, sizeof(BrkHeader), PROT_READ, MAP_SHARED, fd, 0);
+            bool live = false;
+            if (p != MAP_FAILED) {
+                const BrkHeader *h = (const BrkHeader *)p;
+                const int opid = h->pid.load();
+                live = h->state.load() != BS_EXITING && pid_alive(opid) && opid != (int)getpid();
+                munmap(p, sizeof(BrkHeader));
+            }
+            if (live) { close(fd); return mpbi_fail(MPB_E_INVALID, "a broker of this name is already serving (or starting)"); }
+            shm_unlink(path);                                            // a corpse: the name goes, a fresh object comes
+            close(fd);
+            continue;
+        }
+        if (st.st_size != 0) { shm_unlink(path); close(fd); continue; } // a half-sized leftover
+        if (ftruncate(fd, (off_t)bytes) != 0) { shm_unlink(path); close(fd); return mpbi_fail(MPB_E_NOMEM, "cannot size the broker segment"); }
+        void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (p == MAP_FAILED) { shm_unlink(path); close(fd); return mpbi_fail(MPB_E_NOMEM, "mmap of the broker segment failed"); }
+        BrkHeader *h = new (p) BrkHeader();         // ftruncate zero-filled the pages: every slot is free and idle
+        h->n_slots = n_slots;
+        h->slot_bytes = (int32_t)SLOT_BYTES;
+        h->version = BRK_VERSION;
+        h->device.store(device);
+        h->heartbeat_ms.store(now_ms());
+        h->state.store(BS_STARTING);
+        h->pid.store((int32_t)getpid());            // from here on a second starter finds a live owner
+        flock(fd, LOCK_UN);
+        *fd_out = fd;
+        *base_out = p;
+        return MPB_OK;
+    }
+    return mpbi_fail(MPB_E_INVALID, "the broker segment kept changing hands; giving up");
+}
 
 int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t idle_exit_ms)
 {
@@ -339,81 +448,115 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
     int rc = shm_path(name, path, sizeof(path));
     if (rc) return rc;
     BHIP(hipSetDevice(mpbi_ctx_device(ctx)));
-    // a segment left behind by a broker that died is replaced; a live one is an error
-    {
-        Mapping old;
-        if (map_existing(name, &old) == MPB_OK) {
-            const int opid = old.hdr()->pid.load();
-            const bool live = old.hdr()->state.load() != BS_EXITING && pid_alive(opid) && opid != (int)getpid();
-            old.unmap();
-            if (live) return mpbi_fail(MPB_E_INVALID, "a broker of this name is already serving");
-        }
-        shm_unlink(path);
-    }
-    const int fd = shm_open(path, O_RDWR | O_CREAT | O_EXCL, 0600);
-    if (fd < 0) return mpbi_fail(MPB_E_INVALID, "cannot create the broker segment (another broker starting?)");
     const size_t bytes = sizeof(BrkHeader) + (size_t)n_slots * SLOT_BYTES;
-    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(path); return mpbi_fail(MPB_E_NOMEM, "cannot size the broker segment"); }
-    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) { shm_unlink(path); return mpbi_fail(MPB_E_NOMEM, "mmap of the broker segment failed"); }
+    int seg_fd = -1;
+    void *p = nullptr;
+    if ((rc = claim_segment(path, bytes, n_slots, mpbi_ctx_device(ctx), &seg_fd, &p))) return rc;
     Broker b;
     b.ctx = ctx;
     b.map.base = p;
     b.map.bytes = bytes;
     b.n_slots = n_slots;
-    BrkHeader *h = new (p) BrkHeader();             // ftruncate zero-filled the pages: every slot is free and idle
-    h->n_slots = n_slots;
-    h->slot_bytes = (int32_t)SLOT_BYTES;
-    h->pid.store((int32_t)getpid());
-    h->device.store(mpbi_ctx_device(ctx));
-    h->heartbeat_ms.store(now_ms());
-    h->version = BRK_VERSION;
+    BrkHeader *h = b.map.hdr();
     b.zero_copy = !(getenv("MPB_BROKER_COPIES") && atoi(getenv("MPB_BROKER_COPIES")) != 0);
+    // Two knobs of the serving loop (both measured: profiles/r05_per_read_concurrency.txt).  Gather window: with more workers
+    // attached than have a read in, wait this many microseconds for the stragglers before launching -- a launch costs the broker
+    // thread ~10 us whatever it carries, so two reads per launch instead of one is where the call rate comes from.  Retire
+    // thread: a second thread that only watches the lanes' completion words and hands the results back.
+    const int gather_us = getenv("MPB_BROKER_GATHER_US") ? atoi(getenv("MPB_BROKER_GATHER_US")) : 5;
+    const bool retire_thread = !(getenv("MPB_BROKER_RETIRE_THREAD") && atoi(getenv("MPB_BROKER_RETIRE_THREAD")) == 0);
     rc = b.init_lanes();
     if (rc == MPB_OK) {
         std::atomic_thread_fence(std::memory_order_seq_cst);
         h->magic = BRK_MAGIC;                        // clients accept the segment from here on
         h->state.store(BS_SERVING);
     }
+    std::atomic<int> fatal{0}, quit{0};
+    std::thread retirer;
+    if (rc == MPB_OK && retire_thread) {
+        const int device = mpbi_ctx_device(ctx);
+        retirer = std::thread([&b, &fatal, &quit, device] {
+            (void)hipSetDevice(device);
+            int idle = 0;
+            while (!quit.load(std::memory_order_acquire)) {
+                bool any = false, did = false;
+                for (Lane &l : b.lane) {
+                    if (!l.busy.load(std::memory_order_acquire)) continue;
+                    any = true;
+                    const hipError_t q = b.finished(l);
+                    if (q == hipSuccess) { b.retire(l); did = true; }
+                    else if (q != hipErrorNotReady) {
+                        mpbi_fail(MPB_E_HIP, hipGetErrorString(q));
+                        b.fail_lane(l, MPB_E_HIP);
+                        fatal.store(1, std::memory_order_release);
+                    }
+                }
+                if (did) { idle = 0; continue; }
+                if (any) { cpu_relax(); idle = 0; continue; }
+                if (++idle < 2000) cpu_relax();       // a launch is usually microseconds away; after that, off the CPU
+                else usleep(50);
+            }
+        });
+    }
     int64_t last_work = now_ms(), last_house = last_work;
     int cand[BRK_MAX_SLOTS];
     while (rc == MPB_OK && !h->stop.load(std::memory_order_relaxed)) {
         bool progress = false;
         bool any_busy = false;
+        if (fatal.load(std::memory_order_acquire)) { rc = MPB_E_HIP; break; }   // the context is gone: stop serving (clients see BS_EXITING)
         // 1. retire the micro-batches that have finished (every busy lane is asked: launches on streams of their own do not
-        //    finish in launch order, and asking only the oldest one -- tried -- costs a fifth of the call rate)
+        //    finish in launch order, and asking only the oldest one -- tried -- costs a fifth of the call rate) -- unless the
+        //    retire thread does that
         for (Lane &l : b.lane) {
-            if (!l.busy) continue;
+            if (!l.busy.load(std::memory_order_acquire)) continue;
+            any_busy = true;
+            if (retire_thread) continue;
             const hipError_t q = b.finished(l);
             if (q == hipSuccess) { b.retire(l); progress = true; }
             else if (q != hipErrorNotReady) {
                 mpbi_fail(MPB_E_HIP, hipGetErrorString(q));
                 b.fail_lane(l, MPB_E_HIP);
-                rc = MPB_E_HIP;                      // the context is gone: stop serving (clients see BS_EXITING)
+                rc = MPB_E_HIP;
                 break;
-            } else any_busy = true;
+            }
         }
         if (rc) break;
+        if (b.run_queued_solos()) progress = true;
         // 2. whatever has been submitted goes into the next free lane
         Lane *free_lane = nullptr;
-        for (Lane &l : b.lane) if (!l.busy) { free_lane = &l; break; }
+        for (Lane &l : b.lane) if (!l.busy.load(std::memory_order_acquire)) { free_lane = &l; break; }
         if (free_lane) {
-            int m = 0;
+            int m = 0, attached = 0, running = 0;
             double alpha = 0;
-            for (int i = 0; i < n_slots; i++) {
-                BrkSlot *s = b.map.slot(i);
-                if (s->state.load(std::memory_order_acquire) != ST_SUBMITTED) continue;
-                if (s->priv || s->len > MPB_SMALL_MAX_STRIDE - 1) {   // its own code table, or a row too long for k_small: cannot share a launch
-                    s->state.store(ST_RUNNING, std::memory_order_relaxed);
-                    b.run_solo(i);
-                    progress = true;
-                    continue;
+            auto collect = [&](bool first) {
+                for (int i = 0; i < n_slots; i++) {
+                    BrkSlot *s = b.map.slot(i);
+                    const uint32_t st = s->state.load(std::memory_order_acquire);
+                    if (first) {
+                        if (s->owner.load(std::memory_order_relaxed)) attached++;
+                        if (st == ST_RUNNING) running++;
+                    }
+                    if (st != ST_SUBMITTED) continue;
+                    if (m && s->alpha != alpha) continue;          // another alpha: the next micro-batch
+                    if (!b.take(i)) { progress = true; continue; } // malformed: answered with MPB_E_INVALID
+                    if (b.s_priv[i] || b.s_len[i] > MPB_SMALL_MAX_STRIDE - 1) {   // its own code table, or a row too long for k_small
+                        b.run_solo(i);
+                        progress = true;
+                        continue;
+                    }
+                    if (m == 0) alpha = b.s_alpha[i];
+                    else if (b.s_alpha[i] != alpha) {              // (the slot's alpha changed under us: its own launch)
+                        b.run_solo(i);
+                        progress = true;
+                        continue;
+                    }
+                    cand[m++] = i;
                 }
-                if (m == 0) alpha = s->alpha;
-                else if (s->alpha != alpha) continue;              // another alpha: the next micro-batch
-                s->state.store(ST_RUNNING, std::memory_order_relaxed);
-                cand[m++] = i;
+            };
+            collect(true);
+            if (m && gather_us > 0 && m < attached - running) {
+                const int64_t until = now_us() + gather_us;
+                while (m < attached - running && now_us() < until) { cpu_relax(); collect(false); }
             }
             if (m) {
                 const int lrc = b.launch(*free_lane, cand, m, alpha);
@@ -462,14 +605,22 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
     }
     // leave: nobody may wait for an answer that will not come
     h->state.store(BS_EXITING);
-    for (Lane &l : b.lane) if (l.busy) { if (hipStreamSynchronize(l.stream) == hipSuccess) b.retire(l); else b.fail_lane(l, MPB_E_HIP); }
+    quit.store(1, std::memory_order_release);
+    if (retirer.joinable()) retirer.join();
+    for (Lane &l : b.lane) if (l.busy.load()) { if (hipStreamSynchronize(l.stream) == hipSuccess) b.retire(l); else b.fail_lane(l, MPB_E_HIP); }
+    if (rc == MPB_OK) (void)b.run_queued_solos();
     for (int i = 0; i < n_slots; i++) {
         BrkSlot *s = b.map.slot(i);
         const uint32_t st = s->state.load();
         if (st == ST_SUBMITTED || st == ST_RUNNING) { mpbi_fail(MPB_E_HIP, "the broker is shutting down"); b.finish(i, MPB_E_HIP, 0, 0, mpb_last_error()); }
     }
     b.free_lanes();
-    shm_unlink(path);
+    // the name goes only if it still names THIS object: a successor that found us exiting may have replaced it already
+    if (flock(seg_fd, LOCK_EX) == 0) {
+        if (same_object(seg_fd, path)) shm_unlink(path);
+        flock(seg_fd, LOCK_UN);
+    }
+    close(seg_fd);
     b.map.unmap();
     return rc;
 }

@@ -75,6 +75,28 @@ def _broker_name(device):
     return _os.environ.get("MOIRA_PB_BROKER_NAME") or "u%d_d%d" % (_os.getuid(), device)
 
 
+def _runtime_dir():
+    """This user's own directory for the start lock and the broker's log (as moira_amd/broker.py: runtime_dir)."""
+    import stat
+    d = _os.environ.get("XDG_RUNTIME_DIR")
+    if d and _os.path.isdir(d) and _os.stat(d).st_uid == _os.getuid():
+        return d
+    d = _os.path.join("/dev/shm" if _os.path.isdir("/dev/shm") else "/tmp", "moira_pb_%d" % _os.getuid())
+    try:
+        _os.mkdir(d, 0o700)
+    except OSError:
+        pass
+    st = _os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != _os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("%s is not a private directory of this user" % d)
+    return d
+
+
+def _open_private(path, flags, mode):
+    """never through a symbolic link, never readable by others"""
+    return _os.fdopen(_os.open(path, flags | _os.O_CREAT | getattr(_os, "O_NOFOLLOW", 0), 0o600), mode)
+
+
 def _attach(device):
     """-> broker client handle; starts `python3 -m moira_amd.broker` when none is serving (under a file lock)."""
     import fcntl
@@ -82,7 +104,7 @@ def _attach(device):
     h = _C.c_void_p()
     if lib.mpb_broker_attach(name, 0, _C.byref(h)) == 0:
         return h
-    lock = open(_os.path.join("/dev/shm" if _os.path.isdir("/dev/shm") else "/tmp", "moira_pb_%s.lock" % name.decode("ascii")), "w")
+    lock = _open_private(_os.path.join(_runtime_dir(), "start_%s.lock" % name.decode("ascii")), _os.O_RDWR, "r+b")
     fcntl.flock(lock, fcntl.LOCK_EX)
     try:
         if lib.mpb_broker_attach(name, 0, _C.byref(h)) == 0:
@@ -90,7 +112,7 @@ def _attach(device):
         env = dict(_os.environ)
         env["PYTHONPATH"] = _ROOT
         env.pop("MOIRA_PB_BROKER", None)
-        log = open(_os.path.join(_os.environ.get("TMPDIR", "/tmp"), "moira_pb_broker_%s.log" % name.decode("ascii")), "ab")
+        log = _open_private(_os.path.join(_runtime_dir(), "broker_%s.log" % name.decode("ascii")), _os.O_WRONLY | _os.O_APPEND, "ab")
         py3 = _os.environ.get("MOIRA_PB_PYTHON3") or ("python3" if _sys.version_info[0] < 3 else _sys.executable)
         proc = _subprocess.Popen([py3, "-m", "moira_amd.broker", "--device", str(device), "--name", name.decode("ascii")],
                                  cwd=_ROOT, env=env, stdin=open(_os.devnull, "rb"), stdout=log, stderr=log, close_fds=True,

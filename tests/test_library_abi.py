@@ -231,7 +231,7 @@ def test_python2_form_of_the_dropin_parses_as_python2_and_checks_its_arguments()
     ast.parse(src)
     D.Driver(G.python_grammar, convert=T.convert).parse_string(src + "\n")
     imported = {n.names[0].name.split(".")[0] for n in ast.walk(ast.parse(src)) if isinstance(n, ast.Import)}
-    assert imported <= {"array", "ctypes", "os", "subprocess", "sys", "time", "fcntl", "multiprocessing"}
+    assert imported <= {"array", "ctypes", "os", "subprocess", "sys", "time", "fcntl", "multiprocessing", "stat"}      # stdlib only
     tree = ast.parse(src)
     py3_only = (ast.JoinedStr, ast.AnnAssign, ast.Nonlocal, ast.NamedExpr, ast.AsyncFunctionDef, ast.Await, ast.YieldFrom,
                 ast.MatMult)
