@@ -459,12 +459,15 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
     b.n_slots = n_slots;
     BrkHeader *h = b.map.hdr();
     b.zero_copy = !(getenv("MPB_BROKER_COPIES") && atoi(getenv("MPB_BROKER_COPIES")) != 0);
-    // Two knobs of the serving loop (both measured: profiles/r05_per_read_concurrency.txt).  Gather window: with more workers
-    // attached than have a read in, wait this many microseconds for the stragglers before launching -- a launch costs the broker
-    // thread ~10 us whatever it carries, so two reads per launch instead of one is where the call rate comes from.  Retire
-    // thread: a second thread that only watches the lanes' completion words and hands the results back.
+    // Two knobs of the serving loop, both measured (profiles/r05_per_read_concurrency.txt).  Gather window: with more workers
+    // attached than have a read in, wait this many microseconds for the stragglers before launching -- it halves the launches
+    // (4.2 instead of 2.1 reads per launch at 16 workers).  Retire thread (MPB_BROKER_RETIRE_THREAD=1): a second thread that only
+    // watches the lanes' completion words and hands the results back.  Neither moves the call rate of 16 Python workers
+    // (3.3-3.5 x 10^5 calls/s either way): that rate is bound by the workers' own cycle -- 28 us per call alone, 45 us with 16 of
+    // them spinning on the 16 CPUs the box grants, which the kernel's CPU-quota throttling counters show -- not by this thread.
+    // So the window stays (fewer launches) and the second thread is off by default (it is one more spinning thread on the quota).
     const int gather_us = getenv("MPB_BROKER_GATHER_US") ? atoi(getenv("MPB_BROKER_GATHER_US")) : 5;
-    const bool retire_thread = !(getenv("MPB_BROKER_RETIRE_THREAD") && atoi(getenv("MPB_BROKER_RETIRE_THREAD")) == 0);
+    const bool retire_thread = getenv("MPB_BROKER_RETIRE_THREAD") && atoi(getenv("MPB_BROKER_RETIRE_THREAD")) != 0;
     rc = b.init_lanes();
     if (rc == MPB_OK) {
         std::atomic_thread_fence(std::memory_order_seq_cst);

@@ -75,6 +75,8 @@ INC="-D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude"
 gcc -O1 -g -fPIC -c oracle/pb_oracle.c -o $D/oracle.o -lm
 for san in thread address,undefined; do
   g++ -O1 -g -std=c++17 -pthread -fsanitize=$san -fno-omit-frame-pointer $INC $SRC $D/oracle.o -lm -o $D/run_${san%%,*}
-  echo "== -fsanitize=$san"
-  TSAN_OPTIONS="halt_on_error=0" ASAN_OPTIONS="detect_leaks=1" $D/run_${san%%,*}
+  for rt in 0 1; do                # the serving loop alone, and with its optional retire thread (MPB_BROKER_RETIRE_THREAD)
+    echo "== -fsanitize=$san, retire thread $rt"
+    MPB_BROKER_RETIRE_THREAD=$rt TSAN_OPTIONS="halt_on_error=0" ASAN_OPTIONS="detect_leaks=1" $D/run_${san%%,*}
+  done
 done
