@@ -1550,17 +1550,16 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t 
 // A lane per row read straight from HBM is 64 rows per load instruction and every cache line revisited by eight instructions.
 // So a wave moves its 64 rows through LDS in 64-byte panels by LDS-DMA (global_load_lds_dwordx4, no register staging): one
 // instruction covers 64 consecutive bytes of each of 16 rows (the prepass' shape) and lands as [4 chunk columns][16 rows] x 16 B,
-// so the 16 lanes an LDS b128 read groups together hit 16 different bank quads; a private ring of MPB_NAR_DEPTH panels per
-// wave keeps DEPTH - 1 panels (4 KiB each) in flight across row-block boundaries -- the grid is persistent, a wave walks row
-// blocks gw, gw + W, ... as one continuous stream of panels.  The table is {p} alone, 8 bytes (ds_read_b64: half the LDS cycles
-// of the {1-p, p'} pair), and 1 - p is recomputed by the same IEEE subtraction the host used; p' == p bit for bit for every
-// encodable score (tests/test_oracle_golden.py::test_lut_pins, re-checked by mpb_create before this pass is ever chosen).
-// Per base: 1 address op + 1 subtraction + 3R - 2 cell operations + half an instruction of 'N' counting = 6.5 / 9.5 / 12.5
-// vector instructions for R = 2 / 3 / 4.
+// so the 16 lanes an LDS b128 read groups together hit 16 different bank quads; a private ring of MPB_NAR_DEPTH panels (4 KiB
+// each) per wave, a slot refilled as soon as its panel is in registers, keeps DEPTH panels in flight across row-block
+// boundaries -- the grid is persistent, a wave walks row blocks gw, gw + W, ... as one continuous stream of panels.
+// Per base: 1 address op + 3R - 2 cell operations + half an instruction of 'N' counting = 5.5 / 8.5 / 11.5 vector instructions
+// for R = 2 / 3 / 4 (with -DMPB_NAR_LUT64, which keeps {p'} alone and recomputes 1 - p, one more; mpb_create checks
+// a == 1 - b for every score either way).
 // ------------------------------------------------------------------------------------------
 #ifndef MPB_NAR_DEPTH
-#define MPB_NAR_DEPTH 3                     // ring slots per wave: 3 x 4 KiB -> three workgroups per CU
-#endif
+#define MPB_NAR_DEPTH 2                     // ring slots per wave: 2 x 4 KiB -> four workgroups (16 waves) per CU; a slot is refilled as
+#endif                                      // soon as its panel is in registers, so two panels per wave are in flight during a step
 #ifndef MPB_NAR_DEPTH_TAIL
 #define MPB_NAR_DEPTH_TAIL 2                // with the 2 x 2 KiB tail buffers: 2 x 4 + 4 = 12 KiB per wave again
 #endif
@@ -1592,8 +1591,12 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p)      // a __shared
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-#ifdef MPB_NAR_LUT128                          // experiment: the {1 - p, p'} pair from the table (5 instead of 6 instructions per base
-typedef double2 nar_entry_t;                  // at R = 2, twice the LDS cycles): profiles/r05_narrow_variants.txt
+// The table entry: the {1 - p, p'} pair as the context holds it (one ds_read_b128 per base), or -- -DMPB_NAR_LUT64 -- p' alone
+// with 1 - p recomputed by the IEEE subtraction the host used (half the LDS cycles, one more vector instruction per base).
+// Once the pass counts its 'N' bases itself it is bound by vector issue, not by the stream, and the pair is 5 % faster
+// (profiles/r05_narrow_variants.txt); LDS is 50 % busy with it.
+#ifndef MPB_NAR_LUT64
+typedef double2 nar_entry_t;
 #define NAR_P(e) ((e).y)
 #define NAR_A(e) ((e).x)
 #else
@@ -1658,7 +1661,7 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // byte 0 ('N'): the identity step {1, 0} the table holds anyway (counted below); byte 255 ('n'): a NaN -- the read is handed back
-#ifdef MPB_NAR_LUT128
+#ifndef MPB_NAR_LUT64
     s_p[tid] = tid == 255 ? make_double2(__builtin_nan(""), __builtin_nan("")) : lut_g[tid];
 #else
     s_p[tid] = tid == 255 ? __builtin_nan("") : lut_g[tid].y;
@@ -1760,6 +1763,12 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     if (TAIL) issue_tails(gw, tail_lds[0]);    // the first block's (older than every panel request: landed before any counted wait ends)
 #pragma unroll
     for (int k = 0; k < D - 1; k++) request(ring_lds[k]);
+#ifndef MPB_NAR_LATE_FREE
+    // A panel's slot is free as soon as its 64 bytes per lane are in registers -- at the START of its step, not at the end: the
+    // request that refills it is made right behind those reads, so D panels are in flight while one is computed on, not D - 1
+    // (what a CU can have in flight is what bounds the stream, and LDS capacity is what bounds that: profiles/r05_narrow_variants.txt).
+    request(ring_lds[D - 1]);
+#endif
 
     double v[R];
 #pragma unroll
@@ -1774,7 +1783,9 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
 
     auto step = [&](const int S, const int64_t s) {
         (void)s;
+#ifdef MPB_NAR_LATE_FREE
         { NAR_T0(); request(ring_lds[(S + D - 1) % D]); NAR_T1(0); }   // the slot the step before has just finished with
+#endif
         // the panel of this step has landed when at most the requests made after it are still out
         const int64_t younger = pf - (s + 1);               // 0 .. D-1 panels (wave-uniform)
         { NAR_T0();
@@ -1811,15 +1822,28 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
             uint32_t wd[16];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+#ifdef MPB_NAR_X_NOTILE                        // timing experiment: no panel reads (a constant dword)
+                const uint4 x = make_uint4(0x21222324u + lane, 0x25262728u, 0x21232527u, 0x28262422u);
+#else
                 const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
+#endif
                 wd[4 * k] = x.x; wd[4 * k + 1] = x.y; wd[4 * k + 2] = x.z; wd[4 * k + 3] = x.w;
             }
+#ifndef MPB_NAR_LATE_FREE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the panel is in registers: its slot may be overwritten
+            { NAR_T0(); request(ring_lds[S]); NAR_T1(0); }
+#endif
+#ifdef MPB_NAR_X_NOLUT                         // timing experiment: no table reads (the entry made from the byte by one conversion)
+#define NAR_LOOKUP(w, t) ((nar_entry_t)(1e-4 * (double)(((w) >> (8 * (t))) & 0xffu)))
+#else
+#define NAR_LOOKUP(w, t) s_p[((w) >> (8 * (t))) & 0xffu]
+#endif
             nar_entry_t P[18][4];                       // P[d]: table entries of dword d (static indices only)
             double A[17][4];                            // A[d]: their 1 - p
 #pragma unroll
-            for (int t = 0; t < 4; t++) P[0][t] = s_p[(wd[0] >> (8 * t)) & 0xffu];
+            for (int t = 0; t < 4; t++) P[0][t] = NAR_LOOKUP(wd[0], t);
 #pragma unroll
-            for (int t = 0; t < 4; t++) P[1][t] = s_p[(wd[1] >> (8 * t)) & 0xffu];
+            for (int t = 0; t < 4; t++) P[1][t] = NAR_LOOKUP(wd[1], t);
 #pragma unroll
             for (int t = 0; t < 4; t++) A[0][t] = NAR_A(P[0][t]);
             __builtin_amdgcn_sched_barrier(0);
@@ -1839,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
                     for (int r = R - 1; r >= 1; r--) v[r] = x[r] + y[r];
                     __builtin_amdgcn_sched_barrier(0);
                     if (d < 15) A[d + 1][t] = NAR_A(P[d + 1][t]);
-                    if (d < 14) P[d + 2][t] = s_p[(wd[d + 2] >> (8 * t)) & 0xffu];
+                    if (d < 14) P[d + 2][t] = NAR_LOOKUP(wd[d + 2], t);
                     if (t == 0) nonzero = __builtin_amdgcn_msad_u8(wd[d] ^ 0x01010101u, wd[d], nonzero);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1852,6 +1876,10 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
                 const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
                 wd[4 * k] = x.x; wd[4 * k + 1] = x.y; wd[4 * k + 2] = x.z; wd[4 * k + 3] = x.w;
             }
+#ifndef MPB_NAR_LATE_FREE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            request(ring_lds[S]);
+#endif
             nar_entry_t pc[4], pn[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) pc[t] = s_p[(wd[0] >> (8 * t)) & 0xffu];
@@ -1890,12 +1918,21 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
                     }
                 }
             }
+#ifndef MPB_NAR_LATE_FREE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a partial panel is read chunk by chunk: free at its end)
+            request(ring_lds[S]);
+#endif
         }
 #ifdef MPB_NAR_STAMPS
         st[2] += __builtin_readcyclecounter() - t_c;
         const long long t_e = __builtin_readcyclecounter();
 #endif
+#ifdef MPB_NAR_X_NOEPI                         // timing experiment: no epilogue
+        if (++cur_c == ncq) { cur_c = 0; cur_b += W; cur_ord++; }
+        if (false) {
+#else
         if (++cur_c == ncq) {
+#endif
             // ---- a row block is done: sequential CDF, interpolation, predicate (as the tile classes' epilogue) ----
             const int64_t i = cur_b * 64 + lane;
             const bool valid = i < n;

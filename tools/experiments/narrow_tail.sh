@@ -1,4 +1,6 @@
 #!/bin/bash
+# (written when the {p}-only table and a three-slot ring were the defaults: -DMPB_NAR_LUT128 is now a no-op, -DMPB_NAR_LUT64 /
+# -DMPB_NAR_DEPTH=3 select the old forms)
 # Run ON THE GPU BOX: k_narrow with and without the shared-line tails (TAIL), ring depth with tails, table width; time and
 # memory-side reads per launch.
 export TMPDIR=/tmp
