@@ -58,13 +58,14 @@ for k, v in out.items():
         v["clock_ghz"] = v["GRBM_GUI_ACTIVE"] / 8 / v["duration_us_sq"] / 1e3
         v["valu_busy"] = v["SQ_INSTS_VALU"] * 4 / (v["GRBM_GUI_ACTIVE"] / 8 * 1024)
 json.dump(out, open(os.path.join(dst, tag + "_pmc_hq.json"), "w"), indent=1, sort_keys=True)
-k = out.get("k_narrow<2>", {})
+kname = next((x for x in sorted(out) if x.startswith("k_narrow<2")), "")
+k = out.get(kname, {})
 if "hbm_read_bytes_exact" in k:
     rd, wr = k["hbm_read_bytes_exact"], k.get("hbm_write_bytes_exact", k.get("hbm_write_bytes_write_size", 0))
     json.dump({"source": "profiles/%s_pmc_hq.json (rocprofv3 --pmc, separate passes over tools/narrow_probe.py: TCC_EA0_RDREQ_{32B,64B,128B} "
                          "and TCC_EA0_WRREQ{,_64B} request counts x their sizes; FETCH_SIZE x 2 / WRITE_SIZE agree)" % tag,
                "workload": {"reads": 10000000, "length": 300, "stride": 320, "seed": 2, "profile": 1},
-               "kernel": "k_narrow<2>", "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+               "kernel": kname, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                "hbm_bytes_per_launch": rd + wr,
                "valu": {"SQ_INSTS_VALU": k.get("SQ_INSTS_VALU"), "GRBM_GUI_ACTIVE": k.get("GRBM_GUI_ACTIVE"),
                         "duration_us": k.get("duration_us_sq"), "clock_ghz": k.get("clock_ghz"), "valu_busy": k.get("valu_busy")}},
