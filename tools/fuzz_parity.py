@@ -131,6 +131,26 @@ with Engine(0) as eng:
             if not okc:
                 bad += 1
                 print("CLASSIFIED-AT-SOURCE MISMATCH round %d: n=%d stride=%d fixed=%s kind=%d kw=%s" % (it, n, stride, fixed, kind, kw), flush=True)
+        if fixed and int(lens[0]) >= 1 and not too.any():
+            # round 5: the same (fixed-length) batch resident in HBM through the natural-order narrow pass, forced with 2 / 3 / 4 rows
+            # (k_narrow finishes what crosses within them, counts the 'N's, hands the rest -- and every read with an 'n' -- to the
+            # sorted pipeline); ragged batches and the opt-in flags never take that pass
+            rows0 = int(rng.integers(2, 5))
+            bufs = [eng.alloc(n * stride).upload(q), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)]
+            c = eng.filter_device(bufs[0], n, stride, fixed_len=int(lens[0]), d_ee=bufs[1], d_ns=bufs[2], d_pass=bufs[3],
+                                  params=eng.params(narrow_rows=rows0, **kw))
+            path = eng.last_path()
+            amb_n = (q[:, :int(lens[0])] == 255).any(1)
+            okn = (path["narrow_rows"] == rows0 and path["n_fallback"] == int((amb_n | (rows > rows0)).sum())
+                   and np.array_equal(bufs[1].download(np.float64, n), ee, equal_nan=True)
+                   and np.array_equal(bufs[2].download(np.int32, n), ns) and np.array_equal(bufs[3].download(np.uint8, n), ps)
+                   and c.n_pass == int(ps.sum()))
+            for b in bufs:
+                b.free()
+            if not okn:
+                bad += 1
+                print("NARROW-PASS MISMATCH round %d: n=%d stride=%d L=%d rows0=%d kind=%d kw=%s path=%s"
+                      % (it, n, stride, int(lens[0]), rows0, kind, kw, path), flush=True)
         if (it + 1) % 100 == 0:
             print("fuzz: %d rounds done, %d mismatching, %.0f s" % (it + 1, bad, time.time() - t0), flush=True)
         if not ok:
