@@ -93,3 +93,34 @@ def test_cli_device_list_reproduces_the_golden_files(tmp_path, golden_dir):
     assert cli.parse_devices("all") == ["all"] and cli.parse_devices("1, 3") == [1, 3] and cli.parse_devices(2) == [2]
     with pytest.raises(ValueError):
         cli.parse_devices("gpu0")
+
+
+def test_shard_threads_are_placed_next_to_their_gpu_and_the_caller_is_left_alone(oracle):
+    """each shard thread of mpb_filter_host_multi restricts itself to the CPUs of its GPU's NUMA node for the
+    duration of its pipeline.  The CALLING thread runs shard 0: its own affinity mask must be what it was when the call
+    returns; the lookup the pinning uses must answer for this box's GPU; MOIRA_PB_NO_NUMA turns it off; results unchanged."""
+    import ctypes as C
+    import os
+    from moira_amd import _lib as L
+    from moira_amd.shard import MultiEngine
+    lib = L.load()
+    hip = C.CDLL("libamdhip64.so")
+    bus = C.create_string_buffer(64)
+    assert hip.hipDeviceGetPCIBusId(bus, 64, 0) == 0
+    node, cpus = C.c_int32(-9), C.create_string_buffer(4096)
+    assert lib.mpb_numa_cpulist_for_pci(b"", bus.value, C.byref(node), cpus, 4096) == 0
+    assert node.value >= -1 and (node.value == -1 or len(cpus.value) > 0)
+    print("GPU 0 at %s: NUMA node %d, CPUs %s" % (bus.value.decode(), node.value, cpus.value.decode() or "(no information)"))
+    before = os.sched_getaffinity(0)
+    q, _ = oracle.synth_fill(300_001, 320, fixed_len=300, seed=2)
+    ee, ns, ps, _ = oracle.filter_batch(q, fixed_len=300, threads=8)
+    for no_numa in (False, True):
+        if no_numa:
+            os.environ["MOIRA_PB_NO_NUMA"] = "1"
+        try:
+            with MultiEngine([0, 0]) as me:
+                r = me.filter(q, fixed_len=300)
+        finally:
+            os.environ.pop("MOIRA_PB_NO_NUMA", None)
+        assert same(r.ee, ee) and np.array_equal(r.passed, ps.astype(bool))
+        assert os.sched_getaffinity(0) == before
