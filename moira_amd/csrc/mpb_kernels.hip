@@ -1573,13 +1573,8 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t 
 // atomic) only makes a counted wait stricter.  M0 = LDS address; one wait state between the M0 write and the DMA.
 __device__ __forceinline__ void nar_dma16(const uint8_t *base, uint32_t voff, uint32_t lds)
 {
-#ifdef MPB_NAR_NT                              // experiment: non-temporal requests (profiles/r05_narrow_variants.txt)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
-                 :: "s"(lds), "v"(voff), "s"(base) : "memory");
-#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :: "s"(lds), "v"(voff), "s"(base) : "memory");
-#endif
+                 :: "s"(lds), "v"(voff), "s"(base) : "memory");      // (`nt` requests: 5.9 instead of 4.0 GB per launch, slower)
 }
 template <int N>
 __device__ __forceinline__ void nar_wait()                  // until at most N vector-memory operations are outstanding
@@ -1812,7 +1807,6 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
         const int nbases = min(64, li - cur_c * 64);        // wave-uniform
 #endif
         if (nbases == 64) {
-#ifndef MPB_NAR_PLAIN_ORDER
             // All four chunks of the panel at once; the table two dwords (eight bases) ahead of the arithmetic; 1 - p one dword
             // ahead; and inside a base the operations in an order that keeps dependent FP64 instructions three issue slots apart
             // (a dependent v_mul_f64 / v_add_f64 issues 8-9 cycles after its producer, tools/experiments/fp64_latency.hip: back
@@ -1822,22 +1816,14 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
             uint32_t wd[16];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-#ifdef MPB_NAR_X_NOTILE                        // timing experiment: no panel reads (a constant dword)
-                const uint4 x = make_uint4(0x21222324u + lane, 0x25262728u, 0x21232527u, 0x28262422u);
-#else
                 const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
-#endif
                 wd[4 * k] = x.x; wd[4 * k + 1] = x.y; wd[4 * k + 2] = x.z; wd[4 * k + 3] = x.w;
             }
 #ifndef MPB_NAR_LATE_FREE
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the panel is in registers: its slot may be overwritten
             { NAR_T0(); request(ring_lds[S]); NAR_T1(0); }
 #endif
-#ifdef MPB_NAR_X_NOLUT                         // timing experiment: no table reads (the entry made from the byte by one conversion)
-#define NAR_LOOKUP(w, t) ((nar_entry_t)(1e-4 * (double)(((w) >> (8 * (t))) & 0xffu)))
-#else
 #define NAR_LOOKUP(w, t) s_p[((w) >> (8 * (t))) & 0xffu]
-#endif
             nar_entry_t P[18][4];                       // P[d]: table entries of dword d (static indices only)
             double A[17][4];                            // A[d]: their 1 - p
 #pragma unroll
@@ -1868,35 +1854,6 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#else
-            // all four chunks of the panel at once, then the table one dword (four bases) ahead of the arithmetic
-            uint32_t wd[16];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
-                wd[4 * k] = x.x; wd[4 * k + 1] = x.y; wd[4 * k + 2] = x.z; wd[4 * k + 3] = x.w;
-            }
-#ifndef MPB_NAR_LATE_FREE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            request(ring_lds[S]);
-#endif
-            nar_entry_t pc[4], pn[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) pc[t] = s_p[(wd[0] >> (8 * t)) & 0xffu];
-#pragma unroll
-            for (int d = 0; d < 16; d++) {
-                if (d < 15) {
-#pragma unroll
-                    for (int t = 0; t < 4; t++) pn[t] = s_p[(wd[d + 1] >> (8 * t)) & 0xffu];
-                }
-                nonzero = __builtin_amdgcn_msad_u8(wd[d] ^ 0x01010101u, wd[d], nonzero);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 4; t++) nar_step<R>(v, pc[t]);
-#pragma unroll
-                for (int t = 0; t < 4; t++) pc[t] = pn[t];
-            }
-#endif
         } else {
             for (int k = 0; k * 16 < nbases; k++) {
                 const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
@@ -1927,12 +1884,7 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
         st[2] += __builtin_readcyclecounter() - t_c;
         const long long t_e = __builtin_readcyclecounter();
 #endif
-#ifdef MPB_NAR_X_NOEPI                         // timing experiment: no epilogue
-        if (++cur_c == ncq) { cur_c = 0; cur_b += W; cur_ord++; }
-        if (false) {
-#else
         if (++cur_c == ncq) {
-#endif
             // ---- a row block is done: sequential CDF, interpolation, predicate (as the tile classes' epilogue) ----
             const int64_t i = cur_b * 64 + lane;
             const bool valid = i < n;

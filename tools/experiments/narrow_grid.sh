@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 FL="-O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -fno-fast-math -pthread -Iinclude -x hip"
 mkdir -p /tmp/var
 /opt/rocm/bin/hipcc $FL -DMPB_TUNING_KNOBS moira_amd/csrc/mpb_kernels.hip moira_amd/csrc/mpb_api.cpp moira_amd/csrc/mpb_broker.cpp -o /tmp/var/knobs.so || exit 1
-/opt/rocm/bin/hipcc $FL -DMPB_TUNING_KNOBS -DMPB_NAR_NT moira_amd/csrc/mpb_kernels.hip moira_amd/csrc/mpb_api.cpp moira_amd/csrc/mpb_broker.cpp -o /tmp/var/knobs_nt.so || exit 1
+
 run() {  # lib grid
   export MOIRA_PB_LIB=/tmp/var/$1.so MPB_NAR_GRID=$2
   D=/tmp/ng_$1_$2; rm -rf $D
@@ -22,4 +22,4 @@ print("%s | k_narrow reads %.3f GB per launch" % (sys.argv[2], gb))
 PY
 }
 for g in 256 512 768; do run knobs $g; done
-for g in 512 768; do run knobs_nt $g; done
+
