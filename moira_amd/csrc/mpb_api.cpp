@@ -713,27 +713,30 @@ static int ensure_fallback_block(mpb_ctx *c, int64_t m, int64_t stride, Fallback
     return MPB_OK;
 }
 
-// The choice, from the sample's histogram of predicted rows.  Costs in vector instructions per base and read -- what bounds each
-// pass in the regime where the choice is close: the narrow pass issues 3 R per base whatever the read needs (address, 1 - p,
-// 3 R - 2 cell operations); the sorted pipeline costs about 8 for classification + sort (bound by its second read of the matrix)
-// plus 3 per row of the read's class; a read the narrow pass hands back pays the sorted pipeline on top, plus its gather and
-// scatter.  The pass must also finish at least 90 % of the sample: below that the sub-batch's own launches and the doubled
-// traffic eat the gain.  Checked against measured times on five quality mixes: profiles/r05_narrow_choice.txt.
+// The choice, from the sample's histogram of rows.  Costs per read in units of 0.083 ms per 10 M reads of 300 bases, fitted to
+// measured steps (profiles/r05_narrow_rate.txt, r05_narrow_mix.txt): the narrow pass 4 + 3 R for every read whatever it needs; the
+// sorted pipeline 9 (classification + sort: its second read of the matrix) + 3.9 per row of the read's class (its predictor gives
+// the few-row reads one row more than they need); a read the narrow pass hands back pays 1.3 x the sorted pipeline (its sub-batch
+// holds only the expensive classes: no narrow tiles to share a CU with, three more passes over its rows) + 3 for the gather and the
+// scatter.  The pass must finish at least 80 % of the sample and promise at least 5 %: measured break-even is near 20 % handed back.
 static int narrow_rows_from_sample(const int32_t *hist, int n_sample)
 {
     if (n_sample <= 0) return 0;
-    auto sorted_cost = [](int r) { return 8.0 + 3.0 * (r < 2 ? 2 : r == MPB_NAR_BUCKETS - 1 ? 24 : r); };
-    const double amb_cost = 8.0 + 3.0 * 6;                   // a read with a lower-case 'n' (handed back by the pass): a middling class
-    double general = hist[0] * amb_cost;
+    auto sorted_cost = [](int r) {
+        const int cap = r == MPB_NAR_BUCKETS - 1 ? 30 : r <= 4 ? (r < 1 ? 2 : r + 1) : r;
+        return 9.0 + 3.9 * cap;
+    };
+    const double lower_n_cost = sorted_cost(6);              // a read with a lower-case 'n' (handed back by the pass): a middling class
+    double general = hist[0] * lower_n_cost;
     for (int r = 1; r < MPB_NAR_BUCKETS; r++) general += hist[r] * sorted_cost(r);
     int best = 0;
-    double best_cost = 0.9 * general;                        // a narrow pass must promise at least 10 %
+    double best_cost = 0.95 * general;
     for (int R = MPB_NAR_MIN_ROWS; R <= MPB_NAR_MAX_ROWS; R++) {
         int64_t done = 0;
         for (int r = 1; r <= R; r++) done += hist[r];
-        if ((double)done < 0.90 * n_sample) continue;
-        double cost = (double)n_sample * 3.0 * R + hist[0] * (amb_cost + 2.0);
-        for (int r = R + 1; r < MPB_NAR_BUCKETS; r++) cost += hist[r] * (sorted_cost(r) + 2.0);
+        if ((double)done < 0.80 * n_sample) continue;
+        double cost = (double)n_sample * (4.0 + 3.0 * R) + hist[0] * (1.3 * lower_n_cost + 3.0);
+        for (int r = R + 1; r < MPB_NAR_BUCKETS; r++) cost += hist[r] * (1.3 * sorted_cost(r) + 3.0);
         if (cost < best_cost) { best = R; best_cost = cost; }
     }
     return best;
@@ -815,8 +818,8 @@ static int filter_device_narrow(mpb_ctx *c, int rows0, const uint8_t *d_q, int64
         { Span t(c, MPB_K_FALLBACK); mpb_launch_scatter_back(c->ws.nar_list, m, fb.ee, fb.ns, fb.pass, d_ee, d_ns, d_pass, s); }
         HIPCHK(hipGetLastError());
     }
-    // a pass that hands back far more than its sample promised: look again next time
-    if (!((params->flags >> 8) & 15u) && m > n / 8) c->nar_choice.valid = false;
+    // a pass that hands back far more than its sample can have promised: look again next time
+    if (!((params->flags >> 8) & 15u) && m > n / 4) c->nar_choice.valid = false;
     if (counts) {
         if ((rc = ensure_workspace(c, 1))) return rc;
         HIPCHK(hipMemsetAsync(c->ws.pass_count, 0, sizeof(unsigned long long), s));
