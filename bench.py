@@ -1222,7 +1222,7 @@ def high_quality_rate(eng, n, stride, L, seed, d_ee, d_ns, d_pass):
     """the HBM-bound regime.  The same shape as configs[1] (n x 300 bp, stride 320, resident) with the clean
     quality profile of include/mpb_synth.h (profile 1: Q33..Q40, 0.003 % ambiguous bases: every read's CDF crosses 1 - alpha
     on the second row of the table).  The library picks its pass from a sample of <= 0.1 % of the reads (mpb_path_info): here
-    the natural-order narrow pass (k_narrow, the matrix read once) -- timed against the sorted pipeline on the same batch
+    the natural-order narrow pass (k_narrow_rs / k_narrow, the matrix read once) -- timed against the sorted pipeline on the same batch
     (MPB_FLAG_NO_NARROW).  Algorithmic bytes per read = L + 13 as everywhere.  NOT the headline."""
     out = {"note": "10 M x 300 bp of the CLEAN synthetic profile (Q33..Q40; include/mpb_synth.h profile 1), resident; the pass "
                    "is the library's own choice; roofline as for the headline: (L + 13) x reads / time / 8 TB/s; NOT the headline",
@@ -1253,7 +1253,8 @@ def high_quality_rate(eng, n, stride, L, seed, d_ee, d_ns, d_pass):
                     "kernels_ms_per_step": kt,
                     "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": alg,
                                  "whole_step": {"achieved": alg / ms / 1e6, "frac": alg / ms / 1e6 / HBM_PEAK_GBS},
-                                 "kernel": "k_narrow", "avg_launch_ms": nar_ms,
+                                 "kernel": "k_narrow_rs" if stride % 64 == 0 and not os.environ.get("MPB_NAR_NO_RS") else "k_narrow",
+                                 "avg_launch_ms": nar_ms,
                                  "achieved": (alg / nar_ms / 1e6) if nar_ms else None,
                                  "frac": (alg / nar_ms / 1e6 / HBM_PEAK_GBS) if nar_ms else None},
                     "outcome": {"pass": c.n_pass, "fail": c.n_fail, "overflow_reruns": c.n_overflow}})

@@ -128,6 +128,8 @@ struct MpbWorkspace {
 // the read turns out to need, so every read whose CDF crosses inside them is finished bit for bit; the others -- and every read
 // with a lower-case 'n', whose table entry is a NaN in this pass -- go on a list, are gathered into a dense sub-batch and run
 // through the ordinary pipeline.  The choice is made per batch from a sample of <= 0.1 % of the reads.
+// Two forms of the same pass: k_narrow_rs (row strides that are a multiple of 64 bytes: a lane walks one or two rows as one stream
+// of whole 128-byte lines, panels staged in registers) and k_narrow (any stride: 64-byte panels through an LDS-DMA ring).
 #define MPB_NAR_MIN_ROWS 2
 #define MPB_NAR_MAX_ROWS 4
 #define MPB_NAR_BUCKETS 16                // k_sample: [0] reads with a lower-case 'n', [r] reads that need r rows (r = 1..14), [15] more
@@ -179,6 +181,8 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
                        const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks, hipStream_t s);
 int mpb_narrow_lds_bytes(bool tail);      // static LDS of one k_narrow workgroup (the host sizes the persistent grid from it)
 bool mpb_narrow_uses_tails(int64_t stride, int32_t fixed_len);
+int mpb_narrow_rs_reads_per_lane(int64_t stride);   // k_narrow_rs (whole-line panels staged in registers): reads per lane, 0 = k_narrow
+int mpb_narrow_rs_lds_bytes();
 // predicted row budgets of `n_sample` reads spread over the batch -> ws.nar_sample (zeroed here)
 void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
                        const MpbWorkspace &ws, int n_sample, hipStream_t s);

@@ -1940,6 +1940,227 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// k_narrow_rs<R>: the narrow pass with the panel stream staged in REGISTERS and every request a whole, aligned 128-byte line
+// (round 5, second form; rows whose stride is a multiple of 64 bytes).
+//
+// What k_narrow's measurements said (profiles/r05_narrow_variants.txt): its LDS-DMA stream stops at 0.78 ms per 10 M x 320 B
+// whatever the ring depth, the resident workgroups or the bytes it over-fetches, while k_prepass / k_lambda pull the same
+// matrix through plain loads in 0.58-0.64 ms; and a row of 320 bytes starts in the middle of a line every other row, so that
+// 64-byte panels fetch a fifth to two fifths of the lines twice.  Both go away when a LANE walks a whole number of lines:
+// k = 128 / gcd(stride, 128) consecutive reads (k = 2 for the 300-base / 320-byte layout) are one stream of k * stride bytes
+// per lane, cut into 128-byte panels that are lines in memory.  A wave's 64 streams are loaded 8 streams x 128 bytes per
+// instruction (eight lanes = one line) into registers, one panel (32 VGPRs) ahead of the arithmetic through a range-checked
+// buffer (rows past the end of the matrix read zeros = 'N' = the identity step), written into a private 8 KB tile whose
+// 16-byte slots are XOR-swizzled by the stream number (writes and reads both conflict-free, no padding: 16 waves per CU),
+// and read back a stream per lane.  The reads of a lane follow each other in its stream: at every end of a read the same
+// epilogue as k_narrow's; bytes between a read's end and the next read's start (the row padding) are skipped by whole
+// 64-byte halves (wave-uniform) or never looked at.  Same cell arithmetic, same sequential CDF, same list of reads handed
+// back (a wave's segment holds 64 k slots per stream block).
+// ------------------------------------------------------------------------------------------
+#define MPB_NRS_TILE 8192                   // 64 streams x 128 bytes
+
+// ND dwords (4 ND bases) of the lane's stream, already in registers: the table two dwords ahead of the arithmetic, products
+// before sums (k_narrow's unrolled body; see there).  One straight line: a branch inside it makes the compiler drain the LDS
+// queue where the paths meet (measured: a loop over 16-base chunks with the same look-ahead is 8 % slower than this).
+template <int R, int ND>
+__device__ __forceinline__ void nar_run(double (&v)[R], uint32_t &nonzero, const nar_entry_t *s_p, const uint32_t (&wd)[16])
+{
+    nar_entry_t P[ND + 2][4];
+    double A[ND + 1][4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) P[0][t] = NAR_LOOKUP(wd[0], t);
+#pragma unroll
+    for (int t = 0; t < 4; t++) P[1][t] = NAR_LOOKUP(wd[1], t);
+#pragma unroll
+    for (int t = 0; t < 4; t++) A[0][t] = NAR_A(P[0][t]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const double a = A[d][t], p = NAR_P(P[d][t]);
+            double x[R], y[R];
+#pragma unroll
+            for (int r = R - 1; r >= 1; r--) x[r] = a * v[r];
+#pragma unroll
+            for (int r = R - 1; r >= 1; r--) y[r] = p * v[r - 1];
+            v[0] = a * v[0];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = R - 1; r >= 1; r--) v[r] = x[r] + y[r];
+            __builtin_amdgcn_sched_barrier(0);
+            if (d < ND - 1) A[d + 1][t] = NAR_A(P[d + 1][t]);
+            if (d < ND - 2) P[d + 2][t] = NAR_LOOKUP(wd[d + 2], t);
+            if (t == 0) nonzero = __builtin_amdgcn_msad_u8(wd[d] ^ 0x01010101u, wd[d], nonzero);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_narrow_rs(const uint8_t *__restrict__ q, int64_t n, int64_t stride, int32_t li, int32_t k,
+                                                   MpbDevParams prm, const double2 *__restrict__ lut_g,
+                                                   double *__restrict__ ee, int32_t *__restrict__ ns, uint8_t *__restrict__ pass,
+                                                   int32_t *__restrict__ seg, int32_t *__restrict__ wave_count)
+{
+    __shared__ nar_entry_t s_p[256];
+    __shared__ __attribute__((aligned(128))) uint8_t s_tile[4][MPB_NRS_TILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef MPB_NAR_LUT64
+    s_p[tid] = tid == 255 ? make_double2(__builtin_nan(""), __builtin_nan("")) : lut_g[tid];
+#else
+    s_p[tid] = tid == 255 ? __builtin_nan("") : lut_g[tid].y;
+#endif
+    __syncthreads();                                          // the only block barrier
+    const int64_t rows_sb = 64 * (int64_t)k;                  // reads of a stream block: 64 lanes x k reads each
+    const int64_t nsb = (n + rows_sb - 1) / rows_sb;
+    const int KB = __builtin_amdgcn_readfirstlane((int)(k * stride));      // bytes of a lane's stream: a multiple of 128
+    const int NP = KB >> 7;                                   // its panels
+    const int istride = __builtin_amdgcn_readfirstlane((int)stride);
+    const int64_t gw = (int64_t)blockIdx.x * 4 + w, W = (int64_t)gridDim.x * 4;
+    if (gw >= nsb) {
+        if (lane == 0) wave_count[gw] = 0;
+        return;
+    }
+    const int64_t total = ((nsb - gw + W - 1) / W) * NP;      // panels this wave walks
+    int32_t *const my_seg = seg + rows_sb * (gw * (nsb / W) + min(gw, nsb % W));
+    int nlist = 0;                                            // wave-uniform
+    uint8_t *const tile = s_tile[w];
+    // loading: lane (r8, c8) of instruction j holds the 16-byte slot c8 of panel bytes of stream 8 j + r8
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int voff = r8 * KB + c8 * 16;
+    // its place in the tile: stream * 128 + ((slot ^ ((stream >> 1) & 7)) * 16); (8 j + r8) >> 1 & 7 = 4 (j & 1) + (r8 >> 1)
+    const int wr_even = r8 * 128 + ((c8 ^ (r8 >> 1)) << 4), wr_odd = r8 * 128 + ((c8 ^ (4 + (r8 >> 1))) << 4);
+    // reading: lane = stream; slot c at x0 ^ (c << 4)
+    const int x0 = lane * 128 + (((lane >> 1) & 7) << 4);
+
+    u32x4 pre[8];
+    auto load_panel = [&](const int64_t sb, const int pk) {
+        const uint64_t base = (uint64_t)(uintptr_t)q + (uint64_t)(sb * rows_sb) * (uint64_t)stride;
+        const int64_t rows_here = (n - sb * rows_sb) < rows_sb ? (n - sb * rows_sb) : rows_sb;
+        const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+        const uint32_t b_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rows_here * stride));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(uintptr_t)(((uint64_t)b_hi << 32) | b_lo), 0, (int)b_n, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 8; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, j * 8 * KB + pk * 128, 0);
+    };
+    int64_t pf_sb = gw, cur_sb = gw;
+    int pf_pk = 0, cur_pk = 0;
+    load_panel(pf_sb, pf_pk);
+    if (++pf_pk == NP) { pf_pk = 0; pf_sb += W; }
+
+    double v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = r == 0 ? 1.0 : 0.0;
+    const double thr = prm.thr;
+    uint32_t nonzero = 0;                                      // as k_narrow: the bytes that are NOT zero, four per instruction
+    int u = 0, sread = 0;                                      // position in the stream: byte u of its read number sread (wave-uniform)
+
+    // ---- a read is done: sequential CDF, interpolation, predicate (as k_narrow / the tile classes' epilogue) ----
+    // `nonzero` has counted the non-zero bytes of the read's chunks; the bytes of its last chunk past its end were made zero
+    // before they were looked up (the identity step) and so count as 'N' here: 'N' bases = li - nonzero.
+    auto finish = [&](const int64_t sb, const int sr) {
+        const int64_t i = sb * rows_sb + (int64_t)lane * k + sr;
+        const bool valid = i < n;
+        double acc = 0.0, lo = 0.0, hi = 0.0;
+        int js = -1;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const double na = acc + v[r];
+            const bool hit = (js < 0) && (na > thr);
+            lo = hit ? acc : lo;
+            hi = hit ? na : hi;
+            js = hit ? r : js;
+            acc = na;
+        }
+        const bool done = valid && js >= 0;
+        if (done) {
+            double e = (double)(js - 1) + ((thr - lo) / (hi - lo));     // ref: bernoullimodule.c:170-178
+            if (e < 0) e = 0;
+            const int nsv = li - (int)nonzero;                           // 'N' bases (a read with an 'n' never gets here)
+            if (prm.ambig_mode == 0) e = e + (double)nsv;                // moira.py:827-828
+            const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors            // moira.py:925-926
+                                                                  : (double)li * prm.uncert; // moira.py:949-950
+            if (prm.flags & 1u) e = floor(e);                            // moira.py:830-831
+            ee[i] = e;
+            ns[i] = nsv;
+            pass[i] = (uint8_t)((prm.ambig_mode == 2 && nsv > 0) ? 0 : (e <= limit ? 1 : 0));   // moira.py:911
+        }
+        const unsigned long long todo = __ballot(valid && js < 0);
+        if (todo) {
+            if (valid && js < 0) my_seg[nlist + __popcll(todo & ((1ull << lane) - 1ull))] = (int32_t)i;
+            nlist += __popcll(todo);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = r == 0 ? 1.0 : 0.0;
+        nonzero = 0;
+    };
+    for (int64_t t = 0; t < total; t++) {
+        // the panel requested one panel ago -> tile (the tile's last reads were issued before: LDS runs a wave's operations in order)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            *reinterpret_cast<u32x4 *>(tile + j * 1024 + ((j & 1) ? wr_odd : wr_even)) = pre[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef MPB_NAR_NODMA                           // timing experiment: the arithmetic alone (stale panels after the second)
+        if (t + 1 < total && t < 1) {
+#else
+        if (t + 1 < total) {                                    // in flight while this panel is computed on
+#endif
+            load_panel(pf_sb, pf_pk);
+            if (++pf_pk == NP) { pf_pk = 0; pf_sb += W; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MPB_NAR_NOARITH                         // timing experiment: the panel stream alone (loads + tile writes, two tile reads per panel)
+        nonzero += *reinterpret_cast<const uint32_t *>(tile + x0) + *reinterpret_cast<const uint32_t *>(tile + (x0 ^ 64));
+#else
+        // ---- the panel's two 64-byte halves.  A half holds up to four 16-byte chunks of the current read: they go through one
+        // straight-line run (nar_run<R, 4 x chunks>); the bytes of a read's last chunk past its end are made zero first (the
+        // identity step), so a 300-base read's last 44 bases take the same code as the others, as 48.
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int nb = li - u;                              // bases of the current read from this half on (wave-uniform)
+            if (nb > 0) {
+                const int nch = nb >= 64 ? 4 : (nb + 15) >> 4;  // chunks of this half that hold bases
+                uint32_t wd[16];
+#define NRS_LOAD(NC)                                                                                         \
+                _Pragma("unroll") for (int c = 0; c < NC; c++) {                                             \
+                    const u32x4 x = *reinterpret_cast<const u32x4 *>(tile + (x0 ^ ((h * 4 + c) << 4)));      \
+                    wd[4 * c] = x.x; wd[4 * c + 1] = x.y; wd[4 * c + 2] = x.z; wd[4 * c + 3] = x.w;           \
+                }                                                                                            \
+                if (nb < 16 * NC) {                                                                          \
+                    _Pragma("unroll") for (int d = 0; d < 4; d++)                                            \
+                        wd[4 * (NC - 1) + d] = mask_dword(wd[4 * (NC - 1) + d], nb - 16 * (NC - 1) - 4 * d); \
+                }
+                switch (nch) {
+                case 4: { NRS_LOAD(4) nar_run<R, 16>(v, nonzero, s_p, wd); break; }
+                case 3: { NRS_LOAD(3) nar_run<R, 12>(v, nonzero, s_p, wd); break; }
+                case 2: { NRS_LOAD(2) nar_run<R, 8>(v, nonzero, s_p, wd); break; }
+                default: { NRS_LOAD(1) nar_run<R, 4>(v, nonzero, s_p, wd); break; }
+                }
+#undef NRS_LOAD
+                if (nb <= 64) finish(cur_sb, sread);
+            }
+            u += 64;
+            if (u == istride) { u = 0; sread++; }
+        }
+#endif
+        if (++cur_pk == NP) { cur_pk = 0; cur_sb += W; sread = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is overwritten by the next panel
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#ifdef MPB_NAR_NOARITH
+    if (nonzero == 0x12345678u) ns[gw] = 1;                     // keeps the tile reads alive
+#endif
+    if (lane == 0) wave_count[gw] = nlist;
+}
+
 // exclusive prefix of the waves' list counts (one block); total -> *count
 __global__ __launch_bounds__(1024) void k_nar_offsets(const int32_t *__restrict__ wave_count, int nwaves,
                                                       int32_t *__restrict__ wave_off, int32_t *__restrict__ count)
@@ -1966,11 +2187,11 @@ __global__ __launch_bounds__(1024) void k_nar_offsets(const int32_t *__restrict_
 // segment of wave g -> list[wave_off[g] ...): one block per wave
 __global__ __launch_bounds__(256) void k_nar_compact(const int32_t *__restrict__ seg, const int32_t *__restrict__ wave_count,
                                                      const int32_t *__restrict__ wave_off, int64_t nblk, int nwaves,
-                                                     int32_t *__restrict__ list)
+                                                     int per_blk, int32_t *__restrict__ list)
 {
     const int64_t g = blockIdx.x;
     const int cnt = wave_count[g];
-    const int32_t *src = seg + 64 * (g * (nblk / nwaves) + min(g, nblk % nwaves));
+    const int32_t *src = seg + (int64_t)per_blk * (g * (nblk / nwaves) + min(g, nblk % nwaves));
     int32_t *dst = list + wave_off[g];
     for (int k = threadIdx.x; k < cnt; k += 256) dst[k] = src[k];
 }
@@ -2320,10 +2541,25 @@ int mpb_narrow_lds_bytes(bool tail)
     return 256 * (int)sizeof(nar_entry_t) + (tail ? MPB_NAR_DEPTH_TAIL : MPB_NAR_DEPTH) * 4 * MPB_NAR_PANEL + (tail ? 2 * 4 * 2048 : 32);
 }
 
+// k_narrow_rs (register-staged, whole lines): rows whose stride is a multiple of 64 bytes; reads per lane (0: not this form)
+int mpb_narrow_rs_reads_per_lane(int64_t stride)
+{
+    static const bool off = getenv("MPB_NAR_NO_RS") != nullptr;      // A/B runs (tools/): the LDS-DMA form for every stride
+    if (off || stride % 64 != 0 || stride > (1 << 16)) return 0;
+    return stride % 128 == 0 ? 1 : 2;
+}
+
+int mpb_narrow_rs_lds_bytes()
+{
+    return 256 * (int)sizeof(nar_entry_t) + 4 * MPB_NRS_TILE;
+}
+
 void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
                        const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks, hipStream_t s)
 {
-    const int64_t nblk = (n + 63) / 64;
+    const int rs_k = mpb_narrow_rs_reads_per_lane(stride);
+    const int per_blk = 64 * (rs_k ? rs_k : 1);              // reads of one row block / stream block
+    const int64_t nblk = (n + per_blk - 1) / per_blk;
     int64_t blocks = (nblk + 3) / 4;
 #ifdef MPB_TUNING_KNOBS          // experiment builds only (tools/): never in the shipped library
     if (getenv("MPB_NAR_GRID")) grid_blocks = atoi(getenv("MPB_NAR_GRID"));
@@ -2341,11 +2577,21 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
 #define MPB_NAR_LAUNCH(RR) \
     do { if (tail) MPB_NAR_LAUNCH_TAIL(RR); \
          else hipLaunchKernelGGL((k_narrow<RR, false, MPB_NAR_DEPTH>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count); } while (0)
-    switch (rows0) {
-    case 2: MPB_NAR_LAUNCH(2); break;
-    case 3: MPB_NAR_LAUNCH(3); break;
-    default: MPB_NAR_LAUNCH(4); break;
+#define MPB_NRS_LAUNCH(RR) hipLaunchKernelGGL((k_narrow_rs<RR>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, rs_k, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
+    if (rs_k) {
+        switch (rows0) {
+        case 2: MPB_NRS_LAUNCH(2); break;
+        case 3: MPB_NRS_LAUNCH(3); break;
+        default: MPB_NRS_LAUNCH(4); break;
+        }
+    } else {
+        switch (rows0) {
+        case 2: MPB_NAR_LAUNCH(2); break;
+        case 3: MPB_NAR_LAUNCH(3); break;
+        default: MPB_NAR_LAUNCH(4); break;
+        }
     }
+#undef MPB_NRS_LAUNCH
 #undef MPB_NAR_LAUNCH
 #ifdef MPB_NAR_STAMPS
     if (getenv("MPB_NAR_STAMPS_PRINT")) {
@@ -2358,7 +2604,7 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
     }
 #endif
     hipLaunchKernelGGL(k_nar_offsets, dim3(1), dim3(1024), 0, s, ws.nar_wave_count, nwaves, ws.nar_wave_off, ws.nar_count);
-    hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, ws.nar_wave_off, nblk, nwaves, list);
+    hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, ws.nar_wave_off, nblk, nwaves, per_blk, list);
 }
 
 void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,

@@ -58,10 +58,16 @@ def test_forced_narrow_is_the_oracle(eng, oracle, rows, profile):
 
 @pytest.mark.parametrize("L,stride", [(1, 16), (3, 16), (15, 16), (16, 16), (17, 32), (63, 64), (64, 64), (65, 80), (100, 112),
                                       (127, 128), (128, 128), (129, 144), (250, 256), (299, 304), (300, 304), (301, 304),
-                                      (300, 320), (320, 320), (600, 608), (1000, 1008), (1023, 1024), (1500, 1536)])
+                                      (300, 320), (320, 320), (600, 608), (1000, 1008), (1023, 1024), (1500, 1536),
+                                      # k_narrow_rs (strides that are a multiple of 64): one read per lane (stride % 128 == 0) and
+                                      # two (stride % 128 == 64); reads that end on a half panel, one chunk into one, and far before
+                                      # the row does (whole halves and panels of padding are skipped)
+                                      (10, 320), (64, 320), (130, 320), (257, 320), (40, 256), (65, 128), (100, 192), (191, 192),
+                                      (383, 384), (200, 384), (440, 448), (2000, 2048), (30, 1024)])
 def test_lengths_and_strides(eng, oracle, L, stride):
     """Every tail shape of the panel walk: lengths that end inside a dword, a chunk, a panel; strides that are not a multiple of
-    the 64-byte panel (the last panel's DMA is clamped into the row); garbage past the read's end."""
+    the 64-byte panel (k_narrow: the last panel's DMA is clamped into the row) and strides that are (k_narrow_rs: a lane walks
+    one or two rows as one stream of whole 128-byte lines); garbage past the read's end."""
     rng = np.random.default_rng(L * 1000 + stride)
     n = 1000 + (L % 7)
     q = rng.integers(20, 41, (n, stride), dtype=np.uint8)

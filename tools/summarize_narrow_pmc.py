@@ -58,7 +58,7 @@ for k, v in out.items():
         v["clock_ghz"] = v["GRBM_GUI_ACTIVE"] / 8 / v["duration_us_sq"] / 1e3
         v["valu_busy"] = v["SQ_INSTS_VALU"] * 4 / (v["GRBM_GUI_ACTIVE"] / 8 * 1024)
 json.dump(out, open(os.path.join(dst, tag + "_pmc_hq.json"), "w"), indent=1, sort_keys=True)
-kname = next((x for x in sorted(out) if x.startswith("k_narrow<2")), "")
+kname = next((x for x in sorted(out, reverse=True) if x.startswith("k_narrow_rs<2") or x.startswith("k_narrow<2")), "")
 k = out.get(kname, {})
 if "hbm_read_bytes_exact" in k:
     rd, wr = k["hbm_read_bytes_exact"], k.get("hbm_write_bytes_exact", k.get("hbm_write_bytes_write_size", 0))
