@@ -356,7 +356,10 @@ int mpb_filter_host_coded(mpb_ctx *ctx, const uint8_t *q, int64_t n, int64_t row
  * broker -- owns the GPU; the workers never touch it: mpb_broker_call() packs the read (host only, the packer of
  * mpb_calculate_errors_PB) into the caller's slot of a shared-memory segment and waits, the broker gathers whatever is
  * pending into one launch of the one-read-per-wave kernel (several such micro-batches in flight) and hands the results
- * back through the slots.  Results are those of mpb_calculate_errors_PB bit for bit, scores above 254 included.
+ * back through the slots -- or (the default since round 5) keeps ONE kernel resident while calls arrive, a wave per slot that
+ * polls the slot's mailbox entry in pinned host memory: no launch per call; that kernel leaves by itself after 100 ms and
+ * is launched again while calls keep coming (environment MPB_BROKER_SERVER=0: the launches).
+ * Results are those of mpb_calculate_errors_PB bit for bit, scores above 254 included.
  *
  *   mpb_broker_serve   runs the broker loop on `ctx` in the calling thread until mpb_broker_shutdown(name), or until no
  *                      live process has been attached and nothing has been asked for idle_exit_ms milliseconds
@@ -368,7 +371,7 @@ int mpb_filter_host_coded(mpb_ctx *ctx, const uint8_t *q, int64_t n, int64_t row
  *                      itself (mpb_broker_call refuses an attachment made by another pid).
  *   mpb_broker_call    the per-read entry, arguments and errors of mpb_calculate_errors_PB.  MPB_E_HIP when the broker
  *                      stops or dies while the read is pending (the caller may start a new one and attach again).
- *   mpb_broker_stats   reads served / micro-batches launched / reads run alone (row budget missed, or scores above
+ *   mpb_broker_stats   reads served / launches (micro-batches, or generations of the resident kernel) / reads run alone (row budget missed, or scores above
  *                      254), the broker's pid (0: not serving) and the number of attached processes; any may be NULL.
  */
 typedef struct mpb_broker_client mpb_broker_client;

@@ -26,6 +26,9 @@ DEPS = SOURCES + [os.path.join(CSRC, "mpb_internal.h"), os.path.join(CSRC, "mpb_
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
          "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall", "-Wno-unused-function",
+         # a kernel that misses its occupancy target (k_dp at 2 waves per SIMD because a new caller of the shared class bodies
+         # allowed them more registers) must fail the build, not cost 40 % silently
+         "-Werror=pass-failed",
          "-fvisibility=hidden",          # only what include/moira_pb.h declares is exported ...
          "-Wl,--version-script=" + os.path.join(CSRC, "libmoira_pb.map"),   # ... not even weak std:: template instances
          "-x", "hip"]

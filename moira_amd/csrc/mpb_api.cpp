@@ -1563,6 +1563,20 @@ int mpbi_small_async(mpb_ctx *c, const uint8_t *d_q, int64_t m, int64_t stride, 
     return MPB_OK;
 }
 
+void mpbi_small_params(double alpha, MpbDevParams *out)
+{
+    mpb_filter_params prm;
+    prm.alpha = alpha; prm.uncert = 1.0; prm.maxerrors = NAN; prm.ambig_mode = MPB_AMBIG_IGNORE; prm.flags = 0;
+    *out = make_dev_params(&prm, 0, MPB_SERVE_STRIDE);
+}
+
+int mpbi_serve_launch(mpb_ctx *c, const MpbServeBox *box, uint32_t generation, uint32_t lifetime_ms, hipStream_t s)
+{
+    mpb_launch_serve(*box, c->d_lut, generation, lifetime_ms, s);
+    HIPCHK(hipGetLastError());
+    return MPB_OK;
+}
+
 int mpbi_ctx_device(const mpb_ctx *c) { return c ? c->device : -1; }
 
 int mpbi_fail(int code, const char *msg) { return fail(code, "%s", msg); }

@@ -6,7 +6,8 @@
 // whatever P is: profiles/r03_per_read_concurrency.txt).  Here the workers never touch the GPU: a call packs its read into
 // a slot of a shared-memory segment and waits; the broker process gathers whatever is pending -- at most one read per
 // worker, they block -- into ONE launch of the one-read-per-wave kernel (k_small), several such micro-batches in flight on
-// streams of their own, and hands the results back through the slots.
+// streams of their own, and hands the results back through the slots.  Since round 5 the default is no launch per call at
+// all: a resident kernel (k_serve), a wave per slot polling a mailbox entry in pinned host memory (`Server` below).
 //
 // Segment (POSIX shared memory, name "/moira_pb_<name>"): a header and n_slots slots of fixed size.  A client owns one
 // slot for as long as it is attached (claimed by a compare-and-swap of its pid); a slot whose owner has died is reclaimed
@@ -200,6 +201,171 @@ struct Broker {
     // (calls on one context must not overlap)
     std::atomic<int> solo_q[BRK_MAX_SLOTS];
     std::atomic<uint32_t> solo_head{0}, solo_tail{0};
+
+    // ---- the resident server (k_serve, mpb_kernels.hip): calls without a launch each -------------------------------------
+    // One mailbox entry per slot in pinned host memory; the broker thread copies a request in (row, parameters, then the
+    // door word) and polls done[e]; the kernel's waves poll the door words over the link.  The kernel leaves by itself
+    // when its lifetime is over (the grid always drains) and says so in *exited: while calls keep coming it is launched
+    // again at once, otherwise by the next call.  MPB_BROKER_SERVER=0 keeps the launch-per-micro-batch lanes.
+    struct Server {
+        bool enabled = false, running = false;
+        hipStream_t stream = nullptr;
+        char *pin = nullptr, *dev = nullptr;
+        MpbServeBox box{};
+        uint8_t *h_q = nullptr;
+        MpbServePrm *h_prm = nullptr;
+        volatile unsigned long long *h_door = nullptr;
+        volatile uint32_t *h_done = nullptr, *h_stop = nullptr, *h_exited = nullptr;
+        double *h_ee = nullptr;
+        int32_t *h_ns = nullptr;
+        uint8_t *h_pass = nullptr;
+        uint32_t generation = 0;
+        uint32_t tok[BRK_MAX_SLOTS];
+        bool posted[BRK_MAX_SLOTS];
+        int64_t posted_us[BRK_MAX_SLOTS];
+        int n_posted = 0;
+        int64_t launched_us = 0, last_post_us = 0;
+        double cached_alpha = -1.0;
+        MpbDevParams cached_prm;
+        uint32_t lifetime_ms = 100;
+        int64_t turn_us = 0, turn_n = 0;                    // MPB_BROKER_TRACE: door word -> results seen, summed
+    } srv;
+
+    int init_server()
+    {
+        const size_t ns = (size_t)n_slots;
+        size_t o = 0;
+        auto take_bytes = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_q = take_bytes(ns * MPB_SERVE_STRIDE), o_prm = take_bytes(ns * sizeof(MpbServePrm)), o_door = take_bytes(ns * 8),
+                     o_done = take_bytes(ns * 4), o_ee = take_bytes(ns * 8), o_ns = take_bytes(ns * 4), o_pass = take_bytes(ns),
+                     o_stop = take_bytes(64), o_exited = take_bytes(64);
+        const size_t pin_bytes = o;
+        o = 0;
+        const size_t d_stage = take_bytes(ns * MPB_SERVE_STRIDE + ns * 64 /* experiment builds: per-entry stamps behind the rows */), d_ns = take_bytes(ns * 4), d_cls = take_bytes(ns), d_ident = take_bytes(ns * 4),
+                     d_gone = take_bytes(64);
+        const size_t dev_bytes = o;
+        BHIP(hipStreamCreateWithFlags(&srv.stream, hipStreamNonBlocking));
+        BHIP(hipHostMalloc((void **)&srv.pin, pin_bytes, hipHostMallocMapped));
+        BHIP(hipMalloc((void **)&srv.dev, dev_bytes));
+        BHIP(hipMemset(srv.dev, 0, dev_bytes));
+        memset(srv.pin, 0, pin_bytes);
+        srv.h_q = (uint8_t *)(srv.pin + o_q);
+        srv.h_prm = (MpbServePrm *)(srv.pin + o_prm);
+        srv.h_door = (volatile unsigned long long *)(srv.pin + o_door);
+        srv.h_done = (volatile uint32_t *)(srv.pin + o_done);
+        srv.h_ee = (double *)(srv.pin + o_ee);
+        srv.h_ns = (int32_t *)(srv.pin + o_ns);
+        srv.h_pass = (uint8_t *)(srv.pin + o_pass);
+        srv.h_stop = (volatile uint32_t *)(srv.pin + o_stop);
+        srv.h_exited = (volatile uint32_t *)(srv.pin + o_exited);
+        MpbServeBox &x = srv.box;
+        x.q = srv.h_q; x.stride = MPB_SERVE_STRIDE; x.prm = srv.h_prm; x.door = (const unsigned long long *)srv.h_door;
+        x.done = (uint32_t *)srv.h_done; x.ee = srv.h_ee; x.ns = srv.h_ns; x.pass = srv.h_pass;
+        x.stop = (const uint32_t *)srv.h_stop; x.exited = (uint32_t *)srv.h_exited;
+        x.stage = (uint8_t *)(srv.dev + d_stage); x.ns_dev = (int32_t *)(srv.dev + d_ns); x.cls = (uint8_t *)(srv.dev + d_cls);
+        x.ident = (int32_t *)(srv.dev + d_ident); x.gone = (uint32_t *)(srv.dev + d_gone);
+        x.n_ent = n_slots;
+        for (int i = 0; i < BRK_MAX_SLOTS; i++) { srv.tok[i] = 0; srv.posted[i] = false; srv.posted_us[i] = 0; }
+        srv.enabled = true;
+        return MPB_OK;
+    }
+
+    uint32_t exited_generation() const { return __atomic_load_n((const uint32_t *)srv.h_exited, __ATOMIC_ACQUIRE); }
+
+    int server_launch()
+    {
+        if (++srv.generation == 0) srv.generation = 1;
+        const int rc = mpbi_serve_launch(ctx, &srv.box, srv.generation, srv.lifetime_ms, srv.stream);
+        if (rc) return rc;
+        srv.running = true;
+        srv.launched_us = now_us();
+        map.hdr()->batches.fetch_add(1, std::memory_order_relaxed);
+        return MPB_OK;
+    }
+
+    // the request of slot si (taken: s_len / s_alpha are the checked copies) -> its mailbox entry
+    int server_post(int si)
+    {
+        BrkSlot *s = map.slot(si);
+        const int32_t len = s_len[si];
+        memcpy(srv.h_q + (size_t)si * MPB_SERVE_STRIDE, Mapping::row(s), (size_t)((len + 15) & ~15));
+        if (s_alpha[si] != srv.cached_alpha) { mpbi_small_params(s_alpha[si], &srv.cached_prm); srv.cached_alpha = s_alpha[si]; }
+        srv.h_prm[si].p = srv.cached_prm;
+        uint32_t t = srv.tok[si] + 1;
+        if (t == 0) t = 1;
+        srv.tok[si] = t;
+        __atomic_store_n((unsigned long long *)&srv.h_door[si], ((unsigned long long)(uint32_t)len << 32) | t, __ATOMIC_RELEASE);
+        srv.posted[si] = true;
+        srv.posted_us[si] = srv.last_post_us = now_us();
+        srv.n_posted++;
+        if (!srv.running) return server_launch();
+        return MPB_OK;
+    }
+
+    // results of the entries that have been served; true if any
+    bool server_collect()
+    {
+        bool any = false;
+        for (int i = 0; i < n_slots && srv.n_posted > 0; i++) {
+            if (!srv.posted[i] || __atomic_load_n((const uint32_t *)&srv.h_done[i], __ATOMIC_ACQUIRE) != srv.tok[i]) continue;
+            srv.posted[i] = false;
+            srv.n_posted--;
+            any = true;
+            srv.turn_us += now_us() - srv.posted_us[i];
+            srv.turn_n++;
+            if (srv.h_pass[i] == 2) run_solo(i);           // row budget missed (or a wide read): the ordinary per-read path
+            else finish(i, MPB_OK, srv.h_ee[i], srv.h_ns[i], nullptr);
+        }
+        return any;
+    }
+
+    // the launch has drained (lifetime over): again at once while calls are pending or were a moment ago.
+    // A request that has been out for 50 ms: ask the runtime (a fault shows there).
+    int server_watch()
+    {
+        if (srv.running && exited_generation() == srv.generation) srv.running = false;
+        const int64_t t = now_us();
+        if (!srv.running && (srv.n_posted > 0 || t - srv.last_post_us < 20000)) return server_launch();
+        if (srv.running && srv.n_posted > 0) {
+            int64_t oldest = t;
+            for (int i = 0; i < n_slots; i++) if (srv.posted[i] && srv.posted_us[i] < oldest) oldest = srv.posted_us[i];
+            if (t - oldest > 50000 && t - srv.launched_us > 50000) {
+                const hipError_t q = hipStreamQuery(srv.stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return mpbi_fail(MPB_E_HIP, hipGetErrorString(q));
+                if (q == hipSuccess && exited_generation() != srv.generation) srv.running = false;   // gone without a word: launch again
+            }
+        }
+        return MPB_OK;
+    }
+
+    void free_server()
+    {
+        if (!srv.stream) return;
+        if (srv.h_stop) __atomic_store_n((uint32_t *)srv.h_stop, 1u, __ATOMIC_SEQ_CST);
+        if (getenv("MPB_BROKER_TRACE") && srv.turn_n) {
+            fprintf(stderr, "[broker] resident server: %lld requests, %.1f us from the door word to the results on average, %u launches\n",
+                    (long long)srv.turn_n, (double)srv.turn_us / (double)srv.turn_n, srv.generation);
+#ifdef MPB_SERVE_STAMPS
+            (void)hipStreamSynchronize(srv.stream);
+            unsigned long long h[BRK_MAX_SLOTS * 8];
+            if (hipMemcpy(h, srv.dev + (size_t)n_slots * MPB_SERVE_STRIDE, (size_t)n_slots * 64, hipMemcpyDeviceToHost) == hipSuccess) {
+                unsigned long long t[5] = {0, 0, 0, 0, 0};
+                for (int i = 0; i < n_slots; i++) for (int k = 0; k < 5; k++) t[k] += h[i * 8 + k];
+                if (t[0]) fprintf(stderr, "[k_serve stamps] %llu requests: read .. results %.2f us, fence + done %.2f us, whole %.2f us, shader clock %.0f MHz\n",
+                                  t[0], t[1] * 0.01 / t[0], t[2] * 0.01 / t[0], t[4] * 0.01 / t[0], (double)t[3] / ((double)t[4] * 0.01));
+            }
+#endif
+        }
+        (void)hipStreamSynchronize(srv.stream);
+        if (srv.running && srv.h_exited) {                  // (a runtime that completes at once -- the test stub -- still has its server out)
+            const int64_t until = now_ms() + 2000;
+            while (exited_generation() != srv.generation && now_ms() < until) usleep(100);
+        }
+        (void)hipStreamDestroy(srv.stream);
+        if (srv.pin) (void)hipHostFree(srv.pin);
+        if (srv.dev) (void)hipFree(srv.dev);
+        srv.stream = nullptr; srv.pin = srv.dev = nullptr; srv.enabled = srv.running = false;
+    }
 
     bool take(int si)                                                  // SUBMITTED -> RUNNING with a checked copy of the request
     {
@@ -469,6 +635,8 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
     const int gather_us = getenv("MPB_BROKER_GATHER_US") ? atoi(getenv("MPB_BROKER_GATHER_US")) : 5;
     const bool retire_thread = getenv("MPB_BROKER_RETIRE_THREAD") && atoi(getenv("MPB_BROKER_RETIRE_THREAD")) != 0;
     rc = b.init_lanes();
+    const bool want_server = !(getenv("MPB_BROKER_SERVER") && atoi(getenv("MPB_BROKER_SERVER")) == 0) && b.zero_copy;
+    if (rc == MPB_OK && want_server) rc = b.init_server();
     if (rc == MPB_OK) {
         std::atomic_thread_fence(std::memory_order_seq_cst);
         h->magic = BRK_MAGIC;                        // clients accept the segment from here on
@@ -525,10 +693,26 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
         }
         if (rc) break;
         if (b.run_queued_solos()) progress = true;
+        if (b.srv.enabled) {
+            // 1s. results of the entries the resident server has finished; 2s. whatever has been submitted goes into its entry
+            if (b.server_collect()) progress = true;
+            for (int i = 0; i < n_slots && rc == MPB_OK; i++) {
+                BrkSlot *s = b.map.slot(i);
+                if (s->state.load(std::memory_order_acquire) != ST_SUBMITTED) continue;
+                progress = true;
+                if (!b.take(i)) continue;                      // malformed: answered with MPB_E_INVALID
+                if (b.s_priv[i] || b.s_len[i] > MPB_SERVE_STRIDE - 1) { b.run_solo(i); continue; }   // its own table / a long row
+                const int prc = b.server_post(i);
+                if (prc) { b.finish(i, prc, 0, 0, mpb_last_error()); b.srv.posted[i] = false; b.srv.n_posted--; if (prc == MPB_E_HIP) rc = prc; }
+            }
+            if (rc == MPB_OK) { const int wrc = b.server_watch(); if (wrc == MPB_E_HIP) rc = wrc; }
+            if (rc) break;
+            if (b.srv.n_posted > 0) any_busy = true;
+        }
         // 2. whatever has been submitted goes into the next free lane
         Lane *free_lane = nullptr;
         for (Lane &l : b.lane) if (!l.busy.load(std::memory_order_acquire)) { free_lane = &l; break; }
-        if (free_lane) {
+        if (free_lane && !b.srv.enabled) {
             int m = 0, attached = 0, running = 0;
             double alpha = 0;
             auto collect = [&](bool first) {
@@ -611,6 +795,11 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
     quit.store(1, std::memory_order_release);
     if (retirer.joinable()) retirer.join();
     for (Lane &l : b.lane) if (l.busy.load()) { if (hipStreamSynchronize(l.stream) == hipSuccess) b.retire(l); else b.fail_lane(l, MPB_E_HIP); }
+    if (b.srv.enabled && rc == MPB_OK) {                  // what the resident server still has: a moment to finish, then its results
+        const int64_t until = now_ms() + 200;
+        while (b.srv.n_posted > 0 && now_ms() < until) { if (!b.server_collect()) cpu_relax(); if (b.server_watch()) break; }
+    }
+    b.free_server();
     if (rc == MPB_OK) (void)b.run_queued_solos();
     for (int i = 0; i < n_slots; i++) {
         BrkSlot *s = b.map.slot(i);

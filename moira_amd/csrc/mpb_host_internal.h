@@ -23,6 +23,12 @@ int mpbi_small_async(mpb_ctx *c, const uint8_t *d_q, int64_t m, int64_t stride, 
                      const MpbSmallHost *host /* nullptr, or the device scratch + completion flags that go with inputs and
                                                  outputs in pinned host memory (mpb_internal.h) */);
 int mpbi_wait_flags(const volatile uint32_t *done, int64_t n, uint32_t token, hipStream_t s);
+// the resident one-read server (k_serve): parameters of a request with this alpha (what mpbi_small_async gives its launch);
+// one launch of the server over `box` (generation, lifetime); is a launch on `s` still out?
+struct MpbServeBox;
+struct MpbDevParams;
+void mpbi_small_params(double alpha, MpbDevParams *out);
+int mpbi_serve_launch(mpb_ctx *c, const MpbServeBox *box, uint32_t generation, uint32_t lifetime_ms, hipStream_t s);
 
 }
 

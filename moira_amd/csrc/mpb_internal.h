@@ -158,6 +158,27 @@ struct MpbSmallHost {
 void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                       const MpbWorkspace &ws, int32_t *ns, double *ee, uint8_t *pass, hipStream_t s,
                       const MpbSmallHost *host = nullptr);
+// The resident one-read server (k_serve; the broker's calls without a launch each): n_ent mailbox entries, one wave each.
+// Everything the host and the device exchange lies in pinned HOST memory (mapped); the scratch the class body walks in HBM.
+#define MPB_SERVE_STRIDE 2048            // row bytes of a mailbox entry: reads of up to 2047 bases (longer ones take the other paths)
+struct alignas(64) MpbServePrm { MpbDevParams p; };      // one 64-byte line per request
+struct MpbServeBox {
+    // pinned host memory, [n_ent] each
+    const uint8_t *q;                    // rows of `stride` bytes (written by the host before the door word)
+    int64_t stride;
+    const MpbServePrm *prm;              // the request's parameters (fixed_len / max_len are set by the wave)
+    const unsigned long long *door;      // {length << 32 | token}: a token that differs from done[e] is a request
+    uint32_t *done;                      // the token of the last request served
+    double *ee; int32_t *ns; uint8_t *pass;      // its results (pass == 2: the row budget was missed, the host runs it alone)
+    const uint32_t *stop;                // [1] non-zero: every wave leaves
+    uint32_t *exited;                    // [1] the generation of the last launch that has drained
+    // device memory
+    uint8_t *stage;                      // [n_ent x stride] the row, parked by the statistics pass
+    int32_t *ns_dev; uint8_t *cls; int32_t *ident;   // [n_ent] what the class body reads back
+    uint32_t *gone;                      // [1] waves that have left (zeroed before the launch)
+    int32_t n_ent;
+};
+void mpb_launch_serve(const MpbServeBox &box, const double2 *lut, uint32_t generation, uint32_t lifetime_ms, hipStream_t s);
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s);
 void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const MpbDevParams &prm, const MpbWorkspace &ws,
                         hipStream_t s);

@@ -1217,47 +1217,44 @@ __global__ __launch_bounds__(64 * W) void k_wide(DpArgs A, const double2 *__rest
 // latency.  Same prediction formula, same class bodies, same results; a read whose CDF does not
 // cross inside its class is marked pass = 2 and the host sends the batch down the batched path.
 // ------------------------------------------------------------------------------------------
-template <bool FMA>
-__global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args, const double2 *__restrict__ lut_g,
-                                                                    int64_t n, int32_t *__restrict__ ns_out,
-                                                                    uint8_t *__restrict__ cls_out,
-                                                                    int32_t *__restrict__ ident,
-                                                                    uint8_t *__restrict__ stage,
-                                                                    uint32_t *__restrict__ done, uint32_t token)
+#ifdef MPB_SERVE_STAMPS
+__device__ unsigned long long g_sv[8];
+#define SV_STAMP(k) do { const long long t__ = wall_clock64(); if (lane == 0) atomicAdd(&g_sv[k], (unsigned long long)(t__ - sv_t)); sv_t = wall_clock64(); } while (0)
+#define SV_BEGIN long long sv_t = wall_clock64()
+#else
+#define SV_STAMP(k)
+#define SV_BEGIN
+#endif
+// One read, one wave: statistics (and parking the row in device memory when it arrives in pinned host memory), the row
+// prediction, the latency body of its class.  Shared by k_small (a launch per micro-batch) and k_serve (resident waves).
+// `prm` and `li` are the read's own; s_args (LDS, this wave's) is what the non-inlined class body reads.
+// SYS: the row lies in pinned host memory that is rewritten while the kernel runs (k_serve): it is read with system-scope
+// loads, which never stop at a cache, instead of behind a cache-invalidating fence (which would also empty the L2 of what
+// the class body is about to read: measured 6 us per request).  `get_prm` hands over the read's parameters when they are
+// first needed -- after the statistics -- so that a caller who fetches them over the link can have that load in flight
+// beside the row's.
+template <bool FMA, bool SYS, typename PrmFn>
+__device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs *s_args, PrmFn get_prm, const int li,
+                                               const int64_t i, const int lane, int32_t *__restrict__ ns_out,
+                                               uint8_t *__restrict__ cls_out, int32_t *__restrict__ ident,
+                                               uint8_t *__restrict__ stage, const float2 *s_tab)
 {
-    // done != nullptr (pinned host memory): when a read's results are out -- and visible system-wide -- its wave writes
-    // `token` to done[i], so that the host learns of the END OF ITS READS from memory instead of from the runtime's
-    // completion signal (which comes several microseconds after the last wave, and costs a runtime call to ask for).
-    // ns_out is where the ambiguity counts are REPORTED; args.ns (device memory, may be the same array) is where the class
-    // body reads them back: a report that lives in host memory is not read back over the link.
-    // stage != nullptr: args.q is pinned HOST memory (the per-read entry and the broker's micro-batches: one runtime call
-    // per launch, no copy in).  The statistics pass below reads every chunk of the row anyway -- one trip over the link, all
-    // lanes at once -- and leaves it in `stage` (device memory, same shape), which is what the class body then walks: its
-    // five dependent 64-byte trips per 300 bases would otherwise each pay the link's latency.
-    __shared__ float2 s_tab[256];
-    __shared__ DpArgs s_args;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    mpb_s_lut[tid] = lut_g[tid];
-    {
-        const bool amb = tid == 0 || tid == 255;
-        float p = __builtin_amdgcn_exp2f(-0.33219281f * (float)tid);      // 10^(-q/10)
-        p = amb ? 0.0f : p;
-        s_tab[tid] = make_float2(p, tid == 0 ? MPB_MARK_UPPER : tid == 255 ? MPB_MARK_LOWER : p * (1.0f - p));
-    }
-    if (tid == 0) { s_args = args; if (stage) s_args.q = stage; }
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * 4 + w;
-    if (i >= n) return;                                   // wave-uniform; no barrier below
-    do {                                                  // (one exit for every read: the completion flag below)
-    const MpbDevParams &prm = args.prm;
-    const int li = args.len ? clamp_len(args.len[i], prm.max_len) : prm.fixed_len;
     // lane k takes the 16-byte chunks k, k + 64, ... of the row (at most 16 of them: 256 bytes, so the markers peel exactly)
     f32x2 a01 = {0.f, 0.f};
     float s3 = 0.f;
+    SV_BEGIN;
     for (int c0 = 0; c0 * 16 < li; c0 += 64) {            // wave-uniform trip count
         const int nv = li - (c0 + lane) * 16;
         if (nv > 0) {
-            uint4 y = *reinterpret_cast<const uint4 *>(args.q + i * args.stride + (int64_t)(c0 + lane) * 16);
+            const uint8_t *src = args.q + i * args.stride + (int64_t)(c0 + lane) * 16;
+            uint4 y;
+            if (SYS) {
+                const unsigned long long lo = __hip_atomic_load((const unsigned long long *)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long hi = __hip_atomic_load((const unsigned long long *)src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                y = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+            } else {
+                y = *reinterpret_cast<const uint4 *>(src);
+            }
             if (stage) *reinterpret_cast<uint4 *>(stage + i * args.stride + (int64_t)(c0 + lane) * 16) = y;
             y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
             y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
@@ -1278,6 +1275,8 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
         ambi += __shfl_xor(ambi, off);
     }
     const int nzero = (int)(ambi & 0xffffu), n_lower = (int)(ambi >> 16);
+    SV_STAMP(0);
+    const MpbDevParams prm = get_prm();
     const float v = fmaxf(var, 1e-12f);
     const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;           // as k_prepass
     int rows = (int)floorf(fminf(x, 1e9f) + 0.5f) + 1;
@@ -1285,7 +1284,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
     rows = max(min(rows, li - nzero - n_lower + 1), 1);
     if (rows > MPB_TILE_MAX_ROWS) {                                       // a wide read: the host sends the batch down the pipeline
         if (lane == 0) args.pass[i] = 2;
-        break;
+        return;
     }
     const int c = c_class_of_rows.t[rows];
     // One read per wave: a G = 1 body would keep ONE lane busy.  The latency bodies below spread the read's rows over as
@@ -1306,20 +1305,166 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
         ident[i] = (int32_t)i;
         if (settled) { args.ee[i] = __builtin_inf(); args.pass[i] = 0; }
     }
-    if (settled) break;
-    __threadfence();                                      // the class body reads ns / cls / ident back
+    if (settled) return;
+    SV_STAMP(1);
+    // the class body (this wave, other lanes) reads ns / cls / ident / the parked row back: the stores out of the CU, its L1 emptied
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    SV_STAMP(2);
     const int32_t *pc = ident + i;
     switch (thin) {
-#define MPB_CASE(ID, RR, GG) case ID: dp_tiles<RR, GG, FMA>(&s_args, pc, 1, 0, 1); break;
+#define MPB_CASE(ID, RR, GG) case ID: dp_tiles<RR, GG, FMA>(s_args, pc, 1, 0, 1); break;
         MPB_THIN_CLASSES(MPB_CASE)
 #undef MPB_CASE
     default: break;
     }
-    } while (0);
+    SV_STAMP(3);
+#ifdef MPB_SERVE_STAMPS
+    if (lane == 0) atomicAdd(&g_sv[7], 1ull);
+#endif
+}
+
+// the per-wave tables of the one-read path: {1 - p, p'} in LDS (module scope, for the class bodies) and the fp32 statistics table
+__device__ __forceinline__ void small_tables(const double2 *__restrict__ lut_g, float2 *s_tab, const int tid0, const int nthreads)
+{
+    for (int tid = tid0; tid < 256; tid += nthreads) {
+        mpb_s_lut[tid] = lut_g[tid];
+        const bool amb = tid == 0 || tid == 255;
+        float p = __builtin_amdgcn_exp2f(-0.33219281f * (float)tid);      // 10^(-q/10)
+        p = amb ? 0.0f : p;
+        s_tab[tid] = make_float2(p, tid == 0 ? MPB_MARK_UPPER : tid == 255 ? MPB_MARK_LOWER : p * (1.0f - p));
+    }
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args, const double2 *__restrict__ lut_g,
+                                                                    int64_t n, int32_t *__restrict__ ns_out,
+                                                                    uint8_t *__restrict__ cls_out,
+                                                                    int32_t *__restrict__ ident,
+                                                                    uint8_t *__restrict__ stage,
+                                                                    uint32_t *__restrict__ done, uint32_t token)
+{
+    // done != nullptr (pinned host memory): when a read's results are out -- and visible system-wide -- its wave writes
+    // `token` to done[i], so that the host learns of the END OF ITS READS from memory instead of from the runtime's
+    // completion signal (which comes several microseconds after the last wave, and costs a runtime call to ask for).
+    // ns_out is where the ambiguity counts are REPORTED; args.ns (device memory, may be the same array) is where the class
+    // body reads them back: a report that lives in host memory is not read back over the link.
+    // stage != nullptr: args.q is pinned HOST memory (the per-read entry and the broker's micro-batches: one runtime call
+    // per launch, no copy in).  The statistics pass reads every chunk of the row anyway -- one trip over the link, all
+    // lanes at once -- and leaves it in `stage` (device memory, same shape), which is what the class body then walks: its
+    // five dependent 64-byte trips per 300 bases would otherwise each pay the link's latency.
+    // Where a one-read call's 12.5 us inside the kernel go (300 bases, in-kernel stamps, profiles/r05_per_read_server.txt):
+    // tables + barrier 0.7, row over the link + statistics 2.6, class body 8.5 (2.7 + 19 ns per base), completion 0.6.
+    __shared__ float2 s_tab[256];
+    __shared__ DpArgs s_args;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    small_tables(lut_g, s_tab, tid, 256);
+    if (tid == 0) { s_args = args; if (stage) s_args.q = stage; }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= n) return;                                   // wave-uniform; no barrier below
+    const int li = args.len ? clamp_len(args.len[i], args.prm.max_len) : args.prm.fixed_len;
+    small_one_read<FMA, false>(args, &s_args, [&] { return args.prm; }, li, i, lane, ns_out, cls_out, ident, stage, s_tab);
     if (done) {
         __threadfence_system();                           // every lane's stores of this wave: out, and visible to the host
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) __hip_atomic_store(done + i, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_serve: the one-read path WITHOUT a launch per call (round 5).  A per-read call through k_small costs 27-28 us of which
+// the kernel is 12.5 and the launch + dispatch + completion hand-shake the rest; with P workers calling at once the broker
+// thread's launches bound the rate.  So the broker keeps this kernel resident while calls arrive: one wave per mailbox entry
+// (= per broker slot), every entry in pinned host memory.  A wave polls its entry's 8-byte door word {token, length} over the
+// link; a new token = a request: it reads the request's parameters and its row (one trip over the link, as k_small), runs
+// small_one_read, writes ee / Ns / pass to the entry, fences system-wide and stores the token to done[e].  The host side
+// (mpb_broker.cpp) writes row + parameters, then the door word; it learns of the result from done[e].
+// EVERY wave leaves when the host sets *stop, and -- whatever the host does -- when its lifetime (ticks of the 100 MHz
+// clock) is over: the grid always drains.  The last wave out stores `generation` to *exited, so that the host re-launches at
+// once while calls keep coming.  A request posted to an entry whose wave has just left is served by the next launch (a
+// wave starts from done[e]: whatever token differs from it is pending).
+// ------------------------------------------------------------------------------------------
+// ONE wave per workgroup: a CU's vector memory path hands data back in request order, so a sibling wave that polls the
+// link (2 us per look) on the same CU delays every load of the wave that works (measured: 23 instead of 9 us of class body).
+// (Launched with 64 threads per workgroup, but DECLARED with k_dp's bounds: the class bodies are functions shared with k_dp,
+// and a caller that allowed them 512 registers would halve k_dp's occupancy.)
+__global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox box, const double2 *__restrict__ lut_g,
+                                                                    uint32_t generation, unsigned long long lifetime_ticks)
+{
+    __shared__ float2 s_tab[256];
+    __shared__ DpArgs s_args[1];
+    const int lane = threadIdx.x;
+    constexpr int w = 0;
+    small_tables(lut_g, s_tab, lane, 64);
+    __syncthreads();
+    const int e = blockIdx.x;                             // this wave's entry
+    if (e < box.n_ent) {
+        const long long t_start = wall_clock64();
+        DpArgs A;
+        A.q = box.q; A.stride = box.stride; A.len = nullptr; A.ns = box.ns_dev; A.cls = box.cls; A.ee = box.ee; A.pass = box.pass;
+        A.ovf_list = nullptr; A.ovf_count = nullptr; A.alg_cells = nullptr; A.perm = nullptr; A.perm_ns = nullptr; A.final_pass = 2;
+        uint32_t last = __hip_atomic_load(box.done + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (;;) {
+            const unsigned long long door = __hip_atomic_load(box.door + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t token = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)door);
+            if (token != last) {
+#ifdef MPB_SERVE_STAMPS                        // experiment: a request's time inside the wave (100 MHz ticks) and the shader clock it ran at
+                const long long ts0 = wall_clock64(), tc0 = clock64();
+#endif
+                asm volatile("" ::: "memory");               // what the host wrote before the door word is READ from here on, and
+                                                             // only with system-scope loads (no cache holds it): no invalidate
+                const int li = clamp_len(__builtin_amdgcn_readfirstlane((int)(uint32_t)(door >> 32)), (int)box.stride);
+                // the request's parameters: 64 bytes of pinned host memory, 16 per lane of the first four -- requested here,
+                // looked at after the row's statistics (one trip over the link for both)
+                const unsigned long long *hp = (const unsigned long long *)(box.prm + e) + 2 * (lane & 3);
+                const unsigned long long p_lo = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long p_hi = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                static_assert(sizeof(MpbServePrm) == 64, "one 64-byte line per request");
+                auto get_prm = [&] {
+                    const uint32_t xs[4] = {(uint32_t)p_lo, (uint32_t)(p_lo >> 32), (uint32_t)p_hi, (uint32_t)(p_hi >> 32)};
+                    uint32_t pw[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) pw[k] = (uint32_t)__builtin_amdgcn_readlane((int)xs[k & 3], k >> 2);
+                    MpbDevParams prm;
+                    __builtin_memcpy(&prm, pw, sizeof(prm));
+                    prm.fixed_len = li;
+                    prm.max_len = (int32_t)box.stride;
+                    A.prm = prm;
+                    if (lane == 0) { s_args[w] = A; s_args[w].q = box.stage; }
+                    wave_lds_fence();
+                    return prm;
+                };
+                small_one_read<false, true>(A, &s_args[w], get_prm, li, e, lane, box.ns, box.cls, box.ident, box.stage, s_tab);
+#ifdef MPB_SERVE_STAMPS
+                const long long ts1 = wall_clock64();
+#endif
+                __threadfence_system();                   // every lane's stores of this wave: out, and visible to the host
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) __hip_atomic_store(box.done + e, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef MPB_SERVE_STAMPS
+                if (lane == 0) {
+                    unsigned long long *dbg = (unsigned long long *)(box.stage + (size_t)box.n_ent * box.stride) + 8 * e;
+                    dbg[0] += 1; dbg[1] += (unsigned long long)(ts1 - ts0); dbg[2] += (unsigned long long)(wall_clock64() - ts1);
+                    dbg[3] += (unsigned long long)(clock64() - tc0); dbg[4] += (unsigned long long)(wall_clock64() - ts0);
+                }
+#endif
+                last = token;
+                continue;
+            }
+            if (__hip_atomic_load(box.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+            if ((unsigned long long)(wall_clock64() - t_start) > lifetime_ticks) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    // the last wave out tells the host
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        const uint32_t gone = atomicAdd(box.gone, 1u) + 1u;
+        if (gone == gridDim.x) {
+            __threadfence_system();
+            __hip_atomic_store(box.exited, generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -2516,6 +2661,22 @@ void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t
         hipLaunchKernelGGL((k_small<true>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage, done, token);
     else
         hipLaunchKernelGGL((k_small<false>), dim3(blocks), dim3(256), 0, s, A, ws.lut, n, ns, ws.cls, ws.perm, stage, done, token);
+}
+
+// the resident one-read server: one wave per mailbox entry; `gone` (device) is zeroed on the same stream first
+void mpb_launch_serve(const MpbServeBox &box, const double2 *lut, uint32_t generation, uint32_t lifetime_ms, hipStream_t s)
+{
+#ifdef MPB_SERVE_STAMPS
+    {
+        unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sv), sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sv), z, sizeof(z));
+        if (h[7]) fprintf(stderr, "[small_one_read stamps, us] row + statistics %.2f  prediction + report %.2f  fence %.2f  class body %.2f  (%llu reads)\n",
+                          h[0] * 0.01 / h[7], h[1] * 0.01 / h[7], h[2] * 0.01 / h[7], h[3] * 0.01 / h[7], h[7]);
+    }
+#endif
+    (void)hipMemsetAsync(box.gone, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_serve, dim3(box.n_ent), dim3(64), 0, s, box, lut, generation, (unsigned long long)lifetime_ms * 100000ull);
 }
 
 // ---- natural-order narrow pass ----------------------------------------------------------------------------------------

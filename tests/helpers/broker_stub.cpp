@@ -75,6 +75,60 @@ int mpbi_small_async(mpb_ctx *, const uint8_t *d_q, int64_t m, int64_t stride, c
 }
 int mpbi_wait_flags(const volatile uint32_t *, int64_t, uint32_t, hipStream_t) { return MPB_OK; }
 
+// ---- the resident server (k_serve), as a host thread that keeps k_serve's side of the mailbox protocol: it polls the door
+// words, answers with the oracle, stores the token to done[e], leaves on *stop or when its lifetime is over and says so in
+// *exited.  (The parameters carry 1 - alpha; the stub remembers which alpha each came from.)
+}   // extern "C"
+#include <chrono>
+#include <mutex>
+#include <thread>
+#include <vector>
+static std::mutex g_alpha_mu;
+static std::vector<std::pair<double, double>> g_alpha_of_thr;
+extern "C" {
+void mpbi_small_params(double alpha, MpbDevParams *out)
+{
+    memset(out, 0, sizeof(*out));
+    out->thr = 1 - alpha; out->uncert = 1.0; out->maxerrors = NAN; out->ambig_mode = 1;
+    std::lock_guard<std::mutex> g(g_alpha_mu);
+    for (auto &p : g_alpha_of_thr) if (p.first == out->thr) return;
+    g_alpha_of_thr.emplace_back(out->thr, alpha);
+}
+int mpbi_serve_launch(mpb_ctx *, const MpbServeBox *boxp, uint32_t generation, uint32_t lifetime_ms, hipStream_t)
+{
+    const MpbServeBox box = *boxp;
+    std::thread([box, generation, lifetime_ms] {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<uint32_t> last(box.n_ent);
+        for (int e = 0; e < box.n_ent; e++) last[e] = __atomic_load_n(box.done + e, __ATOMIC_ACQUIRE);
+        for (;;) {
+            bool any = false;
+            for (int e = 0; e < box.n_ent; e++) {
+                const unsigned long long door = __atomic_load_n(box.door + e, __ATOMIC_ACQUIRE);
+                const uint32_t token = (uint32_t)door;
+                if (token == last[e]) continue;
+                any = true;
+                const int32_t len = (int32_t)(door >> 32);
+                double alpha = 0.005;
+                { std::lock_guard<std::mutex> g(g_alpha_mu);
+                  for (auto &p : g_alpha_of_thr) if (p.first == box.prm[e].p.thr) alpha = p.second; }
+                double ee = 0; int32_t ns = 0; uint8_t pass = 0;
+                oracle_rows(box.q + (size_t)e * box.stride, 1, box.stride, &len, alpha, &ee, &ns, &pass);
+                if (len % 7 == 0) { pass = 2; ee = -12345.0; }                   // "row budget missed", as the micro-batch stub
+                box.ee[e] = ee; box.ns[e] = ns; box.pass[e] = pass;
+                __atomic_store_n(box.done + e, token, __ATOMIC_RELEASE);
+                last[e] = token;
+            }
+            if (any) continue;
+            if (__atomic_load_n(box.stop, __ATOMIC_ACQUIRE)) break;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(lifetime_ms)) break;
+            std::this_thread::yield();
+        }
+        __atomic_store_n(box.exited, generation, __ATOMIC_RELEASE);
+    }).detach();
+    return MPB_OK;
+}
+
 // ---- the HIP entry points mpb_broker.cpp calls, on host memory ----
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int) { *s = (hipStream_t)malloc(8); return hipSuccess; }

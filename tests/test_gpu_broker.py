@@ -52,12 +52,17 @@ def _worker(name, seed, count, rounds, out):
     out.put((len(bad), bad, len(reads) * rounds, dt))
 
 
-def test_eight_concurrent_processes_are_bit_exact(oracle):
+@pytest.mark.parametrize("server", ["1", "0"])
+def test_eight_concurrent_processes_are_bit_exact(oracle, monkeypatch, server):
+    """Both serving forms of the broker: the resident server (k_serve: a wave per slot polls its mailbox entry, no launch per
+    call) and the launch-per-micro-batch lanes (MPB_BROKER_SERVER=0)."""
     from moira_amd import broker
-    name = "gputest_%d" % os.getpid()
+    monkeypatch.setenv("MPB_BROKER_SERVER", server)        # read by the broker process, which inherits a worker's environment
+    name = "gputest%s_%d" % (server, os.getpid())
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(name, 500 + k, 120, 6, out)) for k in range(8)]
+    t_start = time.time()
     for p in procs:
         p.start()
     res = [out.get(timeout=300) for _ in procs]
@@ -69,7 +74,44 @@ def test_eight_concurrent_processes_are_bit_exact(oracle):
     total = sum(r[2] for r in res)
     assert st is not None and st["served"] == total and st["pid"] > 0
     assert st["solo"] >= 8 * 6 and st["batches"] <= total                   # launches; fewer than reads: they shared launches
+    if server == "1":                                                       # the resident server: a launch per lifetime (100 ms), not per call
+        assert st["batches"] <= 12 * (time.time() - t_start) + 20, (st, time.time() - t_start)
     assert broker.stats(name) is None
+
+
+def test_the_resident_server_leaves_and_comes_back(oracle):
+    """k_serve's grid always drains: its waves leave when their lifetime (100 ms) is over, whatever the host does.  While calls
+    keep coming the broker launches it again at once; after a pause the next call does.  Reads of 2047 bases go through the
+    mailbox, longer ones (and scores above 254) through the ordinary per-read path; a shutdown with the server resident
+    returns promptly."""
+    from moira_amd import broker
+    name = "gpuserve_%d" % os.getpid()
+    cl = broker.client(0, name=name, idle_exit=5.0)
+    rng = np.random.default_rng(5)
+    reads = []
+    for n in (1, 16, 300, 301, 1023, 2047, 2048, 3000):
+        reads.append(("A" * n, [int(v) for v in rng.integers(25, 41, n)], 0.005))
+    reads.append(("ACGT" * 10, [300] * 40, 0.05))
+    want = [oracle.ee_rowwise(s, q, a)[:2] for s, q, a in reads]
+    t_end = time.time() + 0.35                                  # a stream of calls across three lifetimes
+    k = 0
+    while time.time() < t_end:
+        i = k % len(reads)
+        assert cl.calculate_errors_PB(*reads[i]) == want[i], i
+        k += 1
+    st1 = broker.stats(name)
+    assert st1["served"] == k and st1["batches"] >= 3, st1   # launched again while the calls kept coming
+    time.sleep(0.4)                                             # the server has left and nobody called: it stays away ...
+    st2 = broker.stats(name)
+    assert st2["batches"] <= st1["batches"] + 1, (st1, st2)
+    for i in range(len(reads)):                                 # ... until the next call
+        assert cl.calculate_errors_PB(*reads[i]) == want[i], i
+    st3 = broker.stats(name)
+    assert st3["batches"] >= st2["batches"] + 1 and st3["solo"] >= 3 * 2, (st2, st3)
+    cl.close()
+    t0 = time.time()
+    broker.shutdown(name)
+    assert time.time() - t0 < 5.0 and broker.stats(name) is None
 
 
 def _pool_task(args):
