@@ -139,6 +139,7 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned int) { *p = malloc(n); ret
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 const char *hipGetErrorString(hipError_t) { return "stub"; }
 }
