@@ -325,6 +325,10 @@ int mpb_filter_host_multi(mpb_ctx *const *ctxs, int32_t n_ctx,
  * matrix of the batch entries cannot hold -- gets its own code table for the call ({1-p, p'} of every such score, by the
  * same expressions, under a byte code the read does not use).  MPB_E_RANGE only for a negative score, or for a read with
  * more than 254 distinct scores of which some exceed 254.
+ * A stream of such calls pays no kernel launch each (round 5): while they come, the context keeps the one-read kernel
+ * resident -- the call writes the packed read into a mailbox in pinned host memory and waits for the kernel's answer there.
+ * That kernel leaves by itself 100 ms after its launch at the latest (so a context that is no longer called holds nothing
+ * on the GPU), and before any call on this context frees memory.  Environment MPB_SERVE=0: a launch per call, as before.
  */
 int mpb_calculate_errors_PB(mpb_ctx *ctx, const char *contig,
                             const int32_t *contig_quals, int32_t len,

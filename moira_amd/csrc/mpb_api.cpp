@@ -110,7 +110,20 @@ struct mpb_ctx {
         int rows0 = 0; int calls = 0;
     } nar_choice;
     mpb_path_info last_path{};
+    // ---- the per-read entry's resident server (round 5; k_serve with ONE mailbox entry, see serve_one) ----
+    struct CtxServe {
+        bool tried = false, ok = false, running = false;
+        hipStream_t stream = nullptr;
+        char *pin = nullptr, *dev = nullptr;
+        MpbServeBox box{};
+        uint32_t generation = 0, tok = 0;
+        double cached_alpha = -1.0;
+        MpbDevParams cached_prm;
+    } serve;
 };
+
+static void serve_quiesce(mpb_ctx *c);    // the per-read entry's resident kernel leaves (before anything is freed: the runtime
+static void serve_free(mpb_ctx *c);       // waits for the whole device there)
 
 // Threads that copy a pageable input chunk into its pinned staging block: half of the CPUs this process is
 // granted (cgroup quota, else the affinity mask), at most 8 -- one memcpy stream does not saturate PCIe 5.
@@ -254,6 +267,7 @@ int mpb_destroy(mpb_ctx *c)
 {
     if (!c) return MPB_OK;
     (void)hipSetDevice(c->device);
+    serve_free(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->out_stream) (void)hipStreamSynchronize(c->out_stream);
@@ -330,6 +344,7 @@ int mpb_free(mpb_ctx *c, void *dptr)
 {
     CTXCHK(c);
     HIPCHK(hipStreamSynchronize(c->stream));
+    serve_quiesce(c);
     if (dptr) HIPCHK(hipFree(dptr));
     return MPB_OK;
 }
@@ -453,6 +468,7 @@ static int ensure_workspace(mpb_ctx *c, int64_t n)
     }
     if (n <= c->ws_cap) return MPB_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
+    serve_quiesce(c);
     if (c->ws_block) { HIPCHK(hipFree(c->ws_block)); c->ws_block = nullptr; c->ws_cap = 0; }
     const int64_t cap = n + n / 8 + 1024;
     const int64_t nb = (cap + MPB_PRE_READS - 1) / MPB_PRE_READS;
@@ -477,6 +493,7 @@ static int ensure_wide_workspace(mpb_ctx *c, int64_t n)
 {
     if (n <= c->ws_wide_cap) return MPB_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
+    serve_quiesce(c);
     if (c->ws_wide) { HIPCHK(hipFree(c->ws_wide)); c->ws_wide = nullptr; c->ws_wide_cap = 0; c->ws.wide_list = c->ws.wide_rows = nullptr; }
     const int64_t cap = n + n / 8 + 1024;
     HIPCHK(hipMalloc(&c->ws_wide, (size_t)(2 * align_up(cap * 4, 256))));
@@ -679,6 +696,7 @@ static int ensure_narrow_workspace(mpb_ctx *c, int64_t n)
 {
     if (n <= c->ws_nar_cap) return MPB_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
+    serve_quiesce(c);
     if (c->ws_nar) { HIPCHK(hipFree(c->ws_nar)); c->ws_nar = nullptr; c->ws_nar_cap = 0; }
     const int64_t cap = n + n / 8 + 1024;
     const int64_t b_list = align_up((cap + 64) * 4, 256), b_waves = align_up((int64_t)MPB_NAR_MAX_WAVES * 4, 256);
@@ -698,6 +716,7 @@ static int ensure_fallback_block(mpb_ctx *c, int64_t m, int64_t stride, Fallback
 {
     if (m > c->fb_cap || stride > c->fb_stride) {
         HIPCHK(hipStreamSynchronize(c->stream));
+        serve_quiesce(c);
         if (c->fb_block) { HIPCHK(hipFree(c->fb_block)); c->fb_block = nullptr; c->fb_cap = 0; }
         const int64_t cap = m + m / 4 + 4096;
         const int64_t st = stride > c->fb_stride ? stride : c->fb_stride;
@@ -985,6 +1004,7 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
 {
     if (bytes <= c->stage_cap) return MPB_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
+    serve_quiesce(c);
     if (c->stage_dev) { HIPCHK(hipFree(c->stage_dev)); c->stage_dev = nullptr; c->stage_cap = 0; }
     HIPCHK(hipMalloc(&c->stage_dev, (size_t)bytes));
     c->stage_cap = bytes;
@@ -1047,6 +1067,7 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
     if (rc) return rc;
     c->classified.valid = false;                           // k_small rewrites the class bytes
     if (in_bytes + out_bytes + b_done > c->pin_cap) {
+        serve_quiesce(c);
         if (c->pin_host) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->pin_host)); c->pin_host = nullptr; c->pin_cap = 0; }
         const int64_t cap = 2 * (in_bytes + out_bytes + b_done);
         HIPCHK(hipHostMalloc(&c->pin_host, (size_t)cap, hipHostMallocMapped));
@@ -1361,6 +1382,7 @@ int mpb_host_free(mpb_ctx *c, void *hptr)
 {
     CTXCHK(c);
     drain_pipeline(c);
+    serve_quiesce(c);
     if (hptr) HIPCHK(hipHostFree(hptr));
     return MPB_OK;
 }
@@ -1514,6 +1536,125 @@ int mpbi_check_one_read(const char *contig, const int32_t *contig_quals, int32_t
 
 // one packed row (and, when the read carries scores above 254, its private table h) -> (ee, Ns): the GPU half of the
 // per-read entry.  The broker calls it for the reads it cannot put into a micro-batch.
+// ---- the per-read entry without a launch per call (round 5) ----------------------------------------------------------
+// mpb_calculate_errors_PB from a process of its own (moira.py --processors 1: one call per read) paid a k_small launch per
+// call: 26 us of which the kernel is 12.  While such calls keep coming the context keeps k_serve resident with ONE mailbox
+// entry (mpb_kernels.hip; the broker's form has one per slot): the call writes row + parameters + door word into pinned
+// memory and spins on done[0].  The kernel leaves by itself 100 ms after its launch -- so 100 ms after the last call at
+// the latest -- and the next call launches it again.  Anything that frees device or pinned memory (a device-wide wait in the
+// runtime) asks it to leave first.  MPB_SERVE=0 keeps the launch per call.
+static inline int64_t mono_us()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000 + ts.tv_nsec / 1000;
+}
+
+static void serve_quiesce(mpb_ctx *c)
+{
+    auto &sv = c->serve;
+    if (!sv.ok || !sv.running) return;
+    __atomic_store_n((uint32_t *)sv.box.stop, 1u, __ATOMIC_SEQ_CST);
+    (void)hipStreamSynchronize(sv.stream);
+    __atomic_store_n((uint32_t *)sv.box.stop, 0u, __ATOMIC_SEQ_CST);
+    sv.running = false;
+}
+
+static void serve_free(mpb_ctx *c)
+{
+    auto &sv = c->serve;
+    serve_quiesce(c);
+    if (sv.stream) (void)hipStreamDestroy(sv.stream);
+    if (sv.pin) (void)hipHostFree(sv.pin);
+    if (sv.dev) (void)hipFree(sv.dev);
+    sv = mpb_ctx::CtxServe{};
+}
+
+static bool serve_init(mpb_ctx *c)
+{
+    auto &sv = c->serve;
+    if (sv.tried) return sv.ok;
+    sv.tried = true;
+    const char *e = getenv("MPB_SERVE");
+    if (e && atoi(e) == 0) return false;
+    // pinned: row | parameters | door | done | ee | ns | pass | stop | exited, a 256-byte step each
+    const size_t o_q = 0, o_prm = MPB_SERVE_STRIDE, o_door = o_prm + 256, o_done = o_door + 256, o_ee = o_done + 256,
+                 o_ns = o_ee + 256, o_pass = o_ns + 256, o_stop = o_pass + 256, o_exited = o_stop + 256, pin_bytes = o_exited + 256;
+    const size_t d_stage = 0, d_ns = MPB_SERVE_STRIDE + 256, d_cls = d_ns + 256, d_ident = d_cls + 256, d_gone = d_ident + 256,
+                 dev_bytes = d_gone + 256;
+    if (hipStreamCreateWithFlags(&sv.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&sv.pin, pin_bytes, hipHostMallocMapped) != hipSuccess ||
+        hipMalloc((void **)&sv.dev, dev_bytes) != hipSuccess || hipMemset(sv.dev, 0, dev_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (sv.stream) (void)hipStreamDestroy(sv.stream);
+        if (sv.pin) (void)hipHostFree(sv.pin);
+        if (sv.dev) (void)hipFree(sv.dev);
+        sv.stream = nullptr; sv.pin = sv.dev = nullptr;
+        return false;                                   // the launch per call remains
+    }
+    memset(sv.pin, 0, pin_bytes);
+    MpbServeBox &x = sv.box;
+    x.q = (const uint8_t *)(sv.pin + o_q); x.stride = MPB_SERVE_STRIDE; x.prm = (const MpbServePrm *)(sv.pin + o_prm);
+    x.door = (const unsigned long long *)(sv.pin + o_door); x.done = (uint32_t *)(sv.pin + o_done);
+    x.ee = (double *)(sv.pin + o_ee); x.ns = (int32_t *)(sv.pin + o_ns); x.pass = (uint8_t *)(sv.pin + o_pass);
+    x.stop = (const uint32_t *)(sv.pin + o_stop); x.exited = (uint32_t *)(sv.pin + o_exited);
+    x.stage = (uint8_t *)(sv.dev + d_stage); x.ns_dev = (int32_t *)(sv.dev + d_ns); x.cls = (uint8_t *)(sv.dev + d_cls);
+    x.ident = (int32_t *)(sv.dev + d_ident); x.gone = (uint32_t *)(sv.dev + d_gone);
+    x.n_ent = 1;
+    sv.ok = true;
+    return true;
+}
+
+static int serve_launch(mpb_ctx *c)
+{
+    auto &sv = c->serve;
+    if (++sv.generation == 0) sv.generation = 1;
+    mpb_launch_serve(sv.box, c->d_lut, sv.generation, 100, sv.stream);
+    HIPCHK(hipGetLastError());
+    sv.running = true;
+    return MPB_OK;
+}
+
+// one packed read (default table, at most MPB_SERVE_STRIDE - 1 bases) through the resident server; *served = false: not
+// taken (no server, or the read missed its row budget there): the caller goes the ordinary way
+static int serve_one(mpb_ctx *c, const uint8_t *row, int32_t len, double alpha, double *ee, int32_t *ns, bool *served)
+{
+    *served = false;
+    if (!serve_init(c)) return MPB_OK;
+    auto &sv = c->serve;
+    const MpbServeBox &x = sv.box;
+    if (sv.running && __atomic_load_n(x.exited, __ATOMIC_ACQUIRE) == sv.generation) sv.running = false;
+    memcpy((void *)x.q, row, (size_t)((len + 15) & ~15));
+    if (alpha != sv.cached_alpha) { mpbi_small_params(alpha, &sv.cached_prm); sv.cached_alpha = alpha; }
+    ((MpbServePrm *)x.prm)->p = sv.cached_prm;
+    if (++sv.tok == 0) sv.tok = 1;
+    __atomic_store_n((unsigned long long *)x.door, ((unsigned long long)(uint32_t)len << 32) | sv.tok, __ATOMIC_RELEASE);
+    int rc;
+    if (!sv.running && (rc = serve_launch(c))) return rc;
+    const int64_t t0 = mono_us();
+    for (unsigned spins = 0;; spins++) {
+        if (__atomic_load_n(x.done, __ATOMIC_ACQUIRE) == sv.tok) break;
+        __builtin_ia32_pause();
+        if ((spins & 1023u) != 1023u) continue;
+        // a wave that left just before the door word arrived: the launch that follows serves it (it starts from done[0])
+        if (__atomic_load_n(x.exited, __ATOMIC_ACQUIRE) == sv.generation) {
+            if (__atomic_load_n(x.done, __ATOMIC_ACQUIRE) == sv.tok) break;
+            if ((rc = serve_launch(c))) return rc;
+        }
+        if (mono_us() - t0 > 2000000) {                 // two seconds: ask the runtime (a fault shows there)
+            const hipError_t q = hipStreamQuery(sv.stream);
+            sv.running = false;
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(MPB_E_HIP, "the resident per-read kernel failed: %s", hipGetErrorString(q));
+            return fail(MPB_E_HIP, "the resident per-read kernel did not answer");
+        }
+    }
+    if (*x.pass == 2) return MPB_OK;                    // row budget missed / a wide read: the ordinary path
+    *ee = *x.ee;
+    *ns = *x.ns;
+    *served = true;
+    return MPB_OK;
+}
+
 int mpbi_run_packed_read(mpb_ctx *c, const uint8_t *row, int32_t len, int32_t stride, const double2 *h, double alpha,
                          double *ee, int32_t *ns)
 {
@@ -1537,6 +1678,10 @@ int mpb_calculate_errors_PB(mpb_ctx *c, const char *contig, const int32_t *conti
     bool priv = false;
     double2 h[256];
     if ((rc = mpbi_pack_one_read(contig, contig_quals, len, false, row.data(), stride, h, &priv))) return rc;
+    if (!priv && len <= MPB_SERVE_STRIDE - 1 && !c->timing) {
+        bool served = false;
+        if ((rc = serve_one(c, row.data(), len, alpha, ee, ns, &served)) || served) return rc;
+    }
     return mpbi_run_packed_read(c, row.data(), len, stride, priv ? h : nullptr, alpha, ee, ns);
 }
 
