@@ -1385,9 +1385,13 @@ def per_read_broker_rate():
     """What an UNCHANGED moira.py --processors P gets from the drop-in module (moira/moira.py:398-399,431-454: Pool workers
     calling bernoulli.calculate_errors_PB per read): P = the granted CPUs worker processes through ONE GPU-owning broker
     process (moira_amd/broker.py).  Runs tools/per_read_concurrency.py as a child process; never `value`."""
+    server = os.environ.get("MPB_BROKER_SERVER", "1") != "0"
     out = {"note": "P worker processes call bernoulli.calculate_errors_PB per read (300-base reads) through the broker: one "
-                   "GPU-owning process micro-batches what they have pending; the reference's own extension on the same cores "
-                   "is cpu_baseline.all_cores; NOT the headline"}
+                   "GPU-owning process serves them -- " + ("a resident kernel (k_serve), a wave per worker slot polling its mailbox "
+                   "entry in pinned host memory: no launch per call" if server else "micro-batches of what they have pending, a "
+                   "launch each (MPB_BROKER_SERVER=0)") + "; the reference's own extension on the same cores "
+                   "is cpu_baseline.all_cores; NOT the headline",
+           "serving": "resident kernel" if server else "launch per micro-batch"}
     try:
         from moira_amd.contig import usable_cpus
         p = max(2, min(16, usable_cpus()))
@@ -1402,6 +1406,7 @@ def per_read_broker_rate():
         b = rows[1]["broker"] or {}
         if b.get("batches"):
             out["reads_per_launch_since_the_broker_started"] = b["served"] / (b["batches"] + b["solo"])
+            out["launches_since_the_broker_started"] = b["batches"]
     except Exception as e:                                  # an extra must never cost the headline line
         out["error"] = repr(e)
     return out

@@ -24,7 +24,7 @@ t0 = time.time()
 with Engine(0) as eng:
     for it in range(rounds):
         n = int(rng.choice([1, 7, 63, 64, 65, 255, 257, 1000, 5000, 20000]))
-        stride = int(rng.choice([16, 32, 48, 64, 160, 256, 304, 320, 512, 608, 1024]))
+        stride = int(rng.choice([16, 32, 48, 64, 160, 192, 256, 304, 320, 448, 512, 608, 1024]))
         if rng.random() < 0.15:                                      # round 3: long rows (tile classes on long rows, k_wide)
             stride = int(rng.choice([1040, 1536, 2048, 3072, 4096, 8192, 16384, 16384, 32768, 65536]))   # round 4: up to 65535 bases
             n = min(n, max(1, int(3e9 / (stride * stride))))         # bounds the oracle's work (J * L cells per read, J ~ L)
