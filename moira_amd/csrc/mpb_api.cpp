@@ -1291,7 +1291,7 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
         if (e != hipSuccess) { drain_pipeline(c); return fail(MPB_E_HIP, "host pipeline (H2D): %s", hipGetErrorString(e)); }
         if (poisson) {
             Span t(c, MPB_K_LAMBDA);
-            mpb_launch_lambda(d_q, m, row_stride, len ? d_len : nullptr, fixed_len, c->ws.lut, d_ee, d_ns, c->ws.ovf_count, c->stream, 4 * (c->n_cu > 0 ? c->n_cu : 256));
+            mpb_launch_lambda(d_q, m, row_stride, len ? d_len : nullptr, fixed_len, c->ws.lut, d_ee, d_ns, c->ws.ovf_count, c->stream);
             rc = hipGetLastError() == hipSuccess ? MPB_OK : fail(MPB_E_HIP, "k_lambda launch failed");
         } else {
             rc = mpb_filter_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, params, d_ee, d_ns, d_pass, nullptr);
@@ -1757,7 +1757,7 @@ int mpb_poisson_lambda_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(c->ws.ovf_count, 0, sizeof(int32_t), c->stream));
     { Span t(c, MPB_K_LAMBDA);
-      mpb_launch_lambda(d_q, n, row_stride, d_len, fixed_len, c->ws.lut, d_lambda, d_ns, c->ws.ovf_count, c->stream, 4 * (c->n_cu > 0 ? c->n_cu : 256)); }
+      mpb_launch_lambda(d_q, n, row_stride, d_len, fixed_len, c->ws.lut, d_lambda, d_ns, c->ws.ovf_count, c->stream); }
     HIPCHK(hipGetLastError());
     int32_t bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, c->ws.ovf_count, sizeof(bad), hipMemcpyDeviceToHost, c->stream));

@@ -192,7 +192,7 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
 void mpb_launch_wide(const uint8_t *q, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                      const MpbWorkspace &ws, const int32_t *ns, double *ee, uint8_t *pass, hipStream_t s);
 void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, int32_t fixed_len,
-                       const double2 *lut_ap, double *lambda, int32_t *ns, int32_t *bad, hipStream_t s, int grid_blocks = 1024 /* k_lambda_rs' persistent grid: 4 workgroups per CU */);
+                       const double2 *lut_ap, double *lambda, int32_t *ns, int32_t *bad, hipStream_t s);
 void mpb_launch_decode(const uint8_t *seq, const uint8_t *qual, int64_t n, int64_t stride, const int32_t *len,
                        int32_t fixed_len, int32_t offset, uint8_t *out, int32_t *err, hipStream_t s);
 void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hipStream_t s);

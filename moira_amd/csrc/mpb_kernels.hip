@@ -2306,132 +2306,6 @@ __global__ __launch_bounds__(256) void k_narrow_rs(const uint8_t *__restrict__ q
     if (lane == 0) wave_count[gw] = nlist;
 }
 
-// ------------------------------------------------------------------------------------------
-// k_lambda_rs (--error_calc poisson, fixed-length batches whose row stride is a multiple of 64 bytes): k_lambda's in-order
-// sum of p per read (ref: moira/moira.py:1663) on k_narrow_rs' memory path -- a lane walks one or two rows as one stream of
-// whole 128-byte lines, panels staged in registers one ahead, the XOR-swizzled 8 KB tile -- so the matrix is read exactly
-// once and the stream is the 0.52 ms one, not k_lambda's 0.61-0.65.  Per base: one table address, one 8-byte look-up two
-// dwords ahead, one add (in base order: the reference's association), half an instruction of 'N' counting.
-// 'N' (byte 0) looks up 0.0 (x + 0.0 == x), bytes past a read's end are made zero first, 'n' (byte 255) looks up a NaN
-// that poisons the sum and is reported through *bad -- as k_lambda.
-// ------------------------------------------------------------------------------------------
-template <int ND>
-__device__ __forceinline__ void lam_run(double &lam, uint32_t &nonzero, const double *s_p, const uint32_t (&wd)[16])
-{
-    double P[ND + 2][4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) P[0][t] = s_p[(wd[0] >> (8 * t)) & 0xffu];
-#pragma unroll
-    for (int t = 0; t < 4; t++) P[1][t] = s_p[(wd[1] >> (8 * t)) & 0xffu];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int d = 0; d < ND; d++) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            lam = lam + P[d][t];                                          // in base order
-            if (d < ND - 2) P[d + 2][t] = s_p[(wd[d + 2] >> (8 * t)) & 0xffu];
-            if (t == 0) nonzero = __builtin_amdgcn_msad_u8(wd[d] ^ 0x01010101u, wd[d], nonzero);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_lambda_rs(const uint8_t *__restrict__ q, int64_t n, int64_t stride, int32_t li, int32_t k,
-                                                   const double2 *__restrict__ lut_ap, double *__restrict__ lambda,
-                                                   int32_t *__restrict__ ns, int32_t *__restrict__ bad)
-{
-    __shared__ double s_p[256];
-    __shared__ __attribute__((aligned(128))) uint8_t s_tile[4][MPB_NRS_TILE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_p[tid] = tid == 0 ? 0.0 : (tid == 255 ? __builtin_nan("") : lut_ap[tid].y);
-    __syncthreads();
-    const int64_t rows_sb = 64 * (int64_t)k;
-    const int64_t nsb = (n + rows_sb - 1) / rows_sb;
-    const int KB = __builtin_amdgcn_readfirstlane((int)(k * stride));
-    const int NP = KB >> 7;
-    const int istride = __builtin_amdgcn_readfirstlane((int)stride);
-    const int64_t gw = (int64_t)blockIdx.x * 4 + w, W = (int64_t)gridDim.x * 4;
-    if (gw >= nsb) return;
-    const int64_t total = ((nsb - gw + W - 1) / W) * NP;
-    uint8_t *const tile = s_tile[w];
-    const int r8 = lane >> 3, c8 = lane & 7;
-    const int voff = r8 * KB + c8 * 16;
-    const int wr_even = r8 * 128 + ((c8 ^ (r8 >> 1)) << 4), wr_odd = r8 * 128 + ((c8 ^ (4 + (r8 >> 1))) << 4);
-    const int x0 = lane * 128 + (((lane >> 1) & 7) << 4);
-    u32x4 pre[8];
-    auto load_panel = [&](const int64_t sb, const int pk) {
-        const uint64_t base = (uint64_t)(uintptr_t)q + (uint64_t)(sb * rows_sb) * (uint64_t)stride;
-        const int64_t rows_here = (n - sb * rows_sb) < rows_sb ? (n - sb * rows_sb) : rows_sb;
-        const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-        const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
-        const uint32_t b_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rows_here * stride));
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(uintptr_t)(((uint64_t)b_hi << 32) | b_lo), 0, (int)b_n, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 8; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, j * 8 * KB + pk * 128, 0);
-    };
-    int64_t pf_sb = gw, cur_sb = gw;
-    int pf_pk = 0, cur_pk = 0;
-    load_panel(pf_sb, pf_pk);
-    if (++pf_pk == NP) { pf_pk = 0; pf_sb += W; }
-    double lam = 0.0;
-    uint32_t nonzero = 0;
-    int u = 0, sread = 0;
-    for (int64_t t = 0; t < total; t++) {
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            *reinterpret_cast<u32x4 *>(tile + j * 1024 + ((j & 1) ? wr_odd : wr_even)) = pre[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (t + 1 < total) {
-            load_panel(pf_sb, pf_pk);
-            if (++pf_pk == NP) { pf_pk = 0; pf_sb += W; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int nb = li - u;
-            if (nb > 0) {
-                const int nch = nb >= 64 ? 4 : (nb + 15) >> 4;
-                uint32_t wd[16];
-#define LRS_LOAD(NC)                                                                                         \
-                _Pragma("unroll") for (int c = 0; c < NC; c++) {                                             \
-                    const u32x4 x = *reinterpret_cast<const u32x4 *>(tile + (x0 ^ ((h * 4 + c) << 4)));      \
-                    wd[4 * c] = x.x; wd[4 * c + 1] = x.y; wd[4 * c + 2] = x.z; wd[4 * c + 3] = x.w;           \
-                }                                                                                            \
-                if (nb < 16 * NC) {                                                                          \
-                    _Pragma("unroll") for (int d = 0; d < 4; d++)                                            \
-                        wd[4 * (NC - 1) + d] = mask_dword(wd[4 * (NC - 1) + d], nb - 16 * (NC - 1) - 4 * d); \
-                }
-                switch (nch) {
-                case 4: { LRS_LOAD(4) lam_run<16>(lam, nonzero, s_p, wd); break; }
-                case 3: { LRS_LOAD(3) lam_run<12>(lam, nonzero, s_p, wd); break; }
-                case 2: { LRS_LOAD(2) lam_run<8>(lam, nonzero, s_p, wd); break; }
-                default: { LRS_LOAD(1) lam_run<4>(lam, nonzero, s_p, wd); break; }
-                }
-#undef LRS_LOAD
-                if (nb <= 64) {                                   // the read is done
-                    const int64_t i = cur_sb * rows_sb + (int64_t)lane * k + sread;
-                    if (i < n) {
-                        lambda[i] = lam;
-                        ns[i] = li - (int)nonzero;                 // zero bytes among its li (the masked ones past its end are none of them)
-                        if (lam != lam) atomicAdd(bad, 1);         // only a byte 255 can do that
-                    }
-                    lam = 0.0;
-                    nonzero = 0;
-                }
-            }
-            u += 64;
-            if (u == istride) { u = 0; sread++; }
-        }
-        if (++cur_pk == NP) { cur_pk = 0; cur_sb += W; sread = 0; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
 // exclusive prefix of the waves' list counts (one block); total -> *count
 __global__ __launch_bounds__(1024) void k_nar_offsets(const int32_t *__restrict__ wave_count, int nwaves,
                                                       int32_t *__restrict__ wave_off, int32_t *__restrict__ count)
@@ -2734,17 +2608,8 @@ void mpb_launch_overflow(const uint8_t *q, int64_t n, int64_t stride, const int3
 }
 
 void mpb_launch_lambda(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, int32_t fixed_len,
-                       const double2 *lut_ap, double *lambda, int32_t *ns, int32_t *bad, hipStream_t s, int grid_blocks)
+                       const double2 *lut_ap, double *lambda, int32_t *ns, int32_t *bad, hipStream_t s)
 {
-    const int rs_k = (!len && fixed_len >= 1) ? mpb_narrow_rs_reads_per_lane(stride) : 0;
-    if (rs_k) {                                          // fixed length, rows of a multiple of 64 bytes: whole lines, read once
-        const int64_t nsb = (n + 64 * rs_k - 1) / (64 * rs_k);
-        int64_t pb = (nsb + 3) / 4;
-        if (pb > grid_blocks) pb = grid_blocks;          // persistent: a wave walks stream blocks gw, gw + W, ...
-        if (pb < 1) pb = 1;
-        hipLaunchKernelGGL(k_lambda_rs, dim3((unsigned)pb), dim3(256), 0, s, q, n, stride, fixed_len, rs_k, lut_ap, lambda, ns, bad);
-        return;
-    }
     int64_t blocks = (n + 255) / 256;
     if (blocks > (1 << 20)) blocks = 1 << 20;            // the tile loop is grid-strided
     if (len)
