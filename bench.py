@@ -827,6 +827,7 @@ def main():
             except Exception as e:                      # an extra must never cost the headline line
                 extras["config3_paired"] = {"error": repr(e)}
             extras["per_read_broker"] = per_read_broker_rate()
+            extras["per_read_in_process"] = per_read_in_process_rate(eng)
             if n != CONFIG4_SHARD:
                 extras["config4_shard"] = config4_shard_rate(eng, L, stride, args.seed, params)
         extras["poisson_error_calc"] = poisson_rate(eng, d_q, n, stride, L, d_ee, d_ns)
@@ -1376,6 +1377,30 @@ def poisson_rate(eng, d_q, n, stride, L, d_lam, d_ns):
         ML.check(eng.lib.mpb_poisson_finish_host(lam.ctypes.data, ns.ctypes.data, None, L, m, C.byref(prm), ee.ctypes.data, ps.ctypes.data))
         dt = time.perf_counter() - t
         out["host_tail"] = {"reads_per_s": m / dt, "reads": m, "pass": int(ps.sum())}
+    except Exception as e:                                  # an extra must never cost the headline line
+        out["error"] = repr(e)
+    return out
+
+
+def per_read_in_process_rate(eng, calls=4000):
+    """bernoulli.calculate_errors_PB(contig, contig_quals, alpha) called read by read from THIS process (what moira.py
+    --processors 1 does, moira/moira.py:817): since round 5 the context keeps the one-read kernel resident while such calls come
+    (k_serve, one mailbox entry in pinned host memory: no launch per call; MPB_SERVE=0 switches it off).  Never `value`."""
+    import numpy as np
+    out = {"note": "calculate_errors_PB per read from one Python process on the bench's own context (300-base reads); "
+                   + ("resident one-read kernel, no launch per call" if os.environ.get("MPB_SERVE", "1") != "0" else "a k_small launch per call (MPB_SERVE=0)")
+                   + "; the reference extension per read from Python is cpu_baseline (1 core); NOT the headline"}
+    try:
+        rng = np.random.default_rng(1)
+        seq = "".join(rng.choice(list("ACGT"), 300))
+        quals = [int(x) for x in np.clip(38 - (np.arange(300) / 300) ** 3 * 20 - rng.integers(0, 6, 300), 2, 40)]
+        for _ in range(50):
+            eng.calculate_errors_PB(seq, quals, 0.005)
+        t = time.perf_counter()
+        for _ in range(calls):
+            eng.calculate_errors_PB(seq, quals, 0.005)
+        dt = time.perf_counter() - t
+        out.update({"calls": calls, "us_per_call": dt / calls * 1e6, "calls_per_s": calls / dt})
     except Exception as e:                                  # an extra must never cost the headline line
         out["error"] = repr(e)
     return out
