@@ -1705,9 +1705,6 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t 
 #ifndef MPB_NAR_DEPTH
 #define MPB_NAR_DEPTH 2                     // ring slots per wave: 2 x 4 KiB -> four workgroups (16 waves) per CU; a slot is refilled as
 #endif                                      // soon as its panel is in registers, so two panels per wave are in flight during a step
-#ifndef MPB_NAR_DEPTH_TAIL
-#define MPB_NAR_DEPTH_TAIL 2                // with the 2 x 2 KiB tail buffers: 2 x 4 + 4 = 12 KiB per wave again
-#endif
 #define MPB_NAR_PANEL 4096                  // 64 rows x 64 bytes
 
 // One LDS-DMA instruction: 16 bytes per lane from `base + voff` (wave-uniform 64-bit base, per-lane 32-bit offset) to LDS at
@@ -1770,15 +1767,10 @@ __device__ unsigned long long g_nar_stamps[4];
 #define NAR_T1(k)
 #endif
 
-// TAIL (rows of stride = 64 mod 128 bytes that are read to their last panel -- the 300-base / 320-byte layout): every other row
-// starts in the middle of a 128-byte line, which it shares with the row before: that row's last 64 bytes are needed at the END
-// of the block, the next row's first 64 at its beginning, four steps apart -- with thousands of waves streaming, the line has
-// left the L2 by then and is fetched twice (a fifth of all lines: 1.26 x the matrix, profiles/r05_narrow_variants.txt).
-// So the last panel is requested for the odd rows only, and the even rows' last 64 bytes travel with the line they share:
-// they are requested TOGETHER with the next block's first panel (whose odd rows bring the other half of those lines) into a
-// small buffer of their own (2 KB per wave, two of them: the next block's is in flight while this block's is still to be read),
-// from which the even rows take their last panel.  Every request stays four DMA instructions.
-template <int R, bool TAIL, int D>
+// (Rows whose stride is a multiple of 64 bytes take k_narrow_rs below since the second session of round 5; a form of this
+// kernel that fetched the line a row pair shares only once -- tail buffers beside the ring, -DMPB_NAR_TAILS -- is in the
+// history: 4.03 -> 3.49 GB read, 6 % slower.)
+template <int R, int D>
 __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, int64_t n, int64_t stride, int32_t li,
                                                 MpbDevParams prm, const double2 *__restrict__ lut_g,
                                                 double *__restrict__ ee, int32_t *__restrict__ ns, uint8_t *__restrict__ pass,
@@ -1796,8 +1788,6 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     __shared__ __attribute__((aligned(16))) uint8_t s_ring1[4][MPB_NAR_PANEL];
     __shared__ __attribute__((aligned(16))) uint8_t s_ring2[D > 2 ? 4 : 1][D > 2 ? MPB_NAR_PANEL : 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_ring3[D > 3 ? 4 : 1][D > 3 ? MPB_NAR_PANEL : 16];
-    __shared__ __attribute__((aligned(16))) uint8_t s_tail0[TAIL ? 4 : 1][TAIL ? 2048 : 16];     // even rows' last 64 bytes, blocks 0, 2, ..
-    __shared__ __attribute__((aligned(16))) uint8_t s_tail1[TAIL ? 4 : 1][TAIL ? 2048 : 16];     // ... blocks 1, 3, .. of this wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // byte 0 ('N'): the identity step {1, 0} the table holds anyway (counted below); byte 255 ('n'): a NaN -- the read is handed back
@@ -1826,49 +1816,10 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     const uint32_t ring_lds[4] = {lds_offset(s_ring0[w]), lds_offset(s_ring1[w]), lds_offset(s_ring2[D > 2 ? w : 0]),
                                   lds_offset(s_ring3[D > 3 ? w : 0])};
 
-    // TAIL: the odd rows of a block (lane (r16, cl): row 2 (rg 16 + r16) + 1, rg = 0, 1) and, 64 bytes before each, the even rows' tails
-    uint32_t voff_odd[2] = {0, 0};
-    if (TAIL) {
-#pragma unroll
-        for (int rg = 0; rg < 2; rg++) voff_odd[rg] = (uint32_t)((2 * (rg * 16 + r16) + 1) * (int)stride + cl * 16);
-    }
-    uint8_t *const tailbuf[2] = {s_tail0[TAIL ? w : 0], s_tail1[TAIL ? w : 0]};
-    const uint32_t tail_lds[2] = {lds_offset(s_tail0[TAIL ? w : 0]), lds_offset(s_tail1[TAIL ? w : 0])};
-    // the even rows' last 64 bytes of row block b -> dst (two DMA instructions)
-    auto issue_tails = [&](const int64_t b, const uint32_t dst) {
-        const uint8_t *base = q + b * 64 * stride;
-        if (b * 64 + 64 <= n) {
-#pragma unroll
-            for (int rg = 0; rg < 2; rg++) nar_dma16(base, voff_odd[rg] - 64u, dst + rg * 1024);
-        } else {
-            const int last_even = (int)(n - 1 - b * 64) & ~1;                      // the block's last even row exists
-#pragma unroll
-            for (int rg = 0; rg < 2; rg++)
-                nar_dma16(base, (uint32_t)((min(2 * (rg * 16 + r16), last_even) + 1) * (int)stride - 64 + cl * 16), dst + rg * 1024);
-        }
-    };
-
     // one panel = four DMA instructions, always four (the waits below count them)
-    auto issue = [&](const int64_t b, const int c, const uint32_t slot, const int ord) {
-        (void)ord;
+    auto issue = [&](const int64_t b, const int c, const uint32_t slot) {
         const uint8_t *base = q + b * 64 * stride + c * 64;                        // wave-uniform
         const bool edge = (b * 64 + 64 > n) || (c * 4 + 4 > row_chunks);          // wave-uniform
-        if (TAIL && c == ncq - 1) {
-            // the block's last panel: odd rows only (two instructions) ...
-            if (!edge) {
-#pragma unroll
-                for (int rg = 0; rg < 2; rg++) nar_dma16(base, voff_odd[rg], slot + rg * 1024);
-            } else {
-                const int last_row = (int)(n - 1 - b * 64);
-#pragma unroll
-                for (int rg = 0; rg < 2; rg++)
-                    nar_dma16(base, (uint32_t)(min(2 * (rg * 16 + r16) + 1, last_row) * (int)stride + cl * 16), slot + rg * 1024);
-            }
-            // ... and the even rows' tails of the NEXT block of this wave, next to that block's first panel (the request after this one)
-            if (b + W < nblk) issue_tails(b + W, tail_lds[(ord + 1) & 1]);
-            else issue_tails(b, slot + 2048);                                      // nothing follows: two more into the unused half (the count stays four)
-            return;
-        }
         if (!edge) {
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) nar_dma16(base, voff[rg], slot + rg * 1024);
@@ -1888,19 +1839,17 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
 #endif
     int64_t pf_b = gw, cur_b = gw;            // row block of the next panel to request / being computed
     int pf_c = 0, cur_c = 0;
-    int pf_ord = 0, cur_ord = 0;              // ... and which of this wave's blocks that is (TAIL: picks the tail buffer)
     int64_t pf = 0;                           // panels requested so far
     auto request = [&](const uint32_t slot) {
         if (pf < total) {
 #ifdef MPB_NAR_NODMA                           // timing experiment: the arithmetic alone (stale panels after the first)
             if (pf < D - 1)
 #endif
-            issue(pf_b, pf_c, slot, pf_ord);
+            issue(pf_b, pf_c, slot);
             pf++;
-            if (++pf_c == ncq) { pf_c = 0; pf_b += W; pf_ord++; }
+            if (++pf_c == ncq) { pf_c = 0; pf_b += W; }
         }
     };
-    if (TAIL) issue_tails(gw, tail_lds[0]);    // the first block's (older than every panel request: landed before any counted wait ends)
 #pragma unroll
     for (int k = 0; k < D - 1; k++) request(ring_lds[k]);
 #ifndef MPB_NAR_LATE_FREE
@@ -1941,11 +1890,6 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
         const long long t_c = __builtin_readcyclecounter();
 #endif
         const uint8_t *mine = ring[S] + tl;
-        if (TAIL && cur_c == ncq - 1) {
-            // the last panel: odd rows from the ring slot (32 rows: [2 row groups][4 chunk columns][16 rows]), even rows from the tails
-            const uint32_t off = (uint32_t)(((lane >> 1) >> 4) * 1024 + ((lane >> 1) & 15) * 16);
-            mine = ((lane & 1) ? ring[S] : tailbuf[cur_ord & 1]) + off;
-        }
 #ifdef MPB_NAR_NOARITH                         // timing experiment: the panel stream alone
         const int nbases = 0;
 #else
@@ -2067,7 +2011,6 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
             nonzero = 0;
             cur_c = 0;
             cur_b += W;
-            cur_ord++;
         }
 #ifdef MPB_NAR_STAMPS
         st[3] += __builtin_readcyclecounter() - t_e;
@@ -2680,26 +2623,9 @@ void mpb_launch_serve(const MpbServeBox &box, const double2 *lut, uint32_t gener
 }
 
 // ---- natural-order narrow pass ----------------------------------------------------------------------------------------
-// TAIL (see k_narrow): rows that start mid-line every other row (stride = 64 mod 128) and are read to their last 64-byte panel.
-// Measured (profiles/r05_narrow_variants.txt): memory-side reads 4.03 -> 3.49 GB (3.21 GB with a three-slot ring at two
-// workgroups per CU) -- and the kernel 6 % (19 %) SLOWER: the stream is not bound by that traffic (the second touches are served
-// on-die) but by the bytes a CU can have in flight, which LDS capacity fixes, and the tail buffers take LDS from the ring.
-// Bit-exact (the whole narrow test suite ran through it), built only with -DMPB_NAR_TAILS.
-bool mpb_narrow_uses_tails(int64_t stride, int32_t fixed_len)
+int mpb_narrow_lds_bytes()
 {
-#ifdef MPB_NAR_TAILS
-    if (getenv("MPB_NAR_NO_TAIL")) return false;
-    const int64_t ncq = (fixed_len + 63) / 64;
-    return stride % 128 == 64 && stride >= 128 && ncq >= 2 && ncq * 64 == stride;
-#else
-    (void)stride; (void)fixed_len;
-    return false;
-#endif
-}
-
-int mpb_narrow_lds_bytes(bool tail)
-{
-    return 256 * (int)sizeof(nar_entry_t) + (tail ? MPB_NAR_DEPTH_TAIL : MPB_NAR_DEPTH) * 4 * MPB_NAR_PANEL + (tail ? 2 * 4 * 2048 : 32);
+    return 256 * (int)sizeof(nar_entry_t) + MPB_NAR_DEPTH * 4 * MPB_NAR_PANEL + 32;
 }
 
 // k_narrow_rs (register-staged, whole lines): rows whose stride is a multiple of 64 bytes; reads per lane (0: not this form)
@@ -2729,15 +2655,7 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
     if (blocks > MPB_NAR_MAX_WAVES / 4) blocks = MPB_NAR_MAX_WAVES / 4;
     if (blocks < 1) blocks = 1;
     const int nwaves = (int)blocks * 4;
-    const bool tail = mpb_narrow_uses_tails(stride, fixed_len);
-#ifdef MPB_NAR_TAILS
-#define MPB_NAR_LAUNCH_TAIL(RR) hipLaunchKernelGGL((k_narrow<RR, true, MPB_NAR_DEPTH_TAIL>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
-#else
-#define MPB_NAR_LAUNCH_TAIL(RR) ((void)0)
-#endif
-#define MPB_NAR_LAUNCH(RR) \
-    do { if (tail) MPB_NAR_LAUNCH_TAIL(RR); \
-         else hipLaunchKernelGGL((k_narrow<RR, false, MPB_NAR_DEPTH>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count); } while (0)
+#define MPB_NAR_LAUNCH(RR) hipLaunchKernelGGL((k_narrow<RR, MPB_NAR_DEPTH>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
 #define MPB_NRS_LAUNCH(RR) hipLaunchKernelGGL((k_narrow_rs<RR>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, rs_k, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
     if (rs_k) {
         switch (rows0) {

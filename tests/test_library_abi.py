@@ -115,6 +115,19 @@ def test_no_fma_in_exact_dp_kernel():
         sc = [l for l in b.splitlines() if "scratch_" in l]
         assert all("Folded Spill" in l or "Folded Reload" in l for l in sc)
     assert all(b.count("v_fma_f64") + b.count("v_fmac_f64") > 5 for b in fast)
+    # the natural-order narrow pass (k_narrow: LDS-DMA ring; k_narrow_rs: whole lines staged in registers), 2..4 rows, and
+    # the resident one-read server: fused operations only inside their epilogues' IEEE divisions
+    narrow = [b for b in bodies if re.match(r"_ZN\S*(k_narrowILi\d|k_narrow_rsILi\d)", b)]
+    assert len(narrow) == 6, [b.split(":")[0] for b in narrow]
+    for b in narrow:
+        ndiv = b.count("v_div_fixup_f64")
+        assert ndiv >= 1 and b.count("v_fma_f64") == 3 * ndiv and b.count("v_fmac_f64") == 2 * ndiv, b.split(":")[0]
+        assert "scratch_" not in b, b.split(":")[0]                         # no spills
+    # k_dp / k_small / k_serve call the class bodies: all three keep the 128-register budget (4 waves per SIMD) -- a caller
+    # declared with looser launch bounds would let the shared bodies grow and halve k_dp's occupancy
+    for name in ("k_dpILb0ELb0E", "k_smallILb0E", "k_serve"):
+        m = re.search(r"\.amdhsa_kernel _ZN\S*%s\S*\n(?:.*\n)*?\s*\.amdhsa_next_free_vgpr (\d+)" % name, text)
+        assert m and int(m.group(1)) <= 128, (name, m and m.group(1))
 
 
 def test_pack_batch_ascii_matches_per_read_packer(oracle):
