@@ -361,8 +361,10 @@ int mpb_filter_host_coded(mpb_ctx *ctx, const uint8_t *q, int64_t n, int64_t row
  * mpb_calculate_errors_PB) into the caller's slot of a shared-memory segment and waits, the broker gathers whatever is
  * pending into one launch of the one-read-per-wave kernel (several such micro-batches in flight) and hands the results
  * back through the slots -- or (the default since round 5) keeps ONE kernel resident while calls arrive, a wave per slot that
- * polls the slot's mailbox entry in pinned host memory: no launch per call; that kernel leaves by itself after 100 ms and
- * is launched again while calls keep coming (environment MPB_BROKER_SERVER=0: the launches).
+ * polls the slot itself (the segment is registered with the runtime: the worker's row, parameters and door word are read
+ * where they are written, the answer lands in the slot; MPB_BROKER_DIRECT=0: a mailbox of the broker's own copies): no
+ * launch per call, and no pass through the broker thread; that kernel leaves by itself after 100 ms and is launched again
+ * while calls keep coming (environment MPB_BROKER_SERVER=0: the launches).
  * Results are those of mpb_calculate_errors_PB bit for bit, scores above 254 included.
  *
  *   mpb_broker_serve   runs the broker loop on `ctx` in the calling thread until mpb_broker_shutdown(name), or until no

@@ -1599,6 +1599,7 @@ static bool serve_init(mpb_ctx *c)
     x.stop = (const uint32_t *)(sv.pin + o_stop); x.exited = (uint32_t *)(sv.pin + o_exited);
     x.stage = (uint8_t *)(sv.dev + d_stage); x.ns_dev = (int32_t *)(sv.dev + d_ns); x.cls = (uint8_t *)(sv.dev + d_cls);
     x.ident = (int32_t *)(sv.dev + d_ident); x.gone = (uint32_t *)(sv.dev + d_gone);
+    x.q_step = MPB_SERVE_STRIDE; x.prm_step = sizeof(MpbServePrm); x.door_step = 8; x.done_step = 4; x.ee_step = 8; x.ns_step = 4; x.pass_step = 1;
     x.n_ent = 1;
     sv.ok = true;
     return true;

@@ -47,7 +47,7 @@
 namespace {
 
 constexpr uint32_t BRK_MAGIC = 0x4d504252u;        // "MPBR"
-constexpr uint32_t BRK_VERSION = 2;
+constexpr uint32_t BRK_VERSION = 3;
 constexpr int BRK_LANES = 4;                        // micro-batches in flight
 constexpr int BRK_MAX_SLOTS = 256;
 
@@ -66,6 +66,13 @@ struct alignas(64) BrkHeader {
     alignas(64) std::atomic<int64_t> served;
     std::atomic<int64_t> batches, solo;
     std::atomic<int64_t> heartbeat_ms;
+    // direct serving (round 5): the resident kernel reads the requests and writes the results IN the slots (the segment is
+    // registered with the runtime): a call does not pass through the broker thread at all.  `direct`: the clients may post
+    // door words; `server_up`: a launch of the kernel is out (a client that finds it down kicks the broker);
+    // `direct_seq`: bumped by every direct call (how the broker knows that calls keep coming).
+    alignas(64) std::atomic<int32_t> direct;
+    std::atomic<int32_t> server_up;
+    alignas(64) std::atomic<uint32_t> direct_seq;
 };
 
 // One cache line per direction: the client spins on the first (state), the request and the result each have a line of their
@@ -81,6 +88,15 @@ struct alignas(64) BrkSlot {
     int32_t ns;
     double ee;
     char err[160];
+    // direct serving: the client's line (door word, its count of direct calls), the kernel's line (token served, results),
+    // the request's parameters
+    alignas(64) unsigned long long door;            // {length << 32 | token}, written by the client after row + parameters
+    int64_t n_direct;                               // direct calls of this slot's owners (summed by mpb_broker_stats)
+    alignas(64) uint32_t d_done;                    // written by the kernel: the token served ...
+    int32_t d_ns;
+    double d_ee;
+    uint8_t d_pass;                                 // ... 2: row budget missed (or a wide read): the client submits it to the broker
+    alignas(64) MpbServePrm d_prm;
     // then: uint8_t row[MPB_MAX_STRIDE]; double2 lut[256] (only read when priv != 0)
 };
 
@@ -95,6 +111,11 @@ inline long futex(void *addr, int op, uint32_t val, const timespec *ts)
 inline void futex_wait(void *addr, uint32_t val, int ms)
 {
     timespec ts{ms / 1000, (long)(ms % 1000) * 1000000L};
+    futex(addr, FUTEX_WAIT, val, &ts);
+}
+inline void futex_wait_us(void *addr, uint32_t val, int64_t us)
+{
+    timespec ts{(time_t)(us / 1000000), (long)(us % 1000000) * 1000L};
     futex(addr, FUTEX_WAIT, val, &ts);
 }
 inline void futex_wake(void *addr, int n) { futex(addr, FUTEX_WAKE, (uint32_t)n, nullptr); }
@@ -228,6 +249,8 @@ struct Broker {
         double cached_alpha = -1.0;
         MpbDevParams cached_prm;
         uint32_t lifetime_ms = 100;
+        bool direct = false;                                // the kernel serves the slots themselves (the segment is registered)
+        uint32_t seen_direct_seq = 0;
         int64_t turn_us = 0, turn_n = 0;                    // MPB_BROKER_TRACE: door word -> results seen, summed
     } srv;
 
@@ -264,8 +287,26 @@ struct Broker {
         x.stop = (const uint32_t *)srv.h_stop; x.exited = (uint32_t *)srv.h_exited;
         x.stage = (uint8_t *)(srv.dev + d_stage); x.ns_dev = (int32_t *)(srv.dev + d_ns); x.cls = (uint8_t *)(srv.dev + d_cls);
         x.ident = (int32_t *)(srv.dev + d_ident); x.gone = (uint32_t *)(srv.dev + d_gone);
+        x.q_step = MPB_SERVE_STRIDE; x.prm_step = sizeof(MpbServePrm); x.door_step = 8; x.done_step = 4; x.ee_step = 8; x.ns_step = 4; x.pass_step = 1;
         x.n_ent = n_slots;
         for (int i = 0; i < BRK_MAX_SLOTS; i++) { srv.tok[i] = 0; srv.posted[i] = false; srv.posted_us[i] = 0; }
+        // Direct serving: the shared-memory segment itself registered with the runtime, the kernel's entry e = slot e.  Then a
+        // call is: the worker writes row + parameters + door word into its slot, the wave answers there -- this thread only
+        // keeps the kernel resident.  (Registration refused, or MPB_BROKER_DIRECT=0: the copies above stay.)
+        const bool want_direct = !(getenv("MPB_BROKER_DIRECT") && atoi(getenv("MPB_BROKER_DIRECT")) == 0);
+        if (want_direct && hipHostRegister(map.base, map.bytes, hipHostRegisterMapped) == hipSuccess) {
+            void *dbase = nullptr;
+            if (hipHostGetDevicePointer(&dbase, map.base, 0) == hipSuccess && dbase) {
+                BrkSlot *s0 = (BrkSlot *)((char *)dbase + sizeof(BrkHeader));
+                x.q = (const uint8_t *)s0 + SLOT_ROW_OFF; x.prm = &s0->d_prm; x.door = &s0->door; x.done = &s0->d_done;
+                x.ee = &s0->d_ee; x.ns = &s0->d_ns; x.pass = &s0->d_pass;
+                x.q_step = x.prm_step = x.door_step = x.done_step = x.ee_step = x.ns_step = x.pass_step = (int64_t)SLOT_BYTES;
+                srv.direct = true;
+            } else {
+                (void)hipHostUnregister(map.base);
+            }
+        }
+        (void)hipGetLastError();
         srv.enabled = true;
         return MPB_OK;
     }
@@ -280,6 +321,7 @@ struct Broker {
         srv.running = true;
         srv.launched_us = now_us();
         map.hdr()->batches.fetch_add(1, std::memory_order_relaxed);
+        map.hdr()->server_up.store(1, std::memory_order_release);
         return MPB_OK;
     }
 
@@ -323,8 +365,12 @@ struct Broker {
     // A request that has been out for 50 ms: ask the runtime (a fault shows there).
     int server_watch()
     {
-        if (srv.running && exited_generation() == srv.generation) srv.running = false;
+        if (srv.running && exited_generation() == srv.generation) { srv.running = false; map.hdr()->server_up.store(0, std::memory_order_release); }
         const int64_t t = now_us();
+        if (srv.direct) {                                   // calls that do not pass through this thread: their counter says they keep coming
+            const uint32_t ds = map.hdr()->direct_seq.load(std::memory_order_acquire);
+            if (ds != srv.seen_direct_seq) { srv.seen_direct_seq = ds; srv.last_post_us = t; }
+        }
         if (!srv.running && (srv.n_posted > 0 || t - srv.last_post_us < 20000)) return server_launch();
         if (srv.running && srv.n_posted > 0) {
             int64_t oldest = t;
@@ -361,6 +407,9 @@ struct Broker {
             const int64_t until = now_ms() + 2000;
             while (exited_generation() != srv.generation && now_ms() < until) usleep(100);
         }
+        map.hdr()->direct.store(0);
+        map.hdr()->server_up.store(0);
+        if (srv.direct) (void)hipHostUnregister(map.base);
         (void)hipStreamDestroy(srv.stream);
         if (srv.pin) (void)hipHostFree(srv.pin);
         if (srv.dev) (void)hipFree(srv.dev);
@@ -639,6 +688,7 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
     if (rc == MPB_OK && want_server) rc = b.init_server();
     if (rc == MPB_OK) {
         std::atomic_thread_fence(std::memory_order_seq_cst);
+        h->direct.store(b.srv.enabled && b.srv.direct ? 1 : 0);
         h->magic = BRK_MAGIC;                        // clients accept the segment from here on
         h->state.store(BS_SERVING);
     }
@@ -701,7 +751,9 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
                 if (s->state.load(std::memory_order_acquire) != ST_SUBMITTED) continue;
                 progress = true;
                 if (!b.take(i)) continue;                      // malformed: answered with MPB_E_INVALID
-                if (b.s_priv[i] || b.s_len[i] > MPB_SERVE_STRIDE - 1) { b.run_solo(i); continue; }   // its own table / a long row
+                // its own table / a long row -- and, when the kernel serves the slots themselves, whatever a client still submits
+                // here (what the kernel handed back: a missed row budget)
+                if (b.srv.direct || b.s_priv[i] || b.s_len[i] > MPB_SERVE_STRIDE - 1) { b.run_solo(i); continue; }
                 const int prc = b.server_post(i);
                 if (prc) { b.finish(i, prc, 0, 0, mpb_last_error()); b.srv.posted[i] = false; b.srv.n_posted--; if (prc == MPB_E_HIP) rc = prc; }
             }
@@ -775,9 +827,12 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
             if (attached) last_work = t;             // attached clients keep the broker alive even when they are quiet
             if (idle_exit_ms > 0 && t - last_work > idle_exit_ms) break;
         }
-        // spin for a little while (a worker is usually back within tens of microseconds), then sleep on the submit word
+        // spin for a little while (a worker is usually back within tens of microseconds), then sleep on the submit word.
+        // Direct serving: the calls do not come through here, this thread only has to notice that the kernel has left while
+        // they keep coming -- a look every 200 us, hardly any spinning (a spinning thread is one CPU less for the workers).
+        const bool watching = b.srv.enabled && b.srv.direct && (b.srv.running || now_us() - b.srv.last_post_us < 20000);
         const uint32_t seq = h->submit_seq.load(std::memory_order_acquire);
-        const int64_t spin_until = now_us() + 100;
+        const int64_t spin_until = now_us() + (b.srv.enabled && b.srv.direct ? 2 : 100);
         bool woke = false;
         while (now_us() < spin_until) {
             if (h->submit_seq.load(std::memory_order_acquire) != seq) { woke = true; break; }
@@ -787,7 +842,7 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
         h->sleeping.store(1, std::memory_order_seq_cst);
         bool pending = false;
         for (int i = 0; i < n_slots && !pending; i++) pending = b.map.slot(i)->state.load(std::memory_order_seq_cst) == ST_SUBMITTED;
-        if (!pending && !h->stop.load()) futex_wait(&h->submit_seq, seq, 20);
+        if (!pending && !h->stop.load()) { if (watching) futex_wait_us(&h->submit_seq, seq, 200); else futex_wait(&h->submit_seq, seq, 20); }
         h->sleeping.store(0, std::memory_order_seq_cst);
     }
     // leave: nobody may wait for an answer that will not come
@@ -821,6 +876,9 @@ struct mpb_broker_client {
     Mapping map;
     int slot = -1;
     int32_t pid = 0;
+    uint32_t tok = 0;                 // direct serving: the last door token of this attachment
+    double prm_alpha = -1.0;          // ... and the parameters of the last alpha
+    MpbDevParams prm;
 };
 
 int mpb_broker_attach(const char *name, int32_t wait_ms, mpb_broker_client **out)
@@ -857,7 +915,53 @@ int mpb_broker_attach(const char *name, int32_t wait_ms, mpb_broker_client **out
     cl->map = m;
     cl->slot = got;
     cl->pid = me;
+    // direct serving: start behind whatever a former owner of the slot left (a door word still unserved, the token served last)
+    const uint32_t t_door = (uint32_t)__atomic_load_n(&s->door, __ATOMIC_ACQUIRE), t_done = __atomic_load_n(&s->d_done, __ATOMIC_ACQUIRE);
+    cl->tok = (int32_t)(t_door - t_done) > 0 ? t_door : t_done;
     *out = cl;
+    return MPB_OK;
+}
+
+// Direct serving: the request goes to the resident kernel where it lies (the worker's slot); nothing of it passes through the
+// broker thread.  *served = false: the kernel handed the read back (row budget missed / a wide read) -- the caller submits it.
+static int direct_call(mpb_broker_client *cl, BrkHeader *h, BrkSlot *s, int32_t len, double alpha, double *ee, int32_t *ns, bool *served)
+{
+    *served = false;
+    if (alpha != cl->prm_alpha) { mpbi_small_params(alpha, &cl->prm); cl->prm_alpha = alpha; }
+    s->d_prm.p = cl->prm;
+    uint32_t t = cl->tok + 1;
+    if (t == 0) t = 1;
+    cl->tok = t;
+    __atomic_store_n(&s->door, ((unsigned long long)(uint32_t)len << 32) | t, __ATOMIC_RELEASE);
+    h->direct_seq.fetch_add(1, std::memory_order_relaxed);
+    auto kick = [&] {                                   // the kernel is not out: the broker launches it when it looks
+        h->submit_seq.fetch_add(1, std::memory_order_seq_cst);
+        if (h->sleeping.load(std::memory_order_seq_cst)) futex_wake(&h->submit_seq, 1);
+    };
+    if (!h->server_up.load(std::memory_order_acquire)) kick();
+    const int64_t t0 = now_us();
+    int64_t last_kick = t0, last_check = t0;
+    for (unsigned spins = 1;; spins++) {
+        if (__atomic_load_n(&s->d_done, __ATOMIC_ACQUIRE) == t) break;
+        cpu_relax();
+        if (spins & 255u) continue;
+        const int64_t now = now_us();
+        if (now - last_kick > 300 && !h->server_up.load(std::memory_order_acquire)) { kick(); last_kick = now; }
+        if (now - last_check > 1000) {
+            last_check = now;
+            if (h->state.load(std::memory_order_acquire) != BS_SERVING || !h->direct.load(std::memory_order_acquire) ||
+                (now - t0 > 1000000 && !pid_alive(h->pid.load()))) {
+                if (__atomic_load_n(&s->d_done, __ATOMIC_ACQUIRE) == t) break;
+                return mpbi_fail(MPB_E_HIP, "the broker went away while a read was pending");
+            }
+        }
+        if (now - t0 > 2000) usleep(50);                // something is slow (a launch, a loaded box): off the CPU between looks
+    }
+    if (s->d_pass == 2) return MPB_OK;
+    *ee = s->d_ee;
+    *ns = s->d_ns;
+    *served = true;
+    __atomic_store_n(&s->n_direct, s->n_direct + 1, __ATOMIC_RELAXED);      // (a read handed back is counted by the broker, which serves it)
     return MPB_OK;
 }
 
@@ -874,6 +978,10 @@ int mpb_broker_call(mpb_broker_client *cl, const char *contig, const int32_t *co
     bool priv = false;
     const int32_t stride = (int32_t)(((len > 0 ? len : 1) + 15) & ~15);
     if ((rc = mpbi_pack_one_read(contig, contig_quals, len, false, Mapping::row(s), stride, Mapping::lut(s), &priv))) return rc;
+    if (!priv && len <= MPB_SERVE_STRIDE - 1 && h->direct.load(std::memory_order_acquire)) {
+        bool served = false;
+        if ((rc = direct_call(cl, h, s, len, alpha, ee, ns, &served)) || served) return rc;
+    }
     s->len = len;
     s->alpha = alpha;
     s->priv = priv ? 1 : 0;
@@ -945,7 +1053,11 @@ int mpb_broker_stats(const char *name, int64_t *served, int64_t *batches, int64_
     int rc = map_existing(name, &m);
     if (rc) return rc;
     const BrkHeader *h = m.hdr();
-    if (served) *served = h->served.load();
+    if (served) {
+        int64_t v = h->served.load();
+        for (int i = 0; i < h->n_slots; i++) v += __atomic_load_n(&m.slot(i)->n_direct, __ATOMIC_RELAXED);     // direct calls: counted by the callers
+        *served = v;
+    }
     if (batches) *batches = h->batches.load();
     if (solo) *solo = h->solo.load();
     if (pid) *pid = (h->state.load() == BS_SERVING && pid_alive(h->pid.load())) ? h->pid.load() : 0;

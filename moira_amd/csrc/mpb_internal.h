@@ -163,13 +163,16 @@ void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t
 #define MPB_SERVE_STRIDE 2048            // row bytes of a mailbox entry: reads of up to 2047 bases (longer ones take the other paths)
 struct alignas(64) MpbServePrm { MpbDevParams p; };      // one 64-byte line per request
 struct MpbServeBox {
-    // pinned host memory, [n_ent] each
-    const uint8_t *q;                    // rows of `stride` bytes (written by the host before the door word)
-    int64_t stride;
+    // pinned (or registered) host memory: entry e of each array lies e * its byte stride behind the pointer -- dense arrays
+    // (the stride is the element's size: the context's own entry, the broker's copies) or fields of the broker's
+    // shared-memory slots themselves (every stride is the slot size: the workers' requests are served where they lie)
+    const uint8_t *q;                    // the row (written by the host before the door word)
+    int64_t stride;                      // bytes a row may hold (the length is clamped to it)
     const MpbServePrm *prm;              // the request's parameters (fixed_len / max_len are set by the wave)
     const unsigned long long *door;      // {length << 32 | token}: a token that differs from done[e] is a request
     uint32_t *done;                      // the token of the last request served
     double *ee; int32_t *ns; uint8_t *pass;      // its results (pass == 2: the row budget was missed, the host runs it alone)
+    int64_t q_step, prm_step, door_step, done_step, ee_step, ns_step, pass_step;   // the byte strides of the seven
     const uint32_t *stop;                // [1] non-zero: every wave leaves
     uint32_t *exited;                    // [1] the generation of the last launch that has drained
     // device memory

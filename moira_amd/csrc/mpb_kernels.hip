@@ -1401,12 +1401,20 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox 
     const int e = blockIdx.x;                             // this wave's entry
     if (e < box.n_ent) {
         const long long t_start = wall_clock64();
+        // this entry's own pointers (everything below indexes read 0 of them)
+        auto at = [e](const void *base, int64_t step) { return (char *)const_cast<void *>(base) + (int64_t)e * step; };
+        const unsigned long long *e_door = (const unsigned long long *)at(box.door, box.door_step);
+        uint32_t *e_done = (uint32_t *)at(box.done, box.done_step);
+        const MpbServePrm *e_prm = (const MpbServePrm *)at(box.prm, box.prm_step);
+        int32_t *e_ns = (int32_t *)at(box.ns, box.ns_step);
+        uint8_t *e_stage = box.stage + (int64_t)e * box.stride;
         DpArgs A;
-        A.q = box.q; A.stride = box.stride; A.len = nullptr; A.ns = box.ns_dev; A.cls = box.cls; A.ee = box.ee; A.pass = box.pass;
+        A.q = (const uint8_t *)at(box.q, box.q_step); A.stride = box.stride; A.len = nullptr; A.ns = box.ns_dev + e; A.cls = box.cls + e;
+        A.ee = (double *)at(box.ee, box.ee_step); A.pass = (uint8_t *)at(box.pass, box.pass_step);
         A.ovf_list = nullptr; A.ovf_count = nullptr; A.alg_cells = nullptr; A.perm = nullptr; A.perm_ns = nullptr; A.final_pass = 2;
-        uint32_t last = __hip_atomic_load(box.done + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t last = __hip_atomic_load(e_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         for (;;) {
-            const unsigned long long door = __hip_atomic_load(box.door + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long door = __hip_atomic_load(e_door, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const uint32_t token = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)door);
             if (token != last) {
 #ifdef MPB_SERVE_STAMPS                        // experiment: a request's time inside the wave (100 MHz ticks) and the shader clock it ran at
@@ -1417,7 +1425,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox 
                 const int li = clamp_len(__builtin_amdgcn_readfirstlane((int)(uint32_t)(door >> 32)), (int)box.stride);
                 // the request's parameters: 64 bytes of pinned host memory, 16 per lane of the first four -- requested here,
                 // looked at after the row's statistics (one trip over the link for both)
-                const unsigned long long *hp = (const unsigned long long *)(box.prm + e) + 2 * (lane & 3);
+                const unsigned long long *hp = (const unsigned long long *)e_prm + 2 * (lane & 3);
                 const unsigned long long p_lo = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const unsigned long long p_hi = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 static_assert(sizeof(MpbServePrm) == 64, "one 64-byte line per request");
@@ -1431,17 +1439,17 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox 
                     prm.fixed_len = li;
                     prm.max_len = (int32_t)box.stride;
                     A.prm = prm;
-                    if (lane == 0) { s_args[w] = A; s_args[w].q = box.stage; }
+                    if (lane == 0) { s_args[w] = A; s_args[w].q = e_stage; }
                     wave_lds_fence();
                     return prm;
                 };
-                small_one_read<false, true>(A, &s_args[w], get_prm, li, e, lane, box.ns, box.cls, box.ident, box.stage, s_tab);
+                small_one_read<false, true>(A, &s_args[w], get_prm, li, 0, lane, e_ns, box.cls + e, box.ident + e, e_stage, s_tab);
 #ifdef MPB_SERVE_STAMPS
                 const long long ts1 = wall_clock64();
 #endif
                 __threadfence_system();                   // every lane's stores of this wave: out, and visible to the host
                 __builtin_amdgcn_wave_barrier();
-                if (lane == 0) __hip_atomic_store(box.done + e, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane == 0) __hip_atomic_store(e_done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef MPB_SERVE_STAMPS
                 if (lane == 0) {
                     unsigned long long *dbg = (unsigned long long *)(box.stage + (size_t)box.n_ent * box.stride) + 8 * e;

@@ -77,22 +77,19 @@ int mpbi_wait_flags(const volatile uint32_t *, int64_t, uint32_t, hipStream_t) {
 
 // ---- the resident server (k_serve), as a host thread that keeps k_serve's side of the mailbox protocol: it polls the door
 // words, answers with the oracle, stores the token to done[e], leaves on *stop or when its lifetime is over and says so in
-// *exited.  (The parameters carry 1 - alpha; the stub remembers which alpha each came from.)
+// *exited.
 }   // extern "C"
 #include <chrono>
 #include <mutex>
 #include <thread>
 #include <vector>
-static std::mutex g_alpha_mu;
-static std::vector<std::pair<double, double>> g_alpha_of_thr;
 extern "C" {
 void mpbi_small_params(double alpha, MpbDevParams *out)
 {
     memset(out, 0, sizeof(*out));
-    out->thr = 1 - alpha; out->uncert = 1.0; out->maxerrors = NAN; out->ambig_mode = 1;
-    std::lock_guard<std::mutex> g(g_alpha_mu);
-    for (auto &p : g_alpha_of_thr) if (p.first == out->thr) return;
-    g_alpha_of_thr.emplace_back(out->thr, alpha);
+    // (the parameters carry 1 - alpha; with direct serving they are made in the CLIENT's process and read in the broker's, so
+    // the stub -- whose oracle wants alpha itself -- ships it in a field the per-read entries do not use)
+    out->thr = 1 - alpha; out->uncert = alpha; out->maxerrors = NAN; out->ambig_mode = 1;
 }
 int mpbi_serve_launch(mpb_ctx *, const MpbServeBox *boxp, uint32_t generation, uint32_t lifetime_ms, hipStream_t)
 {
@@ -100,23 +97,24 @@ int mpbi_serve_launch(mpb_ctx *, const MpbServeBox *boxp, uint32_t generation, u
     std::thread([box, generation, lifetime_ms] {
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<uint32_t> last(box.n_ent);
-        for (int e = 0; e < box.n_ent; e++) last[e] = __atomic_load_n(box.done + e, __ATOMIC_ACQUIRE);
+        auto at = [](const void *base, int e, int64_t step) { return (char *)const_cast<void *>(base) + (int64_t)e * step; };
+        for (int e = 0; e < box.n_ent; e++) last[e] = __atomic_load_n((uint32_t *)at(box.done, e, box.done_step), __ATOMIC_ACQUIRE);
         for (;;) {
             bool any = false;
             for (int e = 0; e < box.n_ent; e++) {
-                const unsigned long long door = __atomic_load_n(box.door + e, __ATOMIC_ACQUIRE);
+                const unsigned long long door = __atomic_load_n((const unsigned long long *)at(box.door, e, box.door_step), __ATOMIC_ACQUIRE);
                 const uint32_t token = (uint32_t)door;
                 if (token == last[e]) continue;
                 any = true;
-                const int32_t len = (int32_t)(door >> 32);
-                double alpha = 0.005;
-                { std::lock_guard<std::mutex> g(g_alpha_mu);
-                  for (auto &p : g_alpha_of_thr) if (p.first == box.prm[e].p.thr) alpha = p.second; }
+                int32_t len = (int32_t)(door >> 32);
+                if (len < 0) len = 0;
+                if (len > (int32_t)box.stride) len = (int32_t)box.stride;              // as the kernel: clamped, never trusted
+                const double alpha = ((const MpbServePrm *)at(box.prm, e, box.prm_step))->p.uncert;
                 double ee = 0; int32_t ns = 0; uint8_t pass = 0;
-                oracle_rows(box.q + (size_t)e * box.stride, 1, box.stride, &len, alpha, &ee, &ns, &pass);
+                oracle_rows((const uint8_t *)at(box.q, e, box.q_step), 1, box.stride, &len, alpha, &ee, &ns, &pass);
                 if (len % 7 == 0) { pass = 2; ee = -12345.0; }                   // "row budget missed", as the micro-batch stub
-                box.ee[e] = ee; box.ns[e] = ns; box.pass[e] = pass;
-                __atomic_store_n(box.done + e, token, __ATOMIC_RELEASE);
+                *(double *)at(box.ee, e, box.ee_step) = ee; *(int32_t *)at(box.ns, e, box.ns_step) = ns; *(uint8_t *)at(box.pass, e, box.pass_step) = pass;
+                __atomic_store_n((uint32_t *)at(box.done, e, box.done_step), token, __ATOMIC_RELEASE);
                 last[e] = token;
             }
             if (any) continue;
@@ -140,6 +138,10 @@ hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+hipError_t hipHostRegister(void *, size_t, unsigned int) { return getenv("MPB_STUB_NO_REGISTER") ? hipErrorInvalidValue : hipSuccess; }
+hipError_t hipHostUnregister(void *) { return hipSuccess; }
+hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned int) { *d = h; return hipSuccess; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 const char *hipGetErrorString(hipError_t) { return "stub"; }
 }

@@ -52,13 +52,16 @@ def _worker(name, seed, count, rounds, out):
     out.put((len(bad), bad, len(reads) * rounds, dt))
 
 
-@pytest.mark.parametrize("server", ["1", "0"])
-def test_eight_concurrent_processes_are_bit_exact(oracle, monkeypatch, server):
-    """Both serving forms of the broker: the resident server (k_serve: a wave per slot polls its mailbox entry, no launch per
-    call) and the launch-per-micro-batch lanes (MPB_BROKER_SERVER=0)."""
+@pytest.mark.parametrize("form", ["direct", "copies", "lanes"])
+def test_eight_concurrent_processes_are_bit_exact(oracle, monkeypatch, form):
+    """The three serving forms of the broker: the resident server (k_serve: a wave per slot, no launch per call) reading the
+    workers' shared-memory slots themselves (the segment registered with the runtime; the default) or the broker thread's
+    copies of them (MPB_BROKER_DIRECT=0), and the launch-per-micro-batch lanes (MPB_BROKER_SERVER=0)."""
     from moira_amd import broker
+    server = "0" if form == "lanes" else "1"
     monkeypatch.setenv("MPB_BROKER_SERVER", server)        # read by the broker process, which inherits a worker's environment
-    name = "gputest%s_%d" % (server, os.getpid())
+    monkeypatch.setenv("MPB_BROKER_DIRECT", "0" if form == "copies" else "1")
+    name = "gputest%s_%d" % (form, os.getpid())
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(name, 500 + k, 120, 6, out)) for k in range(8)]

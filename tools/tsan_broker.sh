@@ -75,8 +75,10 @@ INC="-D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude"
 gcc -O1 -g -fPIC -c oracle/pb_oracle.c -o $D/oracle.o -lm
 for san in thread address,undefined; do
   g++ -O1 -g -std=c++17 -pthread -fsanitize=$san -fno-omit-frame-pointer $INC $SRC $D/oracle.o -lm -o $D/run_${san%%,*}
-  echo "== -fsanitize=$san, resident server (the stub's host thread keeps k_serve's side of the mailbox)"
+  echo "== -fsanitize=$san, resident server serving the slots themselves (the stub's host thread keeps k_serve's side of the mailbox)"
   TSAN_OPTIONS="halt_on_error=0" ASAN_OPTIONS="detect_leaks=1" $D/run_${san%%,*}
+  echo "== -fsanitize=$san, resident server behind the broker's copies (MPB_BROKER_DIRECT=0)"
+  MPB_BROKER_DIRECT=0 TSAN_OPTIONS="halt_on_error=0" ASAN_OPTIONS="detect_leaks=1" $D/run_${san%%,*}
   for rt in 0 1; do                # the launch-per-micro-batch lanes: the serving loop alone, and with its optional retire thread
     echo "== -fsanitize=$san, lanes (MPB_BROKER_SERVER=0), retire thread $rt"
     MPB_BROKER_SERVER=0 MPB_BROKER_RETIRE_THREAD=$rt TSAN_OPTIONS="halt_on_error=0" ASAN_OPTIONS="detect_leaks=1" $D/run_${san%%,*}
