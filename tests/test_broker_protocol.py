@@ -323,3 +323,37 @@ def test_a_malformed_slot_is_answered_not_obeyed(broker, stub_lib):
     assert lib.mpb_broker_call(h, b"A" * 40, q.ctypes.data, 40, 0.005, C.byref(ee), C.byref(ns)) == 0
     assert (ee.value, ns.value) == good
     lib.mpb_broker_detach(h)
+
+
+@pytest.mark.parametrize("env", [{"MPB_STUB_NO_REGISTER": "1"}, {"MPB_BROKER_DIRECT": "0"}, {"MPB_BROKER_SERVER": "0"}, {}],
+                         ids=["registration-refused", "copies", "lanes", "direct"])
+def test_every_serving_form_and_the_fallback_when_registration_is_refused(stub_lib, env, monkeypatch):
+    """Direct serving (the resident server reads the workers' slots: the segment is registered with the runtime) is the
+    default; a runtime that refuses the registration leaves the broker's own copies, MPB_BROKER_DIRECT=0 asks for them,
+    MPB_BROKER_SERVER=0 for the launch per micro-batch.  Same answers from each, a slot that changes hands included (the new
+    owner's door tokens start behind the old owner's), and a read the server hands back (length divisible by 7 in the stub)
+    still arrives through the broker."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx = mp.get_context("spawn")
+    name = "f%d_%d" % (os.getpid(), int(time.time() * 1e3) % 100000)
+    p = ctx.Process(target=_serve, args=(stub_lib, name, 2, 0))
+    p.start()
+    try:
+        lib = _load(stub_lib)
+        out = ctx.Queue()
+        for rnd in range(3):                                  # three generations of clients over the same two slots
+            procs = [ctx.Process(target=_client, args=(stub_lib, name, 300 + 10 * rnd + k, 60, 3, out)) for k in range(2)]
+            for pr in procs:
+                pr.start()
+            res = [out.get(timeout=120) for _ in procs]
+            for pr in procs:
+                pr.join(30)
+            assert all(r[0] == "ok" and r[1] == 0 for r in res), (env, rnd, res)
+        st = _stats(lib, name)
+        assert st["served"] == 3 * 2 * 60 * 3 and st["solo"] > 0 and st["attached"] == 0, st
+    finally:
+        _load(stub_lib).mpb_broker_shutdown(name.encode())
+        p.join(10)
+        if p.is_alive():
+            p.kill()
