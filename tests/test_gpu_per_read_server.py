@@ -33,6 +33,8 @@ def test_calls_pauses_batches_and_long_reads(oracle):
     reads = _reads(3, 300)
     reads += [("A" * n, [30 + (i % 9) for i in range(n)], 0.005) for n in (2047, 2048, 5000)]       # the last two: not the server's
     reads += [("ACGT" * 10, [300] * 40, 0.05), ("A" * 1500, [1 + (i % 3) for i in range(1500)], 0.005)]   # a private table; > 1024 rows
+    reads += [("", [], 0.005), ("N", [20], 0.005), ("n" * 20, [30] * 20, 0.005), ("A" * 16, [40] * 16, 0.9),   # empty, all-ambiguous,
+              ("ACGT" * 75, [0] * 300, 0.005), ("A" * 300, [254] * 300, 1e-6)]                              # first-row crossing, Q0, Q254
     want = [oracle.ee_rowwise(s, q, a)[:2] for s, q, a in reads]
     with Engine(0) as eng:
         for i, r in enumerate(reads):
