@@ -1242,6 +1242,7 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
     // lane k takes the 16-byte chunks k, k + 64, ... of the row (at most 16 of them: 256 bytes, so the markers peel exactly)
     f32x2 a01 = {0.f, 0.f};
     float s3 = 0.f;
+    uint4 yr = make_uint4(0, 0, 0, 0);                     // SYS, reads of <= 1024 bases: lane k's chunk k, bytes past the end zeroed
     SV_BEGIN;
     for (int c0 = 0; c0 * 16 < li; c0 += 64) {            // wave-uniform trip count
         const int nv = li - (c0 + lane) * 16;
@@ -1256,6 +1257,7 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
                 y = *reinterpret_cast<const uint4 *>(src);
             }
             if (stage) *reinterpret_cast<uint4 *>(stage + i * args.stride + (int64_t)(c0 + lane) * 16) = y;
+            if (SYS) yr = make_uint4(mask_dword(y.x, nv), mask_dword(y.y, nv - 4), mask_dword(y.z, nv - 8), mask_dword(y.w, nv - 12));
             y.x = fill_dword(y.x, nv); y.y = fill_dword(y.y, nv - 4);
             y.z = fill_dword(y.z, nv - 8); y.w = fill_dword(y.w, nv - 12);
             pre_chunk(s_tab, y, a01, s3);
@@ -1284,6 +1286,60 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
     rows = max(min(rows, li - nzero - n_lower + 1), 1);
     if (rows > MPB_TILE_MAX_ROWS) {                                       // a wide read: the host sends the batch down the pipeline
         if (lane == 0) args.pass[i] = 2;
+        return;
+    }
+    if (SYS && !FMA && li <= 1024 && rows <= 64 && !(prm.flags & ~1u)) {
+        // The resident server's common case, entirely in registers: the row is already here (lane k holds chunk k), so the
+        // class body's trips to memory -- the parked row, ns / cls / ident read back, the callee-saved registers of a
+        // non-inlined body -- are not needed: 2.5 us of a request's 12.9.  One row per lane (the latency bodies' shape), the
+        // read's bytes handed round by v_readlane, the same cell, the same sequential CDF, the same expressions at the end.
+        int keep = lane == 0 ? 0 : -1;
+        asm volatile("" : "+v"(keep));
+        double v1 = lane == 0 ? 1.0 : 0.0;
+        const int nchunks = (li + 15) >> 4;
+#pragma unroll 1
+        for (int ck = 0; ck < nchunks; ck++) {
+            const uint32_t wq[4] = {(uint32_t)__builtin_amdgcn_readlane((int)yr.x, ck), (uint32_t)__builtin_amdgcn_readlane((int)yr.y, ck),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)yr.z, ck), (uint32_t)__builtin_amdgcn_readlane((int)yr.w, ck)};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const double2 ab = mpb_s_lut[(wq[d] >> (8 * t)) & 0xffu];      // bytes past the read's end are zero: the identity step
+                    const double cin = dpp_prev_row(v1, keep);
+                    v1 = cell<false>(ab.x, v1, ab.y, cin);
+                }
+            }
+        }
+        // sequential CDF over the rows (= lanes) in order (ref: bernoullimodule.c:233-251); rows beyond the predicted budget are
+        // looked at too (they are there), a read that still does not cross is the host's (pass = 2), as in the class bodies
+        const double thr = prm.thr;
+        double acc = 0.0, lo = 0.0, hi = 0.0;
+        int js = -1;
+#pragma unroll 1
+        for (int g = 0; g < 64 && js < 0; g++) {
+            const long long bits = __double_as_longlong(v1);
+            const double vg = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), g) << 32) |
+                                                   (unsigned int)__builtin_amdgcn_readlane((int)bits, g));
+            const double na = acc + vg;                    // g == 0: 0 + v0 is exact
+            if (na > thr) { lo = acc; hi = na; js = g; }
+            acc = na;
+        }
+        if (lane == 0) {
+            const int nsv = nzero + n_lower;
+            ns_out[i] = nsv;
+            if (js < 0) {
+                args.pass[i] = 2;
+            } else {
+                double e = (double)(js - 1) + ((thr - lo) / (hi - lo));     // ref: bernoullimodule.c:170-178
+                if (e < 0) e = 0;
+                if (prm.ambig_mode == 0) e = e + (double)nsv;                // moira.py:827-828
+                const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
+                if (prm.flags & 1u) e = floor(e);                            // moira.py:830-831
+                args.ee[i] = e;
+                args.pass[i] = (uint8_t)((prm.ambig_mode == 2 && nzero > 0) ? 0 : (e <= limit ? 1 : 0));   // moira.py:911
+            }
+        }
         return;
     }
     const int c = c_class_of_rows.t[rows];
