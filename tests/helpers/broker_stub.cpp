@@ -87,9 +87,16 @@ extern "C" {
 void mpbi_small_params(double alpha, MpbDevParams *out)
 {
     memset(out, 0, sizeof(*out));
-    // (the parameters carry 1 - alpha; with direct serving they are made in the CLIENT's process and read in the broker's, so
-    // the stub -- whose oracle wants alpha itself -- ships it in a field the per-read entries do not use)
-    out->thr = 1 - alpha; out->uncert = alpha; out->maxerrors = NAN; out->ambig_mode = 1;
+    out->thr = 1 - alpha; out->uncert = 1.0; out->maxerrors = NAN; out->ambig_mode = 1;
+}
+// The parameters carry thr = fl(1 - alpha), and with direct serving they are made in the CLIENT's process -- which may be the
+// real library (tests/test_reference_pipeline_with_dropins.py).  The stub's oracle wants alpha itself: an alpha whose
+// fl(1 - alpha) is that thr gives the same arithmetic (the reference only ever uses 1 - alpha: bernoullimodule.c:244).
+static double alpha_of_thr(double thr)
+{
+    double a = 1 - thr;
+    for (int k = 0; k < 8 && 1 - a != thr; k++) a = nextafter(a, 1 - a < thr ? 0.0 : 1.0);
+    return a;
 }
 int mpbi_serve_launch(mpb_ctx *, const MpbServeBox *boxp, uint32_t generation, uint32_t lifetime_ms, hipStream_t)
 {
@@ -109,7 +116,7 @@ int mpbi_serve_launch(mpb_ctx *, const MpbServeBox *boxp, uint32_t generation, u
                 int32_t len = (int32_t)(door >> 32);
                 if (len < 0) len = 0;
                 if (len > (int32_t)box.stride) len = (int32_t)box.stride;              // as the kernel: clamped, never trusted
-                const double alpha = ((const MpbServePrm *)at(box.prm, e, box.prm_step))->p.uncert;
+                const double alpha = alpha_of_thr(((const MpbServePrm *)at(box.prm, e, box.prm_step))->p.thr);
                 double ee = 0; int32_t ns = 0; uint8_t pass = 0;
                 oracle_rows((const uint8_t *)at(box.q, e, box.q_step), 1, box.stride, &len, alpha, &ee, &ns, &pass);
                 if (len % 7 == 0) { pass = 2; ee = -12345.0; }                   // "row budget missed", as the micro-batch stub
