@@ -125,7 +125,7 @@ def test_no_fma_in_exact_dp_kernel():
         assert "scratch_" not in b, b.split(":")[0]                         # no spills
     # k_dp / k_small / k_serve call the class bodies: all three keep the 128-register budget (4 waves per SIMD) -- a caller
     # declared with looser launch bounds would let the shared bodies grow and halve k_dp's occupancy
-    for name in ("k_dpILb0ELb0E", "k_smallILb0E", "k_serve"):
+    for name in ("k_dpILb0ELb0E", "k_smallILb0E", "k_serve", "k_narrow_rsILi2E", "k_narrow_rsILi3E", "k_narrow_rsILi4E"):
         m = re.search(r"\.amdhsa_kernel _ZN\S*%s\S*\n(?:.*\n)*?\s*\.amdhsa_next_free_vgpr (\d+)" % name, text)
         assert m and int(m.group(1)) <= 128, (name, m and m.group(1))
 
