@@ -264,7 +264,7 @@ struct Broker {
                      o_stop = take_bytes(64), o_exited = take_bytes(64);
         const size_t pin_bytes = o;
         o = 0;
-        const size_t d_stage = take_bytes(ns * MPB_SERVE_STRIDE + ns * 64 /* experiment builds: per-entry stamps behind the rows */), d_ns = take_bytes(ns * 4), d_cls = take_bytes(ns), d_ident = take_bytes(ns * 4),
+        const size_t d_stage = take_bytes(ns * MPB_SERVE_STRIDE), d_ns = take_bytes(ns * 4), d_cls = take_bytes(ns), d_ident = take_bytes(ns * 4),
                      d_gone = take_bytes(64);
         const size_t dev_bytes = o;
         BHIP(hipStreamCreateWithFlags(&srv.stream, hipStreamNonBlocking));
@@ -391,16 +391,6 @@ struct Broker {
         if (getenv("MPB_BROKER_TRACE") && srv.turn_n) {
             fprintf(stderr, "[broker] resident server: %lld requests, %.1f us from the door word to the results on average, %u launches\n",
                     (long long)srv.turn_n, (double)srv.turn_us / (double)srv.turn_n, srv.generation);
-#ifdef MPB_SERVE_STAMPS
-            (void)hipStreamSynchronize(srv.stream);
-            unsigned long long h[BRK_MAX_SLOTS * 8];
-            if (hipMemcpy(h, srv.dev + (size_t)n_slots * MPB_SERVE_STRIDE, (size_t)n_slots * 64, hipMemcpyDeviceToHost) == hipSuccess) {
-                unsigned long long t[5] = {0, 0, 0, 0, 0};
-                for (int i = 0; i < n_slots; i++) for (int k = 0; k < 5; k++) t[k] += h[i * 8 + k];
-                if (t[0]) fprintf(stderr, "[k_serve stamps] %llu requests: read .. results %.2f us, fence + done %.2f us, whole %.2f us, shader clock %.0f MHz\n",
-                                  t[0], t[1] * 0.01 / t[0], t[2] * 0.01 / t[0], t[4] * 0.01 / t[0], (double)t[3] / ((double)t[4] * 0.01));
-            }
-#endif
         }
         (void)hipStreamSynchronize(srv.stream);
         if (srv.running && srv.h_exited) {                  // (a runtime that completes at once -- the test stub -- still has its server out)

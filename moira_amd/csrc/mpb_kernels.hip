@@ -1217,14 +1217,6 @@ __global__ __launch_bounds__(64 * W) void k_wide(DpArgs A, const double2 *__rest
 // latency.  Same prediction formula, same class bodies, same results; a read whose CDF does not
 // cross inside its class is marked pass = 2 and the host sends the batch down the batched path.
 // ------------------------------------------------------------------------------------------
-#ifdef MPB_SERVE_STAMPS
-__device__ unsigned long long g_sv[8];
-#define SV_STAMP(k) do { const long long t__ = wall_clock64(); if (lane == 0) atomicAdd(&g_sv[k], (unsigned long long)(t__ - sv_t)); sv_t = wall_clock64(); } while (0)
-#define SV_BEGIN long long sv_t = wall_clock64()
-#else
-#define SV_STAMP(k)
-#define SV_BEGIN
-#endif
 // One read, one wave: statistics (and parking the row in device memory when it arrives in pinned host memory), the row
 // prediction, the latency body of its class.  Shared by k_small (a launch per micro-batch) and k_serve (resident waves).
 // `prm` and `li` are the read's own; s_args (LDS, this wave's) is what the non-inlined class body reads.
@@ -1243,7 +1235,6 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
     f32x2 a01 = {0.f, 0.f};
     float s3 = 0.f;
     uint4 yr = make_uint4(0, 0, 0, 0);                     // SYS, reads of <= 1024 bases: lane k's chunk k, bytes past the end zeroed
-    SV_BEGIN;
     for (int c0 = 0; c0 * 16 < li; c0 += 64) {            // wave-uniform trip count
         const int nv = li - (c0 + lane) * 16;
         if (nv > 0) {
@@ -1277,7 +1268,6 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
         ambi += __shfl_xor(ambi, off);
     }
     const int nzero = (int)(ambi & 0xffffu), n_lower = (int)(ambi >> 16);
-    SV_STAMP(0);
     const MpbDevParams prm = get_prm();
     const float v = fmaxf(var, 1e-12f);
     const float x = mu + prm.z * sqrtf(v) + (k3 / v) * prm.zq;           // as k_prepass
@@ -1362,11 +1352,9 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
         if (settled) { args.ee[i] = __builtin_inf(); args.pass[i] = 0; }
     }
     if (settled) return;
-    SV_STAMP(1);
     // the class body (this wave, other lanes) reads ns / cls / ident / the parked row back: the stores out of the CU, its L1 emptied
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    SV_STAMP(2);
     const int32_t *pc = ident + i;
     switch (thin) {
 #define MPB_CASE(ID, RR, GG) case ID: dp_tiles<RR, GG, FMA>(s_args, pc, 1, 0, 1); break;
@@ -1374,10 +1362,6 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
 #undef MPB_CASE
     default: break;
     }
-    SV_STAMP(3);
-#ifdef MPB_SERVE_STAMPS
-    if (lane == 0) atomicAdd(&g_sv[7], 1ull);
-#endif
 }
 
 // the per-wave tables of the one-read path: {1 - p, p'} in LDS (module scope, for the class bodies) and the fp32 statistics table
@@ -1473,9 +1457,6 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox 
             const unsigned long long door = __hip_atomic_load(e_door, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const uint32_t token = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)door);
             if (token != last) {
-#ifdef MPB_SERVE_STAMPS                        // experiment: a request's time inside the wave (100 MHz ticks) and the shader clock it ran at
-                const long long ts0 = wall_clock64(), tc0 = clock64();
-#endif
                 asm volatile("" ::: "memory");               // what the host wrote before the door word is READ from here on, and
                                                              // only with system-scope loads (no cache holds it): no invalidate
                 const int li = clamp_len(__builtin_amdgcn_readfirstlane((int)(uint32_t)(door >> 32)), (int)box.stride);
@@ -1500,19 +1481,9 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox 
                     return prm;
                 };
                 small_one_read<false, true>(A, &s_args[w], get_prm, li, 0, lane, e_ns, box.cls + e, box.ident + e, e_stage, s_tab);
-#ifdef MPB_SERVE_STAMPS
-                const long long ts1 = wall_clock64();
-#endif
                 __threadfence_system();                   // every lane's stores of this wave: out, and visible to the host
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) __hip_atomic_store(e_done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef MPB_SERVE_STAMPS
-                if (lane == 0) {
-                    unsigned long long *dbg = (unsigned long long *)(box.stage + (size_t)box.n_ent * box.stride) + 8 * e;
-                    dbg[0] += 1; dbg[1] += (unsigned long long)(ts1 - ts0); dbg[2] += (unsigned long long)(wall_clock64() - ts1);
-                    dbg[3] += (unsigned long long)(clock64() - tc0); dbg[4] += (unsigned long long)(wall_clock64() - ts0);
-                }
-#endif
                 last = token;
                 continue;
             }
@@ -2695,15 +2666,6 @@ void mpb_launch_small(const uint8_t *q, int64_t n, int64_t stride, const int32_t
 // the resident one-read server: one wave per mailbox entry; `gone` (device) is zeroed on the same stream first
 void mpb_launch_serve(const MpbServeBox &box, const double2 *lut, uint32_t generation, uint32_t lifetime_ms, hipStream_t s)
 {
-#ifdef MPB_SERVE_STAMPS
-    {
-        unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sv), sizeof(h));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sv), z, sizeof(z));
-        if (h[7]) fprintf(stderr, "[small_one_read stamps, us] row + statistics %.2f  prediction + report %.2f  fence %.2f  class body %.2f  (%llu reads)\n",
-                          h[0] * 0.01 / h[7], h[1] * 0.01 / h[7], h[2] * 0.01 / h[7], h[3] * 0.01 / h[7], h[7]);
-    }
-#endif
     (void)hipMemsetAsync(box.gone, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(k_serve, dim3(box.n_ent), dim3(64), 0, s, box, lut, generation, (unsigned long long)lifetime_ms * 100000ull);
 }
