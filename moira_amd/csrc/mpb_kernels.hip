@@ -1225,8 +1225,10 @@ __global__ __launch_bounds__(64 * W) void k_wide(DpArgs A, const double2 *__rest
 // the class body is about to read: measured 6 us per request).  `get_prm` hands over the read's parameters when they are
 // first needed -- after the statistics -- so that a caller who fetches them over the link can have that load in flight
 // beside the row's.
+// Returns true when the results went out with system-scope stores (the register-resident body below): the caller then needs
+// no cache write-back before it tells the host.
 template <bool FMA, bool SYS, typename PrmFn>
-__device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs *s_args, PrmFn get_prm, const int li,
+__device__ __forceinline__ bool small_one_read(const DpArgs &args, const DpArgs *s_args, PrmFn get_prm, const int li,
                                                const int64_t i, const int lane, int32_t *__restrict__ ns_out,
                                                uint8_t *__restrict__ cls_out, int32_t *__restrict__ ident,
                                                uint8_t *__restrict__ stage, const float2 *s_tab)
@@ -1276,7 +1278,7 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
     rows = max(min(rows, li - nzero - n_lower + 1), 1);
     if (rows > MPB_TILE_MAX_ROWS) {                                       // a wide read: the host sends the batch down the pipeline
         if (lane == 0) args.pass[i] = 2;
-        return;
+        return false;
     }
     if (SYS && !FMA && li <= 1024 && rows <= 64 && !(prm.flags & ~1u)) {
         // The resident server's common case, entirely in registers: the row is already here (lane k holds chunk k), so the
@@ -1316,21 +1318,23 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
             acc = na;
         }
         if (lane == 0) {
+            // system-scope stores: straight to the host's memory, whatever a cache would do with them
             const int nsv = nzero + n_lower;
-            ns_out[i] = nsv;
+            __hip_atomic_store(ns_out + i, nsv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (js < 0) {
-                args.pass[i] = 2;
+                __hip_atomic_store(args.pass + i, (uint8_t)2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
                 double e = (double)(js - 1) + ((thr - lo) / (hi - lo));     // ref: bernoullimodule.c:170-178
                 if (e < 0) e = 0;
                 if (prm.ambig_mode == 0) e = e + (double)nsv;                // moira.py:827-828
                 const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors : (double)li * prm.uncert;
                 if (prm.flags & 1u) e = floor(e);                            // moira.py:830-831
-                args.ee[i] = e;
-                args.pass[i] = (uint8_t)((prm.ambig_mode == 2 && nzero > 0) ? 0 : (e <= limit ? 1 : 0));   // moira.py:911
+                __hip_atomic_store((unsigned long long *)(args.ee + i), (unsigned long long)__double_as_longlong(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(args.pass + i, (uint8_t)((prm.ambig_mode == 2 && nzero > 0) ? 0 : (e <= limit ? 1 : 0)),   // moira.py:911
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        return;
+        return true;
     }
     const int c = c_class_of_rows.t[rows];
     // One read per wave: a G = 1 body would keep ONE lane busy.  The latency bodies below spread the read's rows over as
@@ -1351,7 +1355,7 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
         ident[i] = (int32_t)i;
         if (settled) { args.ee[i] = __builtin_inf(); args.pass[i] = 0; }
     }
-    if (settled) return;
+    if (settled) return false;
     // the class body (this wave, other lanes) reads ns / cls / ident / the parked row back: the stores out of the CU, its L1 emptied
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1362,6 +1366,7 @@ __device__ __forceinline__ void small_one_read(const DpArgs &args, const DpArgs 
 #undef MPB_CASE
     default: break;
     }
+    return false;
 }
 
 // the per-wave tables of the one-read path: {1 - p, p'} in LDS (module scope, for the class bodies) and the fp32 statistics table
@@ -1404,7 +1409,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_small(DpArgs args,
     const int64_t i = (int64_t)blockIdx.x * 4 + w;
     if (i >= n) return;                                   // wave-uniform; no barrier below
     const int li = args.len ? clamp_len(args.len[i], args.prm.max_len) : args.prm.fixed_len;
-    small_one_read<FMA, false>(args, &s_args, [&] { return args.prm; }, li, i, lane, ns_out, cls_out, ident, stage, s_tab);
+    (void)small_one_read<FMA, false>(args, &s_args, [&] { return args.prm; }, li, i, lane, ns_out, cls_out, ident, stage, s_tab);
     if (done) {
         __threadfence_system();                           // every lane's stores of this wave: out, and visible to the host
         __builtin_amdgcn_wave_barrier();
@@ -1480,10 +1485,18 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox 
                     wave_lds_fence();
                     return prm;
                 };
-                small_one_read<false, true>(A, &s_args[w], get_prm, li, 0, lane, e_ns, box.cls + e, box.ident + e, e_stage, s_tab);
-                __threadfence_system();                   // every lane's stores of this wave: out, and visible to the host
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) __hip_atomic_store(e_done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                const bool light = small_one_read<false, true>(A, &s_args[w], get_prm, li, 0, lane, e_ns, box.cls + e, box.ident + e, e_stage, s_tab);
+                // the results before the word that announces them.  Stores made at system scope go straight out and reach the host
+                // in the order they were issued once the wave has seen them acknowledged; anything else (the class bodies'
+                // plain stores) is written back from the caches first
+                if (light) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(e_done, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    __threadfence_system();
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) __hip_atomic_store(e_done, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 last = token;
                 continue;
             }
