@@ -1806,14 +1806,6 @@ __device__ __forceinline__ void nar_dword(double (&v)[R], const nar_entry_t *tab
     for (int t = 0; t < 4; t++) nar_step<R>(v, tab[(w >> (8 * t)) & 0xffu]);
 }
 
-#ifdef MPB_NAR_STAMPS                          // experiment: where a wave's cycles go (request / wait / arithmetic / epilogue)
-__device__ unsigned long long g_nar_stamps[4];
-#define NAR_T0() const long long t_s = __builtin_readcyclecounter()
-#define NAR_T1(k) st[k] += __builtin_readcyclecounter() - t_s
-#else
-#define NAR_T0()
-#define NAR_T1(k)
-#endif
 
 // (Rows whose stride is a multiple of 64 bytes take k_narrow_rs below since the second session of round 5; a form of this
 // kernel that fetched the line a row pair shares only once -- tail buffers beside the ring, -DMPB_NAR_TAILS -- is in the
@@ -1882,9 +1874,6 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
         }
     };
 
-#ifdef MPB_NAR_STAMPS
-    long long st[4] = {0, 0, 0, 0};
-#endif
     int64_t pf_b = gw, cur_b = gw;            // row block of the next panel to request / being computed
     int pf_c = 0, cur_c = 0;
     int64_t pf = 0;                           // panels requested so far
@@ -1900,12 +1889,10 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     };
 #pragma unroll
     for (int k = 0; k < D - 1; k++) request(ring_lds[k]);
-#ifndef MPB_NAR_LATE_FREE
     // A panel's slot is free as soon as its 64 bytes per lane are in registers -- at the START of its step, not at the end: the
     // request that refills it is made right behind those reads, so D panels are in flight while one is computed on, not D - 1
     // (what a CU can have in flight is what bounds the stream, and LDS capacity is what bounds that: profiles/r05_narrow_variants.txt).
     request(ring_lds[D - 1]);
-#endif
 
     double v[R];
 #pragma unroll
@@ -1920,12 +1907,9 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
 
     auto step = [&](const int S, const int64_t s) {
         (void)s;
-#ifdef MPB_NAR_LATE_FREE
-        { NAR_T0(); request(ring_lds[(S + D - 1) % D]); NAR_T1(0); }   // the slot the step before has just finished with
-#endif
         // the panel of this step has landed when at most the requests made after it are still out
         const int64_t younger = pf - (s + 1);               // 0 .. D-1 panels (wave-uniform)
-        { NAR_T0();
+        {
 #ifdef MPB_NAR_NODMA
         nar_wait<0>();
 #endif
@@ -1933,10 +1917,7 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
         else if (younger == 2) nar_wait<8>();
         else if (younger == 1) nar_wait<4>();
         else nar_wait<0>();
-        NAR_T1(1); }
-#ifdef MPB_NAR_STAMPS
-        const long long t_c = __builtin_readcyclecounter();
-#endif
+        }
         const uint8_t *mine = ring[S] + tl;
 #ifdef MPB_NAR_NOARITH                         // timing experiment: the panel stream alone
         const int nbases = 0;
@@ -1956,10 +1937,8 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
                 const uint4 x = *reinterpret_cast<const uint4 *>(mine + k * 256);
                 wd[4 * k] = x.x; wd[4 * k + 1] = x.y; wd[4 * k + 2] = x.z; wd[4 * k + 3] = x.w;
             }
-#ifndef MPB_NAR_LATE_FREE
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the panel is in registers: its slot may be overwritten
-            { NAR_T0(); request(ring_lds[S]); NAR_T1(0); }
-#endif
+            request(ring_lds[S]);
 #define NAR_LOOKUP(w, t) s_p[((w) >> (8 * (t))) & 0xffu]
             nar_entry_t P[18][4];                       // P[d]: table entries of dword d (static indices only)
             double A[17][4];                            // A[d]: their 1 - p
@@ -2012,15 +1991,9 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
                     }
                 }
             }
-#ifndef MPB_NAR_LATE_FREE
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a partial panel is read chunk by chunk: free at its end)
             request(ring_lds[S]);
-#endif
         }
-#ifdef MPB_NAR_STAMPS
-        st[2] += __builtin_readcyclecounter() - t_c;
-        const long long t_e = __builtin_readcyclecounter();
-#endif
         if (++cur_c == ncq) {
             // ---- a row block is done: sequential CDF, interpolation, predicate (as the tile classes' epilogue) ----
             const int64_t i = cur_b * 64 + lane;
@@ -2060,9 +2033,6 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
             cur_c = 0;
             cur_b += W;
         }
-#ifdef MPB_NAR_STAMPS
-        st[3] += __builtin_readcyclecounter() - t_e;
-#endif
     };
     for (int64_t s = 0; s < total; s += D) {
         step(0, s);
@@ -2071,9 +2041,6 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
         if (D > 3 && s + 3 < total) step(3 % D, s + 3);
     }
     if (lane == 0) wave_count[gw] = nlist;
-#ifdef MPB_NAR_STAMPS
-    if (lane == 0) for (int k = 0; k < 4; k++) atomicAdd(&g_nar_stamps[k], (unsigned long long)st[k]);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2733,16 +2700,6 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
     }
 #undef MPB_NRS_LAUNCH
 #undef MPB_NAR_LAUNCH
-#ifdef MPB_NAR_STAMPS
-    if (getenv("MPB_NAR_STAMPS_PRINT")) {
-        (void)hipStreamSynchronize(s);
-        unsigned long long h[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0};
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nar_stamps), sizeof(h));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nar_stamps), z, sizeof(z));
-        fprintf(stderr, "[k_narrow stamps, cycles per wave] request %.0f  wait %.0f  arithmetic %.0f  epilogue %.0f  (%d waves)\n",
-                (double)h[0] / nwaves, (double)h[1] / nwaves, (double)h[2] / nwaves, (double)h[3] / nwaves, nwaves);
-    }
-#endif
     hipLaunchKernelGGL(k_nar_offsets, dim3(1), dim3(1024), 0, s, ws.nar_wave_count, nwaves, ws.nar_wave_off, ws.nar_count);
     hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, ws.nar_wave_off, nblk, nwaves, per_blk, list);
 }

@@ -2,6 +2,7 @@
 # Run ON THE GPU BOX: k_narrow (final form: pair table, slot refilled early) by ring depth = resident workgroups per CU (4 / 3 / 2):
 # time and memory-side reads per launch
 export TMPDIR=/tmp
+export MPB_NAR_NO_RS=1          # the ring form (k_narrow): at this stride the library would take k_narrow_rs
 FL="-O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -fno-fast-math -pthread -Iinclude -x hip"
 mkdir -p /tmp/var
 for d in 2 3 4; do /opt/rocm/bin/hipcc $FL -DMPB_NAR_DEPTH=$d moira_amd/csrc/mpb_kernels.hip moira_amd/csrc/mpb_api.cpp moira_amd/csrc/mpb_broker.cpp -o /tmp/var/dd$d.so 2>/tmp/var/dd$d.err || { tail -5 /tmp/var/dd$d.err; exit 1; }; done

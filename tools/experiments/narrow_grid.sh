@@ -2,6 +2,7 @@
 # Run ON THE GPU BOX: k_narrow's memory-side read requests and time against the number of resident workgroups (the L2
 # footprint of lines waiting for their second 64-byte half) and with non-temporal requests.
 export TMPDIR=/tmp
+export MPB_NAR_NO_RS=1          # the ring form (k_narrow): at this stride the library would take k_narrow_rs
 FL="-O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -fno-fast-math -pthread -Iinclude -x hip"
 mkdir -p /tmp/var
 /opt/rocm/bin/hipcc $FL -DMPB_TUNING_KNOBS moira_amd/csrc/mpb_kernels.hip moira_amd/csrc/mpb_api.cpp moira_amd/csrc/mpb_broker.cpp -o /tmp/var/knobs.so || exit 1

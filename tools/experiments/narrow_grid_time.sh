@@ -1,5 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: k_narrow time against resident workgroups and ring depth (no profiler attached).
+export MPB_NAR_NO_RS=1          # the ring form (k_narrow): at this stride the library would take k_narrow_rs
 FL="-O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off -fno-fast-math -pthread -Iinclude -x hip"
 mkdir -p /tmp/var
 for d in 2 3 4; do
