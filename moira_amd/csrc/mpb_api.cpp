@@ -122,8 +122,10 @@ struct mpb_ctx {
     } serve;
 };
 
+extern "C" {                              // (defined inside the extern "C" block below, next to the entry that uses them)
 static void serve_quiesce(mpb_ctx *c);    // the per-read entry's resident kernel leaves (before anything is freed: the runtime
 static void serve_free(mpb_ctx *c);       // waits for the whole device there)
+}
 
 // Threads that copy a pageable input chunk into its pinned staging block: half of the CPUs this process is
 // granted (cgroup quota, else the affinity mask), at most 8 -- one memcpy stream does not saturate PCIe 5.
