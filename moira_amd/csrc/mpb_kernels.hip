@@ -1236,7 +1236,7 @@ __device__ __forceinline__ bool small_one_read(const DpArgs &args, const DpArgs 
     // lane k takes the 16-byte chunks k, k + 64, ... of the row (at most 16 of them: 256 bytes, so the markers peel exactly)
     f32x2 a01 = {0.f, 0.f};
     float s3 = 0.f;
-    uint4 yr = make_uint4(0, 0, 0, 0);                     // SYS, reads of <= 1024 bases: lane k's chunk k, bytes past the end zeroed
+    uint4 yr = make_uint4(0, 0, 0, 0);                     // reads of <= 1024 bases: lane k's chunk k, bytes past the end zeroed
     for (int c0 = 0; c0 * 16 < li; c0 += 64) {            // wave-uniform trip count
         const int nv = li - (c0 + lane) * 16;
         if (nv > 0) {
@@ -1280,6 +1280,8 @@ __device__ __forceinline__ bool small_one_read(const DpArgs &args, const DpArgs 
         if (lane == 0) args.pass[i] = 2;
         return false;
     }
+    // (the resident server only: in k_small's launches it was measured against the class bodies -- equal for one read, SLOWER
+    // for batches of 64-2048 reads, 35 / 74 / 109 us against 29 / 43 / 60: profiles/r05_per_read_server.txt)
     if (SYS && !FMA && li <= 1024 && rows <= 64 && !(prm.flags & ~1u)) {
         // The resident server's common case, entirely in registers: the row is already here (lane k holds chunk k), so the
         // class body's trips to memory -- the parked row, ns / cls / ident read back, the callee-saved registers of a
