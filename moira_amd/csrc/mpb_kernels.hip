@@ -1280,8 +1280,9 @@ __device__ __forceinline__ bool small_one_read(const DpArgs &args, const DpArgs 
         if (lane == 0) args.pass[i] = 2;
         return false;
     }
-    // (the resident server only: in k_small's launches it was measured against the class bodies -- equal for one read, SLOWER
-    // for batches of 64-2048 reads, 35 / 74 / 109 us against 29 / 43 / 60: profiles/r05_per_read_server.txt)
+    // (the resident server only -- interleaved A/B there: the in-process entry 17.0 against 18.4 us per call, the broker's
+    // workers no different; in k_small's launches it was equal for one read and SLOWER for batches of 64-2048 reads,
+    // 35 / 74 / 109 us against 29 / 43 / 60: profiles/r05_per_read_server.txt)
     if (SYS && !FMA && li <= 1024 && rows <= 64 && !(prm.flags & ~1u)) {
         // The resident server's common case, entirely in registers: the row is already here (lane k holds chunk k), so the
         // class body's trips to memory -- the parked row, ns / cls / ident read back, the callee-saved registers of a
