@@ -80,3 +80,26 @@ def test_the_launch_per_call_gives_the_same(oracle):
     import json
     want = [list(oracle.ee_rowwise(s, q, a)[:2]) for s, q, a in _reads(3, 120)]
     assert json.loads(outs[0]) == want
+
+
+def test_reference_vectors_read_by_read(oracle):
+    """The reference's own results (tests/golden/*.npz: bernoullimodule.c through the real extension, its Python twin where C
+    is undefined), every read of every set, ONE calculate_errors_PB call each: the resident server (registers-only body for
+    reads of <= 1024 bases and <= 64 rows, the class bodies beyond, the ordinary path for >= 2048 bases or > 1024 rows)."""
+    import golden_io as G
+    from moira_amd.engine import Engine
+    done = 0
+    with Engine(0) as eng:
+        for name in G.NPZ_SETS:
+            s = G.load_set(name)
+            q, lens, exp, alpha = s["q"], s["lens"], G.expected_value(s), float(s["alpha"])
+            step = 1 if name != "long_reads" else 4                     # (the long reads: every fourth, they take milliseconds each)
+            for i in range(0, len(lens), step):
+                row = q[i, :int(lens[i])]
+                seq = "".join("N" if b == 0 else "n" if b == 255 else "A" for b in row.tolist())
+                quals = [30 if b in (0, 255) else int(b) for b in row.tolist()]
+                ee, ns = eng.calculate_errors_PB(seq, quals, alpha)
+                want = float(exp[i])
+                assert (ee == want or (ee != ee and want != want)) and ns == int(s["ns_ref"][i]), (name, i, ee, want)
+                done += 1
+    assert done > 10_000
