@@ -816,7 +816,7 @@ static int filter_device_narrow(mpb_ctx *c, int rows0, const uint8_t *d_q, int64
     hipStream_t s = c->stream;
     if ((rc = ensure_narrow_workspace(c, n))) return rc;
     // persistent grid: as many workgroups as fit the CUs' LDS at once
-    const int per_cu = (160 * 1024) / (mpb_narrow_rs_reads_per_lane(row_stride) ? mpb_narrow_rs_lds_bytes() : mpb_narrow_lds_bytes());
+    const int per_cu = (160 * 1024) / (mpb_narrow_rs_reads_per_lane(row_stride, rows0) ? mpb_narrow_rs_lds_bytes() : mpb_narrow_lds_bytes());
     const int grid = (c->n_cu > 0 ? c->n_cu : 256) * (per_cu > 0 ? per_cu : 1);
     { Span t(c, MPB_K_NARROW);
       mpb_launch_narrow(rows0, d_q, n, row_stride, fixed_len, prm, c->ws, d_ee, d_ns, d_pass, c->ws.nar_list, grid, s); }

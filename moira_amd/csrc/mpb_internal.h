@@ -204,7 +204,7 @@ void mpb_launch_count(const uint8_t *pass, int64_t n, const MpbWorkspace &ws, hi
 void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
                        const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks, hipStream_t s);
 int mpb_narrow_lds_bytes();               // static LDS of one k_narrow workgroup (the host sizes the persistent grid from it)
-int mpb_narrow_rs_reads_per_lane(int64_t stride);   // k_narrow_rs (whole-line panels staged in registers): reads per lane, 0 = k_narrow
+int mpb_narrow_rs_reads_per_lane(int64_t stride, int rows0);   // k_narrow_rs (whole-line panels staged in registers): reads per lane, 0 = k_narrow
 int mpb_narrow_rs_lds_bytes();
 // predicted row budgets of `n_sample` reads spread over the batch -> ws.nar_sample (zeroed here)
 void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,

@@ -2112,7 +2112,7 @@ __device__ __forceinline__ void nar_run(double (&v)[R], uint32_t &nonzero, const
     }
 }
 
-template <int R>
+template <int R, bool ALIGNED>
 __global__ __launch_bounds__(256) void k_narrow_rs(const uint8_t *__restrict__ q, int64_t n, int64_t stride, int32_t li, int32_t k,
                                                    MpbDevParams prm, const double2 *__restrict__ lut_g,
                                                    double *__restrict__ ee, int32_t *__restrict__ ns, uint8_t *__restrict__ pass,
@@ -2255,35 +2255,75 @@ __global__ __launch_bounds__(256) void k_narrow_rs(const uint8_t *__restrict__ q
 #ifdef MPB_NAR_NOARITH                         // timing experiment: the panel stream alone (loads + tile writes, two tile reads per panel)
         nonzero += *reinterpret_cast<const uint32_t *>(tile + x0) + *reinterpret_cast<const uint32_t *>(tile + (x0 ^ 64));
 #else
-        // ---- the panel's two 64-byte halves.  A half holds up to four 16-byte chunks of the current read: they go through one
-        // straight-line run (nar_run<R, 4 x chunks>); the bytes of a read's last chunk past its end are made zero first (the
-        // identity step), so a 300-base read's last 44 bases take the same code as the others, as 48.
+        // ---- the panel's two 64-byte halves, four 16-byte chunks each.  The chunks of a half that belong to ONE read go through
+        // one straight-line run (nar_run<R, 4 x chunks>); the bytes of a read's last chunk past its end are made zero first (the
+        // identity step), so a 300-base read's last 44 bases take the same code as the others, as 48.  A read may end -- and the
+        // next one begin -- anywhere a chunk does (strides that are no multiple of 64): then the half is several runs; row
+        // padding is skipped by whole chunks.  All of it wave-uniform.
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int nb = li - u;                              // bases of the current read from this half on (wave-uniform)
-            if (nb > 0) {
-                const int nch = nb >= 64 ? 4 : (nb + 15) >> 4;  // chunks of this half that hold bases
-                uint32_t wd[16];
-#define NRS_LOAD(NC)                                                                                         \
-                _Pragma("unroll") for (int c = 0; c < NC; c++) {                                             \
-                    const u32x4 x = *reinterpret_cast<const u32x4 *>(tile + (x0 ^ ((h * 4 + c) << 4)));      \
-                    wd[4 * c] = x.x; wd[4 * c + 1] = x.y; wd[4 * c + 2] = x.z; wd[4 * c + 3] = x.w;           \
-                }                                                                                            \
-                if (nb < 16 * NC) {                                                                          \
-                    _Pragma("unroll") for (int d = 0; d < 4; d++)                                            \
-                        wd[4 * (NC - 1) + d] = mask_dword(wd[4 * (NC - 1) + d], nb - 16 * (NC - 1) - 4 * d); \
+            if (ALIGNED) {
+                // rows of a multiple of 64 bytes: a read starts with a half, so a half holds chunks of ONE read -- one run, every
+                // address a constant (the form measured in profiles/r05_narrow_variants.txt; the loop below costs it 2-3 %)
+                const int nb = li - u;                          // bases of the current read from this half on
+                if (nb > 0) {
+                    const int nch = nb >= 64 ? 4 : (nb + 15) >> 4;
+                    uint32_t wd[16];
+#define NRS_LOADA(NC)                                                                                        \
+                    _Pragma("unroll") for (int c = 0; c < NC; c++) {                                         \
+                        const u32x4 x = *reinterpret_cast<const u32x4 *>(tile + (x0 ^ ((h * 4 + c) << 4)));  \
+                        wd[4 * c] = x.x; wd[4 * c + 1] = x.y; wd[4 * c + 2] = x.z; wd[4 * c + 3] = x.w;       \
+                    }                                                                                        \
+                    if (nb < 16 * NC) {                                                                      \
+                        _Pragma("unroll") for (int d = 0; d < 4; d++)                                        \
+                            wd[4 * (NC - 1) + d] = mask_dword(wd[4 * (NC - 1) + d], nb - 16 * (NC - 1) - 4 * d); \
+                    }
+                    switch (nch) {
+                    case 4: { NRS_LOADA(4) nar_run<R, 16>(v, nonzero, s_p, wd); break; }
+                    case 3: { NRS_LOADA(3) nar_run<R, 12>(v, nonzero, s_p, wd); break; }
+                    case 2: { NRS_LOADA(2) nar_run<R, 8>(v, nonzero, s_p, wd); break; }
+                    default: { NRS_LOADA(1) nar_run<R, 4>(v, nonzero, s_p, wd); break; }
+                    }
+#undef NRS_LOADA
+                    if (nb <= 64) finish(cur_sb, sread);
                 }
-                switch (nch) {
-                case 4: { NRS_LOAD(4) nar_run<R, 16>(v, nonzero, s_p, wd); break; }
-                case 3: { NRS_LOAD(3) nar_run<R, 12>(v, nonzero, s_p, wd); break; }
-                case 2: { NRS_LOAD(2) nar_run<R, 8>(v, nonzero, s_p, wd); break; }
-                default: { NRS_LOAD(1) nar_run<R, 4>(v, nonzero, s_p, wd); break; }
-                }
-#undef NRS_LOAD
-                if (nb <= 64) finish(cur_sb, sread);
+                u += 64;
+                if (u == istride) { u = 0; sread++; }
+                continue;
             }
-            u += 64;
-            if (u == istride) { u = 0; sread++; }
+            int p = 0;                                          // chunk of this half
+            while (p < 4) {
+                const int nb = li - u;                          // bases of the current read from here on
+                if (nb <= 0) {                                  // its padding: on to the next read, or to the end of the half
+                    const int skip = min((istride - u) >> 4, 4 - p);
+                    p += skip;
+                    u += 16 * skip;
+                } else {
+                    const int nch = min((nb + 15) >> 4, 4 - p); // chunks of this read in what is left of the half
+                    const int c0 = h * 4 + p;
+                    uint32_t wd[16];
+#define NRS_LOAD(NC)                                                                                         \
+                    _Pragma("unroll") for (int c = 0; c < NC; c++) {                                         \
+                        const u32x4 x = *reinterpret_cast<const u32x4 *>(tile + (x0 ^ ((c0 + c) << 4)));     \
+                        wd[4 * c] = x.x; wd[4 * c + 1] = x.y; wd[4 * c + 2] = x.z; wd[4 * c + 3] = x.w;       \
+                    }                                                                                        \
+                    if (nb < 16 * NC) {                                                                      \
+                        _Pragma("unroll") for (int d = 0; d < 4; d++)                                        \
+                            wd[4 * (NC - 1) + d] = mask_dword(wd[4 * (NC - 1) + d], nb - 16 * (NC - 1) - 4 * d); \
+                    }
+                    switch (nch) {
+                    case 4: { NRS_LOAD(4) nar_run<R, 16>(v, nonzero, s_p, wd); break; }
+                    case 3: { NRS_LOAD(3) nar_run<R, 12>(v, nonzero, s_p, wd); break; }
+                    case 2: { NRS_LOAD(2) nar_run<R, 8>(v, nonzero, s_p, wd); break; }
+                    default: { NRS_LOAD(1) nar_run<R, 4>(v, nonzero, s_p, wd); break; }
+                    }
+#undef NRS_LOAD
+                    p += nch;
+                    u += 16 * nch;
+                    if (16 * nch >= nb) finish(cur_sb, sread);  // the read is done (u may stand in its padding now)
+                }
+                if (u >= istride) { u = 0; sread++; }
+            }
         }
 #endif
         if (++cur_pk == NP) { cur_pk = 0; cur_sb += W; sread = 0; }
@@ -2667,12 +2707,18 @@ int mpb_narrow_lds_bytes()
     return 256 * (int)sizeof(nar_entry_t) + MPB_NAR_DEPTH * 4 * MPB_NAR_PANEL + 32;
 }
 
-// k_narrow_rs (register-staged, whole lines): rows whose stride is a multiple of 64 bytes; reads per lane (0: not this form)
-int mpb_narrow_rs_reads_per_lane(int64_t stride)
+// k_narrow_rs (register-staged, whole lines): reads per lane, 0: not this form.  Rows of a multiple of 64 bytes: always (a read
+// starts with a half panel: one run per half).  Other strides: a lane's reads begin anywhere a 16-byte chunk does and a half may
+// be several runs -- measured at stride 304 (profiles/r05_narrow_variants.txt): 7 % faster than the ring at R = 2 (and 3.04
+// instead of 4.2 GB read), 4-5 % slower at R = 3, 4: so only for two rows.
+int mpb_narrow_rs_reads_per_lane(int64_t stride, int rows0)
 {
     static const bool off = getenv("MPB_NAR_NO_RS") != nullptr;      // A/B runs (tools/): the LDS-DMA form for every stride
-    if (off || stride % 64 != 0 || stride > (1 << 16)) return 0;
-    return stride % 128 == 0 ? 1 : 2;
+    if (off || stride % 16 != 0 || stride > (1 << 16)) return 0;
+    if (stride % 64 != 0 && rows0 != 2) return 0;
+    int k = 1;                                                        // 128 / gcd(stride, 128): 1, 2, 4 or 8
+    while ((k * stride) % 128 != 0) k *= 2;
+    return k;
 }
 
 int mpb_narrow_rs_lds_bytes()
@@ -2683,7 +2729,7 @@ int mpb_narrow_rs_lds_bytes()
 void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
                        const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks, hipStream_t s)
 {
-    const int rs_k = mpb_narrow_rs_reads_per_lane(stride);
+    const int rs_k = mpb_narrow_rs_reads_per_lane(stride, rows0);
     const int per_blk = 64 * (rs_k ? rs_k : 1);              // reads of one row block / stream block
     const int64_t nblk = (n + per_blk - 1) / per_blk;
     int64_t blocks = (nblk + 3) / 4;
@@ -2695,8 +2741,10 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
     if (blocks < 1) blocks = 1;
     const int nwaves = (int)blocks * 4;
 #define MPB_NAR_LAUNCH(RR) hipLaunchKernelGGL((k_narrow<RR, MPB_NAR_DEPTH>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
-#define MPB_NRS_LAUNCH(RR) hipLaunchKernelGGL((k_narrow_rs<RR>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, rs_k, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
-    if (rs_k) {
+#define MPB_NRS_LAUNCH(RR) hipLaunchKernelGGL((k_narrow_rs<RR, true>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, rs_k, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
+    if (rs_k && stride % 64 != 0) {                        // (two rows only: mpb_narrow_rs_reads_per_lane)
+        hipLaunchKernelGGL((k_narrow_rs<2, false>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, fixed_len, rs_k, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count);
+    } else if (rs_k) {
         switch (rows0) {
         case 2: MPB_NRS_LAUNCH(2); break;
         case 3: MPB_NRS_LAUNCH(3); break;

@@ -11,7 +11,7 @@ from moira_amd.engine import Engine  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
-stride, L, steps = 320, 300, 30
+stride, L, steps = int(os.environ.get("PROBE_STRIDE", "320")), 300, 30      # PROBE_STRIDE=304: rows that are no multiple of 64 bytes
 with Engine(0) as eng:
     d_q, d_ee, d_ns, d_pass = eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)
     eng.synth_fill(d_q, n, stride, fixed_len=L, seed=2, profile=1)

@@ -30,7 +30,7 @@ void mpb_launch_scatter_back(const int32_t *, int64_t, const double *, const int
 void mpb_launch_serve(const MpbServeBox &, const double2 *, uint32_t, uint32_t, hipStream_t) STUB
 int mpb_narrow_lds_bytes() { return 1 << 15; }
 int mpb_narrow_rs_lds_bytes() { return 1 << 15; }
-int mpb_narrow_rs_reads_per_lane(int64_t) { return 0; }
+int mpb_narrow_rs_reads_per_lane(int64_t, int) { return 0; }
 CPP
 cat > $D/main.cpp <<'CPP'
 #include "moira_pb.h"
