@@ -213,7 +213,8 @@ int mpb_encode_ascii_device(mpb_ctx *ctx, const uint8_t *d_q, int64_t n, int64_t
  * Filter a batch that is RESIDENT IN HBM.
  *   d_q         device, n rows of row_stride bytes (row_stride % 16 == 0, 16-B aligned; a 64-B aligned
  *               matrix with row_stride % 64 == 0 is the fast layout: every 64-byte lane group then reads one
- *               sector -- a matrix offset by 16 bytes costs the prepass 7 %)
+ *               sector -- a matrix offset by 16 bytes costs the prepass 7 %; and the narrow pass of batches of good reads
+ *               then walks whole 128-byte lines at every row count, at other strides only with two rows)
  *   d_len       device int32[n], or NULL when every read has `fixed_len` bases
  *   outputs     device: d_ee double[n], d_ns int32[n], d_pass uint8[n]
  *   counts      host, may be NULL (when non-NULL the call synchronises)
