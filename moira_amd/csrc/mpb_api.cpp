@@ -702,28 +702,41 @@ static int ensure_narrow_workspace(mpb_ctx *c, int64_t n)
     serve_quiesce(c);
     if (c->ws_nar) { HIPCHK(hipFree(c->ws_nar)); c->ws_nar = nullptr; c->ws_nar_cap = 0; }
     const int64_t cap = n + n / 8 + 1024;
-    const int64_t b_list = align_up((cap + 64) * 4, 256), b_waves = align_up((int64_t)MPB_NAR_MAX_WAVES * 4, 256);
-    HIPCHK(hipMalloc(&c->ws_nar, (size_t)(2 * b_list + 2 * b_waves)));
+    const int64_t b_list = align_up((cap + 64) * 4, 256), b_waves = align_up((int64_t)(MPB_NAR_MAX_WAVES + 1) * 4, 256);
+    const int64_t b_groups = align_up((cap / 64 + 2) * 4, 256);
+    // (the ragged pass' order entries, 8 bytes per read, + group costs + wave ranges lie behind the lists)
+    const int64_t b_wins = align_up((cap / 4096 + 2) * 8, 256);
+    HIPCHK(hipMalloc(&c->ws_nar, (size_t)(4 * b_list + 3 * b_waves + b_groups + 2 * b_wins)));
     char *p = (char *)c->ws_nar;
     c->ws.nar_seg = (int32_t *)p; p += b_list;
     c->ws.nar_list = (int32_t *)p; p += b_list;
     c->ws.nar_wave_count = (int32_t *)p; p += b_waves;
-    c->ws.nar_wave_off = (int32_t *)p;
+    c->ws.nar_wave_off = (int32_t *)p; p += b_waves;
+    c->ws.rg_ord = (int2 *)p; p += 2 * b_list;
+    c->ws.rg_gpre = (int32_t *)p; p += b_groups;
+    c->ws.rg_wsum = (unsigned long long *)p; p += b_wins;
+    c->ws.rg_wpre = (unsigned long long *)p; p += b_wins;
+    c->ws.rg_gstart = (int32_t *)p;
     c->ws_nar_cap = cap;
     return MPB_OK;
 }
 
 // the dense sub-batch of the reads a narrow pass handed back: m rows of `stride` bytes + their results
-struct FallbackBlock { uint8_t *q; double *ee; int32_t *ns; uint8_t *pass; };
+struct FallbackBlock { uint8_t *q; double *ee; int32_t *ns; uint8_t *pass; int32_t *len; };
 static int ensure_fallback_block(mpb_ctx *c, int64_t m, int64_t stride, FallbackBlock *out)
 {
     if (m > c->fb_cap || stride > c->fb_stride) {
         HIPCHK(hipStreamSynchronize(c->stream));
         serve_quiesce(c);
-        if (c->fb_block) { HIPCHK(hipFree(c->fb_block)); c->fb_block = nullptr; c->fb_cap = 0; }
+        if (c->fb_block) { HIPCHK(hipFree(c->fb_block)); c->fb_block = nullptr; c->fb_cap = 0; c->fb_stride = 0; }
         const int64_t cap = m + m / 4 + 4096;
-        const int64_t st = stride > c->fb_stride ? stride : c->fb_stride;
-        HIPCHK(hipMalloc(&c->fb_block, (size_t)(align_up(cap * st, 256) + align_up(cap * 8, 256) + align_up(cap * 4, 256) + align_up(cap, 256))));
+        const int64_t st = stride;
+        const size_t bytes = (size_t)(align_up(cap * st, 256) + align_up(cap * 8, 256) + 2 * align_up(cap * 4, 256) + align_up(cap, 256));
+        if (hipMalloc(&c->fb_block, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            c->fb_block = nullptr;
+            return fail(MPB_E_NOMEM, "no device memory for the sub-batch of %lld reads the narrow pass handed back (%zu bytes)", (long long)m, bytes);
+        }
         c->fb_cap = cap;
         c->fb_stride = st;
     }
@@ -731,6 +744,7 @@ static int ensure_fallback_block(mpb_ctx *c, int64_t m, int64_t stride, Fallback
     out->q = (uint8_t *)p; p += align_up(c->fb_cap * c->fb_stride, 256);
     out->ee = (double *)p; p += align_up(c->fb_cap * 8, 256);
     out->ns = (int32_t *)p; p += align_up(c->fb_cap * 4, 256);
+    out->len = (int32_t *)p; p += align_up(c->fb_cap * 4, 256);
     out->pass = (uint8_t *)p;
     return MPB_OK;
 }
@@ -764,10 +778,12 @@ static int narrow_rows_from_sample(const int32_t *hist, int n_sample)
     return best;
 }
 
-static bool narrow_eligible(const mpb_ctx *c, int64_t n, const int32_t *d_len, int32_t fixed_len, const mpb_filter_params *p)
+// Fixed-length batches, and (round 6) ragged ones whose rows hold up to MPB_RG_MAX_STRIDE bytes (k_narrow_rg).
+static bool narrow_eligible(const mpb_ctx *c, int64_t n, int64_t row_stride, const int32_t *d_len, int32_t fixed_len, const mpb_filter_params *p)
 {
     const uint32_t forbidden = MPB_FLAG_FAST_FMA | MPB_FLAG_TEST_UNDERPREDICT | MPB_FLAG_DECISION_ONLY | MPB_FLAG_COUNT_CELLS | MPB_FLAG_NO_NARROW;
-    return c->narrow_ok && !d_len && fixed_len >= 1 && n >= 1 && !(p->flags & forbidden) && c->ws.lut == c->d_lut;
+    if (!(c->narrow_ok && n >= 1 && !(p->flags & forbidden) && c->ws.lut == c->d_lut)) return false;
+    return d_len ? row_stride <= MPB_RG_MAX_STRIDE : fixed_len >= 1;
 }
 
 static int filter_device_general(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len,
@@ -783,7 +799,7 @@ static int filter_device_general(mpb_ctx *c, const uint8_t *d_q, int64_t n, int6
 }
 
 // 0: the sorted pipeline; 2..4: the narrow pass with that many rows.  May draw a sample (one small launch + a synchronisation).
-static int narrow_choose(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,
+static int narrow_choose(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len, int32_t fixed_len,
                          const mpb_filter_params *params, const MpbDevParams &prm, int *rows0)
 {
     *rows0 = 0;
@@ -792,63 +808,84 @@ static int narrow_choose(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_
     if (forced) { *rows0 = forced < MPB_NAR_MIN_ROWS ? MPB_NAR_MIN_ROWS : forced > MPB_NAR_MAX_ROWS ? MPB_NAR_MAX_ROWS : forced; return MPB_OK; }
     if (n < MPB_NAR_AUTO_MIN_READS) return MPB_OK;
     auto &ch = c->nar_choice;
+    if (d_len) fixed_len = -1;                                // (a ragged batch of the same shape is another batch)
     const bool same = ch.valid && ch.n == n && ch.stride == row_stride && ch.fixed_len == fixed_len &&
                       memcmp(&ch.alpha, &params->alpha, sizeof(double)) == 0 && ch.flags == params->flags;
     if (same && ch.calls < 64) { ch.calls++; *rows0 = ch.rows0; return MPB_OK; }
     // a sample of <= 0.1 % of the reads: the prepass' row prediction on 256 .. 4096 reads spread over the batch
     int n_sample = (int)(n / 1024 < 256 ? 256 : n / 1024 > 4096 ? 4096 : n / 1024);
-    { Span t(c, MPB_K_SAMPLE); mpb_launch_sample(d_q, n, row_stride, fixed_len, prm, c->ws, n_sample, c->stream); }
+    { Span t(c, MPB_K_SAMPLE); mpb_launch_sample(d_q, n, row_stride, fixed_len, d_len, prm, c->ws, n_sample, c->stream); }
     HIPCHK(hipMemcpyAsync(c->pin_words + 16, c->ws.nar_sample, MPB_NAR_BUCKETS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->last_path.sampled = 1;
-    for (int k = 0; k < MPB_NAR_BUCKETS; k++) c->last_path.sample_hist[k] = c->pin_words[16 + k];
-    *rows0 = narrow_rows_from_sample(c->pin_words + 16, n_sample);
+    int weight = 0;                                           // reads, or (ragged batches) their 16-byte chunks
+    for (int k = 0; k < MPB_NAR_BUCKETS; k++) { c->last_path.sample_hist[k] = c->pin_words[16 + k]; weight += c->pin_words[16 + k]; }
+    *rows0 = narrow_rows_from_sample(c->pin_words + 16, weight);
     ch.valid = true; ch.n = n; ch.stride = row_stride; ch.fixed_len = fixed_len; ch.alpha = params->alpha; ch.flags = params->flags;
     ch.rows0 = *rows0; ch.calls = 0;
     return MPB_OK;
 }
 
-static int filter_device_narrow(mpb_ctx *c, int rows0, const uint8_t *d_q, int64_t n, int64_t row_stride, int32_t fixed_len,
-                                const mpb_filter_params *params, const MpbDevParams &prm,
+static int filter_device_narrow(mpb_ctx *c, int rows0, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len,
+                                int32_t fixed_len, const mpb_filter_params *params, const MpbDevParams &prm,
                                 double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
 {
     int rc;
     hipStream_t s = c->stream;
     if ((rc = ensure_narrow_workspace(c, n))) return rc;
     // persistent grid: as many workgroups as fit the CUs' LDS at once
-    const int per_cu = (160 * 1024) / (mpb_narrow_rs_reads_per_lane(row_stride, rows0) ? mpb_narrow_rs_lds_bytes() : mpb_narrow_lds_bytes());
+    const int lds = d_len ? mpb_narrow_rs_lds_bytes()
+                          : (mpb_narrow_rs_reads_per_lane(row_stride, rows0) ? mpb_narrow_rs_lds_bytes() : mpb_narrow_lds_bytes());
+    const int per_cu = (160 * 1024) / lds;
     const int grid = (c->n_cu > 0 ? c->n_cu : 256) * (per_cu > 0 ? per_cu : 1);
     { Span t(c, MPB_K_NARROW);
-      mpb_launch_narrow(rows0, d_q, n, row_stride, fixed_len, prm, c->ws, d_ee, d_ns, d_pass, c->ws.nar_list, grid, s); }
+      if (d_len) mpb_launch_narrow_ragged(rows0, d_q, n, row_stride, d_len, prm, c->ws, d_ee, d_ns, d_pass, c->ws.nar_list, grid, s);
+      else mpb_launch_narrow(rows0, d_q, n, row_stride, fixed_len, prm, c->ws, d_ee, d_ns, d_pass, c->ws.nar_list, grid, s); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->pin_words, c->ws.nar_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const int64_t m = c->pin_words[0];
     c->last_path.narrow_rows = rows0;
     c->last_path.n_fallback = m;
+    const bool forced = ((params->flags >> 8) & 15u) != 0;
+    // a pass that hands back far more than its sample can have promised: look again next time
+    if (!forced && m > n / 4) c->nar_choice.valid = false;
     int64_t novf = 0;
     if (m > 0) {
+        // The reads handed back go through the sorted pipeline as a dense sub-batch of their own.  When that sub-batch would be a
+        // large part of the batch (a stale choice met a batch of bad reads: ADVICE r5), or there is no memory for it, the WHOLE
+        // batch takes the sorted pipeline in place instead: the same results, the finished reads are simply computed again.
         FallbackBlock fb;
-        if ((rc = ensure_fallback_block(c, m, row_stride, &fb))) return rc;
-        { Span t(c, MPB_K_FALLBACK); mpb_launch_gather_rows(d_q, row_stride, c->ws.nar_list, m, fb.q, s); }
+        const bool in_place = (!forced && m > n / 4) || ensure_fallback_block(c, m, row_stride, &fb) != MPB_OK;
+        if (in_place) {
+            c->last_path.n_fallback = n;
+            return filter_device_general(c, d_q, n, row_stride, d_len, fixed_len, prm.max_len, params, d_ee, d_ns, d_pass, counts);
+        }
+        { Span t(c, MPB_K_FALLBACK); mpb_launch_gather_rows(d_q, row_stride, d_len, c->ws.nar_list, m, fb.q, d_len ? fb.len : nullptr, s); }
         mpb_filter_params sub = *params;
         sub.flags = (sub.flags & ~(15u << 8)) | MPB_FLAG_NO_NARROW;
         mpb_filter_counts sc;
         // the sub-batch's counts are only fetched (a synchronisation) when the caller wants counts
-        if ((rc = filter_device_general(c, fb.q, m, row_stride, nullptr, fixed_len, fixed_len, &sub, fb.ee, fb.ns, fb.pass, counts ? &sc : nullptr))) return rc;
+        if ((rc = filter_device_general(c, fb.q, m, row_stride, d_len ? fb.len : nullptr, fixed_len, prm.max_len, &sub, fb.ee, fb.ns, fb.pass, counts ? &sc : nullptr))) return rc;
         if (counts) novf = sc.n_overflow;
         { Span t(c, MPB_K_FALLBACK); mpb_launch_scatter_back(c->ws.nar_list, m, fb.ee, fb.ns, fb.pass, d_ee, d_ns, d_pass, s); }
         HIPCHK(hipGetLastError());
     }
-    // a pass that hands back far more than its sample can have promised: look again next time
-    if (!((params->flags >> 8) & 15u) && m > n / 4) c->nar_choice.valid = false;
     if (counts) {
         if ((rc = ensure_workspace(c, 1))) return rc;
         HIPCHK(hipMemsetAsync(c->ws.pass_count, 0, sizeof(unsigned long long), s));
         mpb_launch_count(d_pass, n, c->ws, s);
         unsigned long long np = 0;
+        int32_t bad = 0;
         HIPCHK(hipMemcpyAsync(&np, c->ws.pass_count, sizeof(np), hipMemcpyDeviceToHost, s));
+        if (d_len) HIPCHK(hipMemcpyAsync(&bad, c->ws.bad_len, sizeof(bad), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (bad) {
+            // raised by an earlier call that fetched no counts (include/moira_pb.h: "the next call that fetches counts fails")
+            HIPCHK(hipMemsetAsync(c->ws.bad_len, 0, sizeof(int32_t), s));
+            return fail(MPB_E_INVALID, "%d read length(s) in d_len outside 0..%d (row_stride %lld; reads longer than %d bases "
+                        "are not supported); those reads were given ee = NaN, pass = 0", bad, prm.max_len, (long long)row_stride, MPB_MAX_LEN);
+        }
         counts->n_pass = (int64_t)np;
         counts->n_fail = n - (int64_t)np;
         counts->n_overflow = novf;
@@ -870,11 +907,11 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     c->classified.valid = false;                     // the workspace now describes THIS batch
     c->last_path = mpb_path_info{};
     if ((rc = ensure_workspace(c, 1))) return rc;    // the small block (tables, counters) exists from here on
-    if (narrow_eligible(c, n, d_len, fixed_len, params)) {
+    if (narrow_eligible(c, n, row_stride, d_len, fixed_len, params)) {
         const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
         int rows0 = 0;
-        if ((rc = narrow_choose(c, d_q, n, row_stride, fixed_len, params, prm, &rows0))) return rc;
-        if (rows0) return filter_device_narrow(c, rows0, d_q, n, row_stride, fixed_len, params, prm, d_ee, d_ns, d_pass, counts);
+        if ((rc = narrow_choose(c, d_q, n, row_stride, d_len, fixed_len, params, prm, &rows0))) return rc;
+        if (rows0) return filter_device_narrow(c, rows0, d_q, n, row_stride, d_len, fixed_len, params, prm, d_ee, d_ns, d_pass, counts);
     }
     return filter_device_general(c, d_q, n, row_stride, d_len, fixed_len, max_len, params, d_ee, d_ns, d_pass, counts);
 }

@@ -119,6 +119,11 @@ struct MpbWorkspace {
     int32_t  *nar_list;    // [n + 64] ... compacted: the dense list the sub-batch is gathered by
     int32_t  *nar_wave_count, *nar_wave_off;   // [MPB_NAR_MAX_WAVES] entries of each wave's segment / where it goes in nar_list
     int32_t  *nar_sample;  // [MPB_NAR_BUCKETS] histogram of the batch sample that picks the pass (k_sample)
+    // the narrow pass of RAGGED batches (k_narrow_rg, round 6)
+    int2     *rg_ord;      // [n + 64] {read, length} in the order the pass walks them: windows of 4096 reads sorted by length
+    int32_t  *rg_gpre;     // [n / 64 + 2] cost of each group of 64 entries (from its longest read), summed up inside its window
+    unsigned long long *rg_wsum, *rg_wpre;   // [n / 4096 + 2] cost of each window; exclusive prefix ([nwin] = the total)
+    int32_t  *rg_gstart;   // [MPB_NAR_MAX_WAVES + 1] first group of each wave of the persistent grid (written by the pass itself)
 };
 
 // ---- natural-order narrow pass (round 5) -------------------------------------------------------
@@ -207,10 +212,17 @@ int mpb_narrow_lds_bytes();               // static LDS of one k_narrow workgrou
 int mpb_narrow_rs_reads_per_lane(int64_t stride, int rows0);   // k_narrow_rs (whole-line panels staged in registers): reads per lane, 0 = k_narrow
 int mpb_narrow_rs_lds_bytes();
 // predicted row budgets of `n_sample` reads spread over the batch -> ws.nar_sample (zeroed here)
-void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
+void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const int32_t *len, const MpbDevParams &prm,
                        const MpbWorkspace &ws, int n_sample, hipStream_t s);
-// rows list[0..m) of q -> the dense matrix q2 (m rows of `stride` bytes), and results back: ee[list[k]] = ee2[k] ...
-void mpb_launch_gather_rows(const uint8_t *q, int64_t stride, const int32_t *list, int64_t m, uint8_t *q2, hipStream_t s);
+// the narrow pass of a RAGGED batch (k_rag_sort, k_rag_plan, k_narrow_rg): rows of up to MPB_RG_MAX_STRIDE bytes
+#define MPB_RG_MAX_STRIDE 4096
+void mpb_launch_narrow_ragged(int rows0, const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
+                              const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks,
+                              hipStream_t s);
+// rows list[0..m) of q -> the dense matrix q2 (m rows of `stride` bytes; their lengths -> len2 when len != nullptr), and
+// results back: ee[list[k]] = ee2[k] ...
+void mpb_launch_gather_rows(const uint8_t *q, int64_t stride, const int32_t *len, const int32_t *list, int64_t m, uint8_t *q2,
+                            int32_t *len2, hipStream_t s);
 void mpb_launch_scatter_back(const int32_t *list, int64_t m, const double *ee2, const int32_t *ns2, const uint8_t *pass2,
                              double *ee, int32_t *ns, uint8_t *pass, hipStream_t s);
 void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, int32_t min_len,

@@ -2337,6 +2337,351 @@ __global__ __launch_bounds__(256) void k_narrow_rs(const uint8_t *__restrict__ q
     if (lane == 0) wave_count[gw] = nlist;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_narrow_rg<R>: the narrow pass for RAGGED batches (round 6: one padded matrix + int32 len[], e.g. the contigs the
+// reference's paired mode produces, moira/moira.py:789-801,1376-1558).
+//
+// A wave's 64 lanes run in lock step, so a wave is as slow as its longest read; and a padded row is mostly padding, so the
+// matrix must not be read as it lies (a stride-640 matrix of U{50..600} reads is 1.9 x its bases).  Both go away when a wave
+// takes 64 reads of (nearly) ONE length and fetches only the lines their bases lie in:
+//   k_rag_sort   windows of MPB_RG_WIN consecutive reads are counting-sorted by ceil(len / 16) (stable, in LDS, one workgroup
+//                per window: 8 bytes per read in, 8 out); 64 consecutive entries of the sorted order are a GROUP, whose cost is
+//                its longest read's 16-byte chunks.  A window is small enough that a group's rows lie within 4096 rows of
+//                each other, large enough that a group straddles a length boundary about as often as not (<= 1 chunk wasted);
+//   k_rag_scan   prefix sums of the windows' costs (one small block); the list of groups is cut into one contiguous range per
+//                wave of the persistent grid, equal in cost -- each wave finds its own borders (rg_first_group; deterministic);
+//   k_narrow_rg  a wave walks its groups.  Memory path as k_narrow_rs: eight lanes fetch one 128-byte piece of one row per
+//                instruction (per-lane row offsets from a wave-uniform window base: the rows of a group are a gather), eight
+//                instructions = one panel of the 64 rows, staged in registers one panel ahead -- across group borders: the next
+//                group's order entries are fetched two groups ahead -- written to the wave's private XOR-swizzled tile and read
+//                back a row per lane.  Only chunks below the group's longest read are requested.  Arithmetic: the same
+//                straight-line runs per 64-byte half (nar_run); chunks that are complete in every lane take them unmasked, the
+//                one or two last chunks are masked per lane to the identity step (zero bytes) by the lane's own length.
+//                Epilogue per group, with the lane's own length in the predicate (moira.py:949-950).  Reads the pass cannot finish
+//                (more rows, a lower-case 'n', a length outside 0..max_len: left to the sorted pipeline's checks) are listed
+//                in the wave's own segment (64 slots per group it owns).
+// Rows of a multiple of 128 bytes are fetched in whole lines; other strides work (a line shared by two rows is fetched twice).
+// ------------------------------------------------------------------------------------------
+#define MPB_RG_WIN 4096                     // reads per sort window (64 groups)
+#define MPB_RG_BINS 64                      // sort keys per window: ceil(len / 16) >> key_shift
+#define MPB_RG_PAD(e) ((e) + 2 * ((e) >> 6))  // counter (bin, thread) -> 16-bit LDS slot: one pad dword per 64, so that the threads' runs of 64 are conflict-free
+
+// cost of a group = its chunks + a panel's fixed work per 8 chunks + the epilogue (in chunk units; it balances, nothing else)
+__device__ __forceinline__ int rg_group_cost(int chunks) { return chunks + ((chunks + 7) >> 3) + 2; }
+
+__global__ __launch_bounds__(256) void k_rag_sort(const int32_t *__restrict__ len, int64_t n, int32_t max_len, int key_shift,
+                                                  int2 *__restrict__ ord, int32_t *__restrict__ gpre,
+                                                  unsigned long long *__restrict__ wsum)
+{
+    __shared__ uint16_t s_cnt[MPB_RG_BINS * 256 + 2 * 256];
+    __shared__ uint16_t s_ord[MPB_RG_WIN];
+    __shared__ int32_t s_len[MPB_RG_WIN];
+    __shared__ uint32_t s_part[256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * MPB_RG_WIN;
+    const int m = (int)min((int64_t)MPB_RG_WIN, n - w0);
+#pragma unroll
+    for (int k = 0; k < MPB_RG_BINS; k++) s_cnt[MPB_RG_PAD(k * 256 + tid)] = 0;
+    // thread t owns reads 16 t .. 16 t + 15 of the window (consecutive: the order inside a key is the order in memory)
+    int lv[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i = 16 * tid + r;
+        lv[r] = i < m ? len[w0 + i] : -2;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const bool bad = lv[r] < 0 || lv[r] > max_len;          // (a length outside the row: key 0, marked -1; -2: past the batch)
+        const int bin = bad ? 0 : ((lv[r] + 15) >> 4) >> key_shift;
+        if (lv[r] != -2) s_cnt[MPB_RG_PAD(bin * 256 + tid)]++;  // the thread's own column: no atomics
+    }
+    __syncthreads();
+    // exclusive scan over (bin, thread): thread t takes counters 64 t .. 64 t + 63
+    uint32_t sum = 0;
+    for (int e = 0; e < 64; e++) sum += s_cnt[66 * tid + e];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t x = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += x;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (int e = 0; e < 64; e++) {
+        const uint32_t c = s_cnt[66 * tid + e];
+        s_cnt[66 * tid + e] = (uint16_t)run;
+        run += c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (lv[r] == -2) continue;
+        const bool bad = lv[r] < 0 || lv[r] > max_len;
+        const int bin = bad ? 0 : ((lv[r] + 15) >> 4) >> key_shift;
+        const uint32_t pos = s_cnt[MPB_RG_PAD(bin * 256 + tid)]++;
+        s_ord[pos] = (uint16_t)(16 * tid + r);
+        s_len[pos] = bad ? -1 : lv[r];
+    }
+    __syncthreads();
+    for (int p = tid; p < m; p += 256) ord[w0 + p] = make_int2((int)(w0 + s_ord[p]), s_len[p]);
+    // a group's cost comes from the 16-byte chunks of its longest read; gpre[g] = cost of the window's groups up to and with g
+    // (one wave: lane = group), wsum[window] = the window's total
+    if (w == 0) {
+        int c = 0;
+        if (lane * 64 < m) {
+            int mx = 0;
+            for (int t = 0; t < 64; t++) {
+                const int k = lane * 64 + ((t + lane) & 63);      // (rotated by the lane: no bank conflict)
+                if (k < m) mx = max(mx, s_len[k]);
+            }
+            c = rg_group_cost((mx + 15) >> 4);
+        }
+        int pre = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int x = __shfl_up(pre, off);
+            if (lane >= off) pre += x;
+        }
+        if (lane * 64 < m) gpre[(w0 >> 6) + lane] = pre;
+        if (lane == 63) wsum[blockIdx.x] = (unsigned long long)pre;
+    }
+}
+
+// exclusive prefix of the windows' costs (one block): wpre[0 .. nwin], wpre[nwin] = the batch's total
+__global__ __launch_bounds__(1024) void k_rag_scan(const unsigned long long *__restrict__ wsum, int nwin,
+                                                   unsigned long long *__restrict__ wpre)
+{
+    __shared__ unsigned long long s_sum[1024];
+    const int tid = threadIdx.x;
+    const int per = (nwin + 1023) / 1024;
+    const int a = min(nwin, tid * per), b = min(nwin, a + per);
+    unsigned long long sum = 0;
+    for (int k = a; k < b; k++) sum += wsum[k];
+    s_sum[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned long long x = tid >= off ? s_sum[tid - off] : 0;
+        __syncthreads();
+        s_sum[tid] += x;
+        __syncthreads();
+    }
+    unsigned long long run = s_sum[tid] - sum;
+    for (int k = a; k < b; k++) { wpre[k] = run; run += wsum[k]; }
+    if (tid == 1023) wpre[nwin] = s_sum[1023];
+}
+
+// The groups are cut into one contiguous range per wave of the persistent grid, equal in cost: wave w of W starts at the first
+// group whose inclusive cost prefix exceeds floor(w T / W).  Every wave finds its own two borders (a 64-ary search over the
+// windows' prefixes, then the 64 groups of one window: three or four dependent loads), so there is no serial plan pass.
+__device__ __forceinline__ int rg_first_group(const unsigned long long *__restrict__ wpre, const int32_t *__restrict__ gpre,
+                                              int nwin, int ngroups, int wv, int nwaves, int lane)
+{
+    if (wv >= nwaves) return ngroups;
+    const unsigned long long T = wpre[nwin];
+    const unsigned long long target = T * (unsigned long long)wv / (unsigned long long)nwaves;   // (T < 2^35, wv < 2^13)
+    int lo = 0, hi = nwin;                                     // wpre[lo] <= target < wpre[hi]
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) >> 6;
+        const int idx = lo + lane * step;
+        const bool ok = idx < hi && wpre[idx] <= target;
+        const int k = __popcll(__ballot(ok)) - 1;              // lanes 0 .. k hold a prefix <= target (lane 0 always does)
+        lo += k * step;
+        hi = min(hi, lo + step);
+    }
+    const unsigned long long rem = target - wpre[lo];
+    const int ng = min(64, ngroups - lo * 64);
+    const bool over = lane < ng && (unsigned long long)gpre[lo * 64 + lane] > rem;
+    const unsigned long long m = __ballot(over);               // never empty: the window's total exceeds rem
+    return lo * 64 + (m ? __builtin_ctzll(m) : ng - 1);
+}
+
+template <int R>
+__global__ __launch_bounds__(256, 4) void k_narrow_rg(const uint8_t *__restrict__ q, int64_t n, int64_t stride,
+                                                   const int2 *__restrict__ ord, const unsigned long long *__restrict__ wpre,
+                                                   const int32_t *__restrict__ gpre, int32_t *__restrict__ gstart,
+                                                   MpbDevParams prm, const double2 *__restrict__ lut_g,
+                                                   double *__restrict__ ee, int32_t *__restrict__ ns, uint8_t *__restrict__ pass,
+                                                   int32_t *__restrict__ seg, int32_t *__restrict__ wave_count)
+{
+    __shared__ nar_entry_t s_p[256];
+    __shared__ __attribute__((aligned(128))) uint8_t s_tile[4][MPB_NRS_TILE];
+    __shared__ uint32_t s_row[4][64];                         // byte offsets of the rows of the group being loaded, from its window's base
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    s_p[tid] = tid == 255 ? make_double2(__builtin_nan(""), __builtin_nan("")) : lut_g[tid];
+    __syncthreads();                                          // the only block barrier
+    const int gw = blockIdx.x * 4 + w;
+    const int ngroups = (int)((n + 63) >> 6), nwin = (int)((n + MPB_RG_WIN - 1) / MPB_RG_WIN), nwaves = (int)gridDim.x * 4;
+    const int g0 = __builtin_amdgcn_readfirstlane(rg_first_group(wpre, gpre, nwin, ngroups, gw, nwaves, lane));
+    const int g1 = __builtin_amdgcn_readfirstlane(rg_first_group(wpre, gpre, nwin, ngroups, gw + 1, nwaves, lane));
+    if (lane == 0) gstart[gw] = g0;                           // (where the wave's list segment starts: k_nar_compact_rg)
+    if (g0 >= g1) {
+        if (lane == 0) wave_count[gw] = 0;
+        return;
+    }
+    int32_t *const my_seg = seg + 64 * (int64_t)g0;
+    int nlist = 0;                                            // wave-uniform
+    uint8_t *const tile = s_tile[w];
+    const int istride = __builtin_amdgcn_readfirstlane((int)stride);
+    // loading: lane (r8, c8) of instruction j holds the 16-byte slot c8 of the panel of stream 8 j + r8; tile layout as k_narrow_rs
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int wr_even = r8 * 128 + ((c8 ^ (r8 >> 1)) << 4), wr_odd = r8 * 128 + ((c8 ^ (4 + (r8 >> 1))) << 4);
+    const int x0 = lane * 128 + (((lane >> 1) & 7) << 4);
+
+    // a group's order entries {read, length}: -1 / -1 past the batch or past the wave's range; length -1: outside 0..max_len
+    auto fetch = [&](const int g, int &idx, int &ln) {
+        const int64_t p = (int64_t)g * 64 + lane;
+        unsigned long long e = ~0ull;                           // {-1, -1}
+        if (g < g1 && p < n) e = gload(reinterpret_cast<const unsigned long long *>(ord) + p);
+        idx = (int)(uint32_t)e; ln = (int)(uint32_t)(e >> 32);
+    };
+    int cur_idx, cur_len, nx_idx, nx_len, nn_idx, nn_len;
+    fetch(g0, cur_idx, cur_len);
+    fetch(g0 + 1, nx_idx, nx_len);
+    fetch(g0 + 2, nn_idx, nn_len);
+
+    // arming a group for loading: per-lane row offsets from the window's base, the group's chunks (longest read) and the
+    // chunks complete in every lane (shortest)
+    uint32_t *const rows = s_row[w];
+    const uint8_t *wbase = q;
+    int ld_maxc = 0, ld_full = 0;
+    auto arm = [&](const int g, const int idx, const int ln) {
+        const int64_t wrow = ((int64_t)g * 64) & ~(int64_t)(MPB_RG_WIN - 1);          // first row of the group's window
+        wbase = q + wrow * stride;
+        const bool good = idx >= 0 && ln >= 0;
+        const int rowoff = idx >= 0 ? (int)(idx - wrow) * istride : 0;                // (rows past the batch: the window's first)
+        int mx = good ? (ln + 15) >> 4 : 0, mn = good ? ln >> 4 : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { mx = max(mx, __shfl_xor(mx, off)); mn = min(mn, __shfl_xor(mn, off)); }
+        ld_maxc = __builtin_amdgcn_readfirstlane(mx);
+        ld_full = __builtin_amdgcn_readfirstlane(mn);
+        rows[lane] = (uint32_t)rowoff;                          // (the loads of the group before this one have all been issued)
+    };
+    u32x4 pre[8];
+    auto load_panel = [&](const int pk) {
+        const uint8_t *pb = wbase + pk * 128;                   // wave-uniform
+        uint32_t voff[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) voff[j] = rows[8 * j + r8] + (uint32_t)(c8 * 16);
+        if (8 * pk + c8 < ld_maxc) {                            // (the group's last panel: only the chunks its longest read has)
+#pragma unroll
+            for (int j = 0; j < 8; j++) pre[j] = *(const __attribute__((address_space(1))) u32x4 *)(pb + voff[j]);
+        }
+    };
+    arm(g0, cur_idx, cur_len);
+    int cur_maxc = ld_maxc, cur_full = ld_full;
+    load_panel(0);
+
+    double v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = r == 0 ? 1.0 : 0.0;
+    const double thr = prm.thr;
+    uint32_t nonzero = 0;
+
+    for (int g = g0; g < g1; g++) {
+        const int np = __builtin_amdgcn_readfirstlane(max(1, (cur_maxc + 7) >> 3));      // panels of this group
+        for (int pk = 0; pk < np; pk++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                *reinterpret_cast<u32x4 *>(tile + j * 1024 + ((j & 1) ? wr_odd : wr_even)) = pre[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                int next_pk = pk + 1;
+                const bool next_group = next_pk == np && g + 1 < g1;
+                if (next_group) { arm(g + 1, nx_idx, nx_len); next_pk = 0; }
+                if (next_pk < np || next_group) load_panel(next_pk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int cb = 8 * pk + 4 * h;                   // first chunk of this half
+                const int rem = cur_maxc - cb;                   // chunks of the group's longest read from here on
+                if (rem <= 0) continue;
+                const int fullc = cur_full - cb;                 // ... that are complete in every lane
+                const int nbl = cur_len - 16 * cb;               // this lane's bases from here on (may be <= 0)
+                uint32_t wd[16];
+#define NRG_LOAD(NC)                                                                                         \
+                _Pragma("unroll") for (int c = 0; c < NC; c++) {                                             \
+                    const u32x4 x = *reinterpret_cast<const u32x4 *>(tile + (x0 ^ ((h * 4 + c) << 4)));      \
+                    wd[4 * c] = x.x; wd[4 * c + 1] = x.y; wd[4 * c + 2] = x.z; wd[4 * c + 3] = x.w;           \
+                    if (c >= fullc) {                                                                        \
+                        _Pragma("unroll") for (int d = 0; d < 4; d++)                                        \
+                            wd[4 * c + d] = mask_dword(wd[4 * c + d], nbl - 16 * c - 4 * d);                 \
+                    }                                                                                        \
+                }
+                switch (rem >= 4 ? 4 : rem) {
+                case 4: { NRG_LOAD(4) nar_run<R, 16>(v, nonzero, s_p, wd); break; }
+                case 3: { NRG_LOAD(3) nar_run<R, 12>(v, nonzero, s_p, wd); break; }
+                case 2: { NRG_LOAD(2) nar_run<R, 8>(v, nonzero, s_p, wd); break; }
+                default: { NRG_LOAD(1) nar_run<R, 4>(v, nonzero, s_p, wd); break; }
+                }
+#undef NRG_LOAD
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is overwritten by the next panel
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // ---- the group is done: sequential CDF, interpolation, predicate (as k_narrow / the tile classes' epilogue) ----
+        {
+            const int64_t i = cur_idx;
+            const int li = cur_len;
+            const bool valid = cur_idx >= 0, good = valid && li >= 0;
+            double acc = 0.0, lo = 0.0, hi = 0.0;
+            int js = -1;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const double na = acc + v[r];
+                const bool hit = (js < 0) && (na > thr);
+                lo = hit ? acc : lo;
+                hi = hit ? na : hi;
+                js = hit ? r : js;
+                acc = na;
+            }
+            const bool done = good && js >= 0;
+            if (done) {
+                double e = (double)(js - 1) + ((thr - lo) / (hi - lo));     // ref: bernoullimodule.c:170-178
+                if (e < 0) e = 0;
+                const int nsv = li - (int)nonzero;                           // 'N' bases (a read with an 'n' never gets here)
+                if (prm.ambig_mode == 0) e = e + (double)nsv;                // moira.py:827-828
+                const double limit = (prm.maxerrors == prm.maxerrors) ? prm.maxerrors            // moira.py:925-926
+                                                                      : (double)li * prm.uncert; // moira.py:949-950
+                if (prm.flags & 1u) e = floor(e);                            // moira.py:830-831
+                ee[i] = e;
+                ns[i] = nsv;
+                pass[i] = (uint8_t)((prm.ambig_mode == 2 && nsv > 0) ? 0 : (e <= limit ? 1 : 0));   // moira.py:911
+            }
+            const unsigned long long todo = __ballot(valid && !done);
+            if (todo) {
+                if (valid && !done) my_seg[nlist + __popcll(todo & ((1ull << lane) - 1ull))] = (int32_t)i;
+                nlist += __popcll(todo);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) v[r] = r == 0 ? 1.0 : 0.0;
+            nonzero = 0;
+        }
+        cur_idx = nx_idx; cur_len = nx_len;
+        nx_idx = nn_idx; nx_len = nn_len;
+        cur_maxc = __builtin_amdgcn_readfirstlane(ld_maxc); cur_full = __builtin_amdgcn_readfirstlane(ld_full);
+        fetch(g + 3, nn_idx, nn_len);
+    }
+    if (lane == 0) wave_count[gw] = nlist;
+}
+
+// segment of wave g (64 slots per group it owns, from gstart) -> list[wave_off[g] ...): one block per wave
+__global__ __launch_bounds__(256) void k_nar_compact_rg(const int32_t *__restrict__ seg, const int32_t *__restrict__ wave_count,
+                                                        const int32_t *__restrict__ wave_off, const int32_t *__restrict__ gstart,
+                                                        int32_t *__restrict__ list)
+{
+    const int g = blockIdx.x;
+    const int cnt = wave_count[g];
+    const int32_t *src = seg + 64 * (int64_t)gstart[g];
+    int32_t *dst = list + wave_off[g];
+    for (int k = threadIdx.x; k < cnt; k += 256) dst[k] = src[k];
+}
+
 // exclusive prefix of the waves' list counts (one block); total -> *count
 __global__ __launch_bounds__(1024) void k_nar_offsets(const int32_t *__restrict__ wave_count, int nwaves,
                                                       int32_t *__restrict__ wave_off, int32_t *__restrict__ count)
@@ -2382,8 +2727,9 @@ __global__ __launch_bounds__(256) void k_nar_compact(const int32_t *__restrict__
 // A read that needs more than 4 rows is binned by the prepass' prediction (it only feeds the cost estimate of the sorted
 // pipeline).  fp32 throughout: the sample steers speed, never a result.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, int64_t n, int64_t stride, int32_t li,
-                                                MpbDevParams prm, int n_sample, int32_t *__restrict__ hist)
+__global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, int64_t n, int64_t stride, int32_t fixed_len,
+                                                const int32_t *__restrict__ len, MpbDevParams prm, int n_sample,
+                                                int32_t *__restrict__ hist)
 {
     __shared__ float2 s_tab[256];
     __shared__ float4 s_pow[256];                 // {log(1 - p), r, r^2, r^3}; ambiguous bases: zeros
@@ -2401,6 +2747,11 @@ __global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, i
     if (k >= n_sample) return;
     const int64_t step = n / n_sample;                                     // >= 1 (the host sees to it)
     const int64_t i = min(n - 1, (int64_t)k * step + (int64_t)(mpb_mix64((uint64_t)k) % (uint64_t)step));
+    // ragged batches: the read's own length (one outside its row counts as a read the pass hands back); the histogram is then
+    // weighted by 16-byte chunks, because a long read costs either pass more than a short one
+    const int li_raw = len ? len[i] : fixed_len;
+    const bool bad_len = li_raw < 0 || li_raw > prm.max_len;
+    const int li = bad_len ? 0 : li_raw;
     float mu = 0.f, var = 0.f, k3 = 0.f;
     float lp0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     int ambi = 0, lower = 0;                                               // ambiguous bases in all / lower-case 'n' among them
@@ -2452,7 +2803,8 @@ __global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, i
         else if ((cdf += p0 * e2) > thr) rows = 3;
         else if ((cdf += p0 * e3) > thr) rows = 4;
         rows = max(min(rows, li - ambi + 1), 1);
-        atomicAdd(hist + (lower > 0 ? 0 : min(rows, MPB_NAR_BUCKETS - 1)), 1);      // an 'n' is what the narrow pass hands back
+        atomicAdd(hist + ((lower > 0 || bad_len) ? 0 : min(rows, MPB_NAR_BUCKETS - 1)),      // an 'n' is what the narrow pass hands back
+                  len ? max(1, (li + 15) >> 4) : 1);
     }
 }
 
@@ -2467,6 +2819,13 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint8_t *__restrict__
     const int64_t c = g - k * cpr;
     const int64_t i = list[k];
     *reinterpret_cast<uint4 *>(q2 + k * stride + c * 16) = *reinterpret_cast<const uint4 *>(q + i * stride + c * 16);
+}
+
+__global__ __launch_bounds__(256) void k_gather_len(const int32_t *__restrict__ len, const int32_t *__restrict__ list, int64_t m,
+                                                    int32_t *__restrict__ len2)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < m) len2[k] = len[list[k]];
 }
 
 __global__ __launch_bounds__(256) void k_scatter_back(const int32_t *__restrict__ list, int64_t m,
@@ -2763,17 +3122,65 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
     hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, ws.nar_wave_off, nblk, nwaves, per_blk, list);
 }
 
-void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const MpbDevParams &prm,
+// ragged batches (k_narrow_rg): sort windows by length, cut the groups into one range per wave, walk them
+int mpb_narrow_rg_key_shift(int64_t stride)
+{
+    int ks = 0;                                              // ceil(len / 16) <= stride / 16; the key must stay below MPB_RG_BINS
+    while (((stride >> 4) >> ks) >= MPB_RG_BINS) ks++;
+    return ks;
+}
+
+void mpb_launch_narrow_ragged(int rows0, const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
+                              const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks,
+                              hipStream_t s)
+{
+    const int64_t ngroups = (n + 63) / 64, nwin = (n + MPB_RG_WIN - 1) / MPB_RG_WIN;
+    int64_t blocks = (ngroups + 3) / 4;
+    // persistent, and every wave's range is fixed before the launch: the grid must be resident at once, so it is sized by what
+    // the runtime says fits a CU (registers as well as LDS), never by more than the caller's LDS-only figure
+    static int per_cu[5] = {0, 0, 0, 0, 0};
+    const int ri = rows0 < 2 ? 2 : rows0 > 4 ? 4 : rows0;
+    if (!per_cu[ri]) {
+        int nb = 0;
+        const void *fn = ri == 2 ? (const void *)k_narrow_rg<2> : ri == 3 ? (const void *)k_narrow_rg<3> : (const void *)k_narrow_rg<4>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+        per_cu[ri] = nb;
+    }
+    {
+        int dev = 0, n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if ((int64_t)n_cu * per_cu[ri] < grid_blocks) grid_blocks = n_cu * per_cu[ri];
+    }
+    if (blocks > grid_blocks) blocks = grid_blocks;          // a wave walks a contiguous range of groups
+    if (blocks > MPB_NAR_MAX_WAVES / 4) blocks = MPB_NAR_MAX_WAVES / 4;
+    if (blocks < 1) blocks = 1;
+    const int nwaves = (int)blocks * 4;
+    hipLaunchKernelGGL(k_rag_sort, dim3((unsigned)nwin), dim3(256), 0, s, len, n, prm.max_len, mpb_narrow_rg_key_shift(stride), ws.rg_ord, ws.rg_gpre, ws.rg_wsum);
+    hipLaunchKernelGGL(k_rag_scan, dim3(1), dim3(1024), 0, s, ws.rg_wsum, (int)nwin, ws.rg_wpre);
+#define MPB_NRG_LAUNCH(RR) hipLaunchKernelGGL((k_narrow_rg<RR>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, ws.rg_ord, ws.rg_wpre, ws.rg_gpre, ws.rg_gstart, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
+    switch (rows0) {
+    case 2: MPB_NRG_LAUNCH(2); break;
+    case 3: MPB_NRG_LAUNCH(3); break;
+    default: MPB_NRG_LAUNCH(4); break;
+    }
+#undef MPB_NRG_LAUNCH
+    hipLaunchKernelGGL(k_nar_offsets, dim3(1), dim3(1024), 0, s, ws.nar_wave_count, nwaves, ws.nar_wave_off, ws.nar_count);
+    hipLaunchKernelGGL(k_nar_compact_rg, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, ws.nar_wave_off, ws.rg_gstart, list);
+}
+
+void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const int32_t *len, const MpbDevParams &prm,
                        const MpbWorkspace &ws, int n_sample, hipStream_t s)
 {
     (void)hipMemsetAsync(ws.nar_sample, 0, MPB_NAR_BUCKETS * sizeof(int32_t), s);
-    hipLaunchKernelGGL(k_sample, dim3((unsigned)((n_sample + 3) / 4)), dim3(256), 0, s, q, n, stride, fixed_len, prm, n_sample, ws.nar_sample);
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)((n_sample + 3) / 4)), dim3(256), 0, s, q, n, stride, fixed_len, len, prm, n_sample, ws.nar_sample);
 }
 
-void mpb_launch_gather_rows(const uint8_t *q, int64_t stride, const int32_t *list, int64_t m, uint8_t *q2, hipStream_t s)
+void mpb_launch_gather_rows(const uint8_t *q, int64_t stride, const int32_t *len, const int32_t *list, int64_t m, uint8_t *q2,
+                            int32_t *len2, hipStream_t s)
 {
     const int64_t chunks = m * (stride / 16);
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, q, stride, list, m, q2);
+    if (len) hipLaunchKernelGGL(k_gather_len, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, len, list, m, len2);
 }
 
 void mpb_launch_scatter_back(const int32_t *list, int64_t m, const double *ee2, const int32_t *ns2, const uint8_t *pass2,
