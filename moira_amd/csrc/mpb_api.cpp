@@ -1013,6 +1013,9 @@ int mpb_last_class_histogram(mpb_ctx *c, int32_t *caps, int64_t *cnts, int32_t m
 {
     CTXCHK(c);
     if (!caps || !cnts || max_classes < 0) return fail(MPB_E_INVALID, "bad arguments");
+    if (c->last_path.narrow_rows != 0)      // (the workspace then describes the handed-back sub-batch, or an earlier batch: ADVICE r5)
+        return fail(MPB_E_INVALID, "the last filter call took the narrow pass (%d rows): there is no class histogram of its batch; "
+                                   "call with MPB_FLAG_NO_NARROW to get one", c->last_path.narrow_rows);
     if (!c->ws.tables) return 0;
     static const MpbClass classes[MPB_NCLS] = MPB_CLASS_TABLE;
     MpbTables h;
@@ -1027,6 +1030,9 @@ int mpb_last_read_budgets(mpb_ctx *c, int32_t *caps_out, int64_t n)
 {
     CTXCHK(c);
     if (!caps_out || n < 0) return fail(MPB_E_INVALID, "bad arguments");
+    if (c->last_path.narrow_rows != 0)
+        return fail(MPB_E_INVALID, "the last filter call took the narrow pass (%d rows): there are no per-read row budgets of its "
+                                   "batch; call with MPB_FLAG_NO_NARROW to get them", c->last_path.narrow_rows);
     if (n > c->ws_cap || !c->ws.cls) return fail(MPB_E_INVALID, "no filter call of at least %lld reads precedes", (long long)n);
     static const MpbClass classes[MPB_NCLS] = MPB_CLASS_TABLE;
     std::vector<uint8_t> cls((size_t)n);

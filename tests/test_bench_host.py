@@ -8,6 +8,7 @@ import subprocess
 import sys
 import time
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -196,3 +197,58 @@ def test_held_clock_is_read_from_the_line_with_the_asterisk():
     assert s.stop() is None                                  # no device path: nothing sampled, nothing raised
     assert bench._decode_rank('{"k":{"dp":3.1},"mhz":[2010,1990,2100]}') == {
         "kernels_ms_per_step": {"dp": 3.1}, "held_clock": {"mean_mhz": 2010, "min_mhz": 1990, "max_mhz": 2100}}
+
+
+def test_the_headline_is_out_before_the_extras_and_survives_a_kill():
+    """bench.py prints the complete headline and flushes BEFORE any extra runs, and the full line again as the last
+    line.  On the CPU rehearsal path (N = 1, stub step, stub extras that sleep): (a) killing the process inside the extras leaves a
+    parseable headline on stdout; (b) left alone, the last line carries `extras` and the first one does not."""
+    import signal
+    env = dict(os.environ, PYTHONUNBUFFERED="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse-on-cpu", "--steps", "3", "--warmup", "1",
+           "--reads", "1000", "--_stub-extras"]
+    p = subprocess.Popen(cmd + ["60"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    try:
+        first = p.stdout.readline()                       # blocks until the headline is flushed; the "extras" then sleep 3 x 60 s
+        assert first.startswith("{"), first
+        head = json.loads(first)
+        assert head["metric"].startswith("reads/sec") and head["value"] > 0 and "extras" not in head
+        assert p.poll() is None                           # still inside the extras
+        p.send_signal(signal.SIGKILL)
+        rest = p.stdout.read()
+        assert rest.strip() == ""                         # nothing else had been printed: the headline is all there is, and it parses
+    finally:
+        if p.poll() is None:
+            p.kill()
+        p.wait(timeout=30)
+    q = subprocess.run(cmd + ["0.05"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert q.returncode == 0, q.stderr[-2000:]
+    lines = [l for l in q.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and "extras" not in json.loads(lines[0])
+    last = json.loads(lines[-1])
+    assert sorted(last["extras"]) == ["stub_0", "stub_1", "stub_2"]
+    assert {k: v for k, v in last.items() if k != "extras"} == json.loads(lines[0])
+
+
+def test_bench_py_stays_small_and_the_extras_live_in_tools():
+    n = len(open(os.path.join(ROOT, "bench.py")).read().splitlines())
+    assert n < 600, n
+    bench = load_bench()
+    assert callable(bench.config3_paired_rate) and callable(bench.real_profile_batches)      # forwarded to tools/bench_extras.py
+    with pytest.raises(AttributeError):
+        bench.no_such_extra
+
+
+def test_masked_share_reproduces_a_hand_made_tiling():
+    """tools/bench_extras.masked_share: reads of one class are ordered by length bin (stable) and cut into tiles of 64 / G; a tile
+    runs as long as its longest read."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_extras as X
+    caps = np.array([2] * 65 + [160] * 5)                 # G = 1: tiles of 64 reads; G = 16: tiles of 4
+    lens = np.array([100] * 64 + [10] + [300, 280, 290, 310, 100])
+    budget, issued, per_class = X.masked_share(caps, lens)
+    assert budget == 2 * (6400 + 10) + 160 * 1280
+    # class 2: one full tile of length-100 reads (bin 1) -- but the length-10 read (bin 0) sorts FIRST: tiles [10, 100 x 63], [100]
+    # class 160: bins 100 -> 1, 280..310 -> 4: order [100, 300, 280, 290 | 310]: tiles of 4
+    assert issued == 2 * 64 * (100 + 100) + 160 * 4 * (300 + 310)
+    assert abs(per_class[2] - (1 - 2 * 6410 / (2 * 64 * 200))) < 1e-12

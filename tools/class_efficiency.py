@@ -22,7 +22,7 @@ with Engine(0) as eng:
     nmax = max(n0, target)
     d_ee, d_ns, d_pass = eng.alloc(nmax * 8), eng.alloc(nmax * 4), eng.alloc(nmax)
     eng.synth_fill(d_q, n0, stride, fixed_len=L, seed=2)
-    eng.filter_device(d_q, n0, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+    eng.filter_device(d_q, n0, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=eng.params(no_narrow=True))
     caps = eng.read_budgets(n0)
     host = d_q.download(np.uint8, n0 * stride).reshape(n0, stride)
     d_b = eng.alloc(target * stride)
@@ -40,12 +40,12 @@ with Engine(0) as eng:
             m += len(uniq)
         if m == 0:
             continue
-        eng.filter_device(d_b, m, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+        eng.filter_device(d_b, m, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=eng.params(no_narrow=True))
         hist = eng.class_histogram()
         assert hist.get(cap, 0) == m, (cap, hist)
         eng.timing(True); eng.timing_reset()
         for _ in range(4):
-            eng.filter_device(d_b, m, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, want_counts=False)
+            eng.filter_device(d_b, m, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, want_counts=False, params=eng.params(no_narrow=True))
         t = eng.kernel_times()["dp"]
         eng.timing(False)
         ms = t[0] / t[1]

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Experiment builds WITHOUT switches in the shipped kernels: a variant is a list of exact text replacements applied
+to a COPY of moira_amd/csrc/mpb_kernels.hip; the copy is written next to the original's includes so that it compiles unchanged.
+
+    python tools/experiments/make_variant.py NAME OUT.hip      # writes the patched source, exits non-zero if a patch does not apply
+    python tools/experiments/make_variant.py --list
+
+Use with tools/experiments/variants.sh:   name:""@/tmp/var/NAME.hip
+Every variant here is a MEASUREMENT device; none of them is bit-exact unless it says so.  Results: profiles/r06_*."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SRC = os.path.join(ROOT, "moira_amd", "csrc", "mpb_kernels.hip")
+
+VARIANTS = {
+    # k_narrow_rg: results written at the SORTED position (64 g + lane) instead of the read's own index: coalesced stores, wrong
+    # placement -- what the scattered 13-byte result stores cost
+    "rg_coalesced_results": [
+        ("            const int64_t i = cur_idx;\n            const int li = cur_len;",
+         "            const int64_t i = cur_idx < 0 ? (int64_t)cur_idx : (int64_t)g * 64 + lane;\n            const int li = cur_len;"),
+    ],
+    # k_narrow_rg: no result stores at all (the list of handed-back reads stays)
+    "rg_no_results": [
+        ("                ee[i] = e;\n                ns[i] = nsv;\n                pass[i] = (uint8_t)((prm.ambig_mode == 2 && nsv > 0) ? 0 : (e <= limit ? 1 : 0));   // moira.py:911\n            }\n            const unsigned long long todo = __ballot(valid && !done);",
+         "                if (e == 1.2345e-300) ee[i] = e;\n            }\n            const unsigned long long todo = __ballot(valid && !done);"),
+    ],
+}
+
+
+def main():
+    if len(sys.argv) == 2 and sys.argv[1] == "--list":
+        for k in VARIANTS:
+            print(k)
+        return 0
+    name, out = sys.argv[1], sys.argv[2]
+    s = open(SRC).read()
+    for old, new in VARIANTS[name]:
+        if s.count(old) != 1:
+            sys.stderr.write("variant %s: a patch applies %d times (must be exactly once):\n%s\n" % (name, s.count(old), old))
+            return 1
+        s = s.replace(old, new)
+    # the copy lives elsewhere: make its relative includes absolute
+    s = s.replace('#include "mpb_internal.h"', '#include "%s"' % os.path.join(ROOT, "moira_amd", "csrc", "mpb_internal.h"))
+    s = s.replace('#include "../../include/mpb_synth.h"', '#include "%s"' % os.path.join(ROOT, "include", "mpb_synth.h"))
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    open(out, "w").write(s)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -49,7 +49,7 @@ def resident(eng, q, lens):
 def main():
     rng = np.random.default_rng(3)
     with Engine(0) as eng:
-        prm = eng.params()
+        prm = eng.params(no_narrow=True)      # (the row-budget histograms below describe the sorted pipeline)
         # a
         n, L = 200_000, 1500
         q = rng.integers(25, 41, (n, 1536), dtype=np.uint8)

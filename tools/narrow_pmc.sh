@@ -2,12 +2,13 @@
 # Run ON THE GPU BOX: rocprofv3 passes over the clean 10 M x 300 batch through the narrow pass (tools/narrow_probe.py):
 # kernel trace + stats, then the counters in passes of their own (never combined with sys / hip / hsa tracing).
 #   tools/narrow_pmc.sh TAG [R]        -> gpurun_out/narrow_pmc_TAG/{trace,fetch,write,sq,lds}/ + summary.txt
-TAG=${1:-r05}; R=${2:-2}
+#   PROBE=tools/ragged_probe.py N=5000000 tools/narrow_pmc.sh TAG 3      the same passes over a ragged batch (k_narrow_rg)
+TAG=${1:-r05}; R=${2:-2}; PROBE=${PROBE:-tools/narrow_probe.py}; N=${N:-10000000}
 export TMPDIR=/tmp
 D=$PWD/gpurun_out/narrow_pmc_$TAG
 mkdir -p $D
-rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 tools/narrow_probe.py $R > $D/trace.log 2>&1 || exit 1
-pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $D/$name -- python3 tools/narrow_probe.py $R 10000000 > $D/$name.log 2>&1 || exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $PROBE $R $N > $D/trace.log 2>&1 || exit 1
+pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $D/$name -- python3 $PROBE $R $N > $D/$name.log 2>&1 || exit 1; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass tccrd TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
