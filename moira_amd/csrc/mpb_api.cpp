@@ -1059,23 +1059,15 @@ static int ensure_stage(mpb_ctx *c, int64_t bytes)
 // Batches of at most MPB_SMALL_N reads (the two paths cost the same at about 8 k reads): one host-to-device copy from pinned memory, one kernel (one read
 // per wave), one copy back -- the batched pipeline's eight launches and six copies cost ~150 us whatever
 // the size, which is all a per-read caller (bernoulli.calculate_errors_PB) would ever see.
-#ifndef MPB_SMALL_N
 #define MPB_SMALL_N 4096
-#endif
 // small batches whose inputs are at most this many bytes are read by the kernel straight from pinned host memory
 // ... and batches of at most this many reads report their completion through a word per read in pinned memory
-#ifndef MPB_SMALL_FLAG_N
 #define MPB_SMALL_FLAG_N 256
-#endif
-#ifndef MPB_SMALL_ZC_BYTES
 #define MPB_SMALL_ZC_BYTES (1 << 20)
-#endif
 // qualities per chunk of the host pipeline: large enough that a chunk's launch sequence (~0.2 ms fixed) is
 // noise beside its 2 ms of PCIe time; the four slots then hold 4 x (128 MiB of qualities + 5.5 MiB of results) of device
 // memory, the same again of pinned staging when the input is pageable, and 4 x 5.5 MiB of pinned results
-#ifndef MPB_HOST_CHUNK_BYTES
 #define MPB_HOST_CHUNK_BYTES (128ll << 20)
-#endif
 
 // Wait until done[0..n) all hold `token` (k_small writes it once a read's results are visible to the host).  The kernel
 // normally takes tens of microseconds: spin; a launch that has not finished after 20 ms is asked about through the runtime
@@ -1128,11 +1120,7 @@ static int filter_host_small(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t ro
     uint8_t *d_pass = (uint8_t *)(d + in_bytes + b_ee + b_ns);
     const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
     char *ho = h + in_bytes;
-#ifdef MPB_TUNING_KNOBS          // experiment builds only
-    static const int64_t zc_bytes = getenv("MPB_SMALL_ZC_BYTES") ? atoll(getenv("MPB_SMALL_ZC_BYTES")) : MPB_SMALL_ZC_BYTES;
-#else
     constexpr int64_t zc_bytes = MPB_SMALL_ZC_BYTES;
-#endif
     if (in_bytes <= zc_bytes) {
         // a handful of reads (the per-read entry: ONE): the kernel reads the rows from, and writes the results to, the pinned
         // host block -- one runtime call instead of three dependent ones (copy in, kernel, copy out) -- and the host learns
@@ -1291,6 +1279,11 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
     int rc = ensure_workspace(c, chunk);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < nslots; k++) {                       // a slot that must grow frees memory: the resident one-read kernel leaves first
+        const HostSlot &sl = c->slot[k];
+        if (L.in_bytes + L.out_bytes > sl.dev_cap || L.out_bytes > sl.pin_out_cap ||
+            (!(q_pinned && (!len || len_pinned)) && L.in_bytes > sl.pin_in_cap)) { serve_quiesce(c); break; }
+    }
     for (int k = 0; k < nslots; k++) {
         HostSlot &sl = c->slot[k];
         sl.off = -1;

@@ -675,7 +675,18 @@ int mpb_broker_serve(mpb_ctx *ctx, const char *name, int32_t n_slots, int32_t id
     const bool retire_thread = getenv("MPB_BROKER_RETIRE_THREAD") && atoi(getenv("MPB_BROKER_RETIRE_THREAD")) != 0;
     rc = b.init_lanes();
     const bool want_server = !(getenv("MPB_BROKER_SERVER") && atoi(getenv("MPB_BROKER_SERVER")) == 0) && b.zero_copy;
-    if (rc == MPB_OK && want_server) rc = b.init_server();
+    if (rc == MPB_OK && want_server) {
+        // The context's one-read workspaces are sized BEFORE the resident server is first launched: a workspace that
+        // grows later frees memory, the runtime then waits for the whole device, and the broker's own server is a kernel the
+        // context's quiesce cannot see -- the broker thread would stall for the rest of that kernel's lifetime (<= 100 ms).
+        // One read of the longest row the server takes through the path run_solo uses covers the reads it hands back; only a read
+        // of more than 16384 bases (the chunked host pipeline) can still grow something, once.
+        std::vector<uint8_t> row(MPB_SERVE_STRIDE, 30);
+        double ee = 0;
+        int32_t ns = 0;
+        (void)mpbi_run_packed_read(ctx, row.data(), MPB_SERVE_STRIDE - 1, MPB_SERVE_STRIDE, nullptr, 0.005, &ee, &ns);
+        rc = b.init_server();
+    }
     if (rc == MPB_OK) {
         std::atomic_thread_fence(std::memory_order_seq_cst);
         h->direct.store(b.srv.enabled && b.srv.direct ? 1 : 0);

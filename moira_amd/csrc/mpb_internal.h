@@ -50,9 +50,7 @@ struct MpbClass { int cap, G, R; };
 
 // reads handled by one prepass / scatter block: MPB_PRE_ROUNDS rounds of 256 (one thread per read in
 // the ranking step).  More reads per block = shorter histograms to scan.
-#ifndef MPB_PRE_ROUNDS
 #define MPB_PRE_ROUNDS 4
-#endif
 #define MPB_PRE_READS (256 * MPB_PRE_ROUNDS)
 // class byte of a read the prepass already settled (MPB_FLAG_DECISION_ONLY): never scattered, never run
 #define MPB_CLS_SETTLED 0x7f
@@ -62,9 +60,7 @@ struct MpbClass { int cap, G, R; };
 // Sort key of a read = (class, length bin of 2^len_shift bases): perm[] is grouped by class and, inside a class,
 // by length, because a DP tile runs as long as its longest read.  Batches with one fixed length use a
 // single bin.  16 bins: 64 bases wide for rows of up to 1024 bases, wider (MpbDevParams.len_shift) for longer rows.
-#ifndef MPB_LEN_SHIFT
 #define MPB_LEN_SHIFT 6               // narrowest bin width: 2^6 bases
-#endif
 #define MPB_LEN_BINS (1024 >> MPB_LEN_SHIFT)
 #define MPB_SKEYS (MPB_NCLS * MPB_LEN_BINS)
 

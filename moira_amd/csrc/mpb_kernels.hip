@@ -130,9 +130,7 @@ __device__ __forceinline__ uint32_t fill_dword(uint32_t w, int nvalid_bytes)
     return (w & m) | (0xFEFEFEFEu & ~m);
 }
 
-#ifndef MPB_PRE_NB
 #define MPB_PRE_NB 5              // column quads (4 x 16 bytes of a row) loaded ahead
-#endif
 #define MPB_MARK_UPPER 128.0f     // second LUT component of 'N'
 #define MPB_MARK_LOWER 65536.0f   // ... of 'n' (> 256 * 128)
 
@@ -146,9 +144,7 @@ __device__ __forceinline__ void pre_chunk(const float2 *tab, const uint4 x, f32x
         for (int t = 0; t < 4; t++) {
             const float2 e = tab[(ww[d] >> (8 * t)) & 0xffu];
             a01 += (f32x2){e.x, e.y};
-#ifndef MPB_PREPASS_NO_K3                                 // experiment (profiles/r04_prepass_variants.txt): 2 instead of 3 VALU per byte
-            s3 = __builtin_fmaf(e.x, e.y, s3);            // p == 0 for marked bytes
-#endif
+            s3 = __builtin_fmaf(e.x, e.y, s3);            // p == 0 for marked bytes (a kappa3-free prepass, 2 VALU per byte, was no faster: profiles/r04_prepass_variants.txt)
         }
 }
 
@@ -367,11 +363,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
         const float pvar = rem - MPB_MARK_UPPER * nzero;
         mu += a01.x;
         var += pvar;
-#ifdef MPB_PREPASS_NO_K3
-        k3 += pvar;                                                       // kappa3 := sigma^2: conservative (never under-predicts)
-#else
         k3 += pvar - 2.0f * s3;                                           // sum p(1-p)(1-2p)
-#endif
         ambi += (uint32_t)nzero + ((uint32_t)n255 << 16);
         };  // panel
         if (LONG) { for (int pb = 0; pb < ncol; pb += 12 * MPB_PRE_NB) panel(pb, min(ncol, pb + 12 * MPB_PRE_NB)); }
@@ -413,9 +405,7 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
 // rows of the tile are then summed from LDS in a fixed order (deterministic) by a few lanes each and classified.
 // Block b still owns reads [1024 b, 1024 b + 1024): the histograms keep the layout k_scan / k_scatter expect.
 // ------------------------------------------------------------------------------------------
-#ifndef MPB_LIN_K
 #define MPB_LIN_K 5                               // chunks per thread and tile, all loaded before the first is used
-#endif
 #define MPB_LIN_CHUNKS (256 * MPB_LIN_K)
 
 template <bool RAGGED, bool DECODE>
@@ -758,9 +748,7 @@ __device__ __forceinline__ void dp_chunk(double (&v)[R], const uint4 x, int keep
 }
 
 // Register budget of the DP kernel: 4 waves per SIMD = at most 128 VGPRs per lane.
-#ifndef MPB_DP_WAVES_PER_EU
 #define MPB_DP_WAVES_PER_EU 4
-#endif
 
 struct DpArgs {
     const uint8_t *q;
@@ -1475,6 +1463,7 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox 
                 const unsigned long long p_lo = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const unsigned long long p_hi = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 static_assert(sizeof(MpbServePrm) == 64, "one 64-byte line per request");
+                bool bad_request = false;                            // wave-uniform
                 auto get_prm = [&] {
                     const uint32_t xs[4] = {(uint32_t)p_lo, (uint32_t)(p_lo >> 32), (uint32_t)p_hi, (uint32_t)(p_hi >> 32)};
                     uint32_t pw[16];
@@ -1482,6 +1471,16 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox 
                     for (int k = 0; k < 16; k++) pw[k] = (uint32_t)__builtin_amdgcn_readlane((int)xs[k & 3], k >> 2);
                     MpbDevParams prm;
                     __builtin_memcpy(&prm, pw, sizeof(prm));
+                    // In direct serving these 64 bytes are the CLIENT's (a shared-memory slot no broker thread has checked): only
+                    // alpha's threshold and the prediction constants are taken from them; everything a per-read call never sets is
+                    // forced to what mpbi_small_params writes (no opt-in flag, ambiguous bases ignored, no limit), and a threshold
+                    // outside (0, 1) makes the request one the host answers itself through its checked path (pass = 2 below).
+                    prm.flags = 0;
+                    prm.ambig_mode = 1;                             // MPB_AMBIG_IGNORE
+                    prm.uncert = 1.0;
+                    prm.maxerrors = __builtin_nan("");
+                    bad_request = !(prm.thr > 0.0 && prm.thr < 1.0);
+                    if (bad_request) prm.thr = 0.5;
                     prm.fixed_len = li;
                     prm.max_len = (int32_t)box.stride;
                     A.prm = prm;
@@ -1489,7 +1488,11 @@ __global__ __launch_bounds__(256, MPB_DP_WAVES_PER_EU) void k_serve(MpbServeBox 
                     wave_lds_fence();
                     return prm;
                 };
-                const bool light = small_one_read<false, true>(A, &s_args[w], get_prm, li, 0, lane, e_ns, box.cls + e, box.ident + e, e_stage, s_tab);
+                bool light = small_one_read<false, true>(A, &s_args[w], get_prm, li, 0, lane, e_ns, box.cls + e, box.ident + e, e_stage, s_tab);
+                if (bad_request) {                                   // whatever was computed on the stand-in threshold is withdrawn
+                    if (lane == 0) __hip_atomic_store(A.pass, (uint8_t)2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    light = false;
+                }
                 // the results before the word that announces them.  Stores made at system scope go straight out and reach the host
                 // in the order they were issued once the wave has seen them acknowledged; anything else (the class bodies'
                 // plain stores) is written back from the caches first
@@ -1557,9 +1560,7 @@ __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict__ pass,
 // 'N' (byte 0) looks up 0.0 (x + 0.0 == x: the reference skips the base), lower-case 'n' (byte 255) looks up a NaN
 // that poisons the sum and is reported; Ns are counted eight bytes at a time with integer arithmetic.
 // ------------------------------------------------------------------------------------------
-#ifndef MPB_LAM_W
 #define MPB_LAM_W 128                       // 64, 128, 192, 256: measured 128 best
-#endif
 #define MPB_LAM_PITCH (MPB_LAM_W + 16)      // (pitch / 16) odd for every W above
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -1758,12 +1759,11 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *__restrict__ q, int64_t 
 // each) per wave, a slot refilled as soon as its panel is in registers, keeps DEPTH panels in flight across row-block
 // boundaries -- the grid is persistent, a wave walks row blocks gw, gw + W, ... as one continuous stream of panels.
 // Per base: 1 address op + 3R - 2 cell operations + half an instruction of 'N' counting = 5.5 / 8.5 / 11.5 vector instructions
-// for R = 2 / 3 / 4 (with -DMPB_NAR_LUT64, which keeps {p'} alone and recomputes 1 - p, one more; mpb_create checks
-// a == 1 - b for every score either way).
+// for R = 2 / 3 / 4 (a form that keeps {p'} alone and recomputes 1 - p costs one more and was 5-8 % slower:
+// profiles/r05_narrow_variants.txt, git history; mpb_create still checks a == 1 - b for every score).
 // ------------------------------------------------------------------------------------------
-#ifndef MPB_NAR_DEPTH
 #define MPB_NAR_DEPTH 2                     // ring slots per wave: 2 x 4 KiB -> four workgroups (16 waves) per CU; a slot is refilled as
-#endif                                      // soon as its panel is in registers, so two panels per wave are in flight during a step
+                                            // soon as its panel is in registers, so two panels per wave are in flight during a step
 #define MPB_NAR_PANEL 4096                  // 64 rows x 64 bytes
 
 // One LDS-DMA instruction: 16 bytes per lane from `base + voff` (wave-uniform 64-bit base, per-lane 32-bit offset) to LDS at
@@ -1787,19 +1787,13 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p)      // a __shared
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-// The table entry: the {1 - p, p'} pair as the context holds it (one ds_read_b128 per base), or -- -DMPB_NAR_LUT64 -- p' alone
-// with 1 - p recomputed by the IEEE subtraction the host used (half the LDS cycles, one more vector instruction per base).
+// The table entry: the {1 - p, p'} pair as the context holds it (one ds_read_b128 per base).  (p' alone with 1 - p recomputed by
+// the IEEE subtraction the host used -- half the LDS cycles, one more vector instruction per base -- was measured and dropped.)
 // Once the pass counts its 'N' bases itself it is bound by vector issue, not by the stream, and the pair is 5 % faster
 // (profiles/r05_narrow_variants.txt); LDS is 50 % busy with it.
-#ifndef MPB_NAR_LUT64
 typedef double2 nar_entry_t;
 #define NAR_P(e) ((e).y)
 #define NAR_A(e) ((e).x)
-#else
-typedef double nar_entry_t;
-#define NAR_P(e) (e)
-#define NAR_A(e) (1.0 - (e))                  // the table's own 1 - p
-#endif
 
 template <int R>
 __device__ __forceinline__ void nar_step(double (&v)[R], const nar_entry_t e)
@@ -1842,11 +1836,7 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // byte 0 ('N'): the identity step {1, 0} the table holds anyway (counted below); byte 255 ('n'): a NaN -- the read is handed back
-#ifndef MPB_NAR_LUT64
     s_p[tid] = tid == 255 ? make_double2(__builtin_nan(""), __builtin_nan("")) : lut_g[tid];
-#else
-    s_p[tid] = tid == 255 ? __builtin_nan("") : lut_g[tid].y;
-#endif
     __syncthreads();                                          // the only block barrier
     const int64_t nblk = (n + 63) >> 6;                       // row blocks of 64 reads
     const int ncq = (li + 63) >> 6;                           // 64-byte panels per row block (li >= 1)
@@ -1890,9 +1880,6 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     int64_t pf = 0;                           // panels requested so far
     auto request = [&](const uint32_t slot) {
         if (pf < total) {
-#ifdef MPB_NAR_NODMA                           // timing experiment: the arithmetic alone (stale panels after the first)
-            if (pf < D - 1)
-#endif
             issue(pf_b, pf_c, slot);
             pf++;
             if (++pf_c == ncq) { pf_c = 0; pf_b += W; }
@@ -1921,20 +1908,13 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
         // the panel of this step has landed when at most the requests made after it are still out
         const int64_t younger = pf - (s + 1);               // 0 .. D-1 panels (wave-uniform)
         {
-#ifdef MPB_NAR_NODMA
-        nar_wait<0>();
-#endif
         if (younger >= 3) nar_wait<12>();
         else if (younger == 2) nar_wait<8>();
         else if (younger == 1) nar_wait<4>();
         else nar_wait<0>();
         }
         const uint8_t *mine = ring[S] + tl;
-#ifdef MPB_NAR_NOARITH                         // timing experiment: the panel stream alone
-        const int nbases = 0;
-#else
         const int nbases = min(64, li - cur_c * 64);        // wave-uniform
-#endif
         if (nbases == 64) {
             // All four chunks of the panel at once; the table two dwords (eight bases) ahead of the arithmetic; 1 - p one dword
             // ahead; and inside a base the operations in an order that keeps dependent FP64 instructions three issue slots apart
@@ -2122,11 +2102,7 @@ __global__ __launch_bounds__(256) void k_narrow_rs(const uint8_t *__restrict__ q
     __shared__ __attribute__((aligned(128))) uint8_t s_tile[4][MPB_NRS_TILE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifndef MPB_NAR_LUT64
     s_p[tid] = tid == 255 ? make_double2(__builtin_nan(""), __builtin_nan("")) : lut_g[tid];
-#else
-    s_p[tid] = tid == 255 ? __builtin_nan("") : lut_g[tid].y;
-#endif
     __syncthreads();                                          // the only block barrier
     const int64_t rows_sb = 64 * (int64_t)k;                  // reads of a stream block: 64 lanes x k reads each
     const int64_t nsb = (n + rows_sb - 1) / rows_sb;
@@ -2243,18 +2219,11 @@ __global__ __launch_bounds__(256) void k_narrow_rs(const uint8_t *__restrict__ q
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef MPB_NAR_NODMA                           // timing experiment: the arithmetic alone (stale panels after the second)
-        if (t + 1 < total && t < 1) {
-#else
         if (t + 1 < total) {                                    // in flight while this panel is computed on
-#endif
             load_panel(pf_sb, pf_pk);
             if (++pf_pk == NP) { pf_pk = 0; pf_sb += W; }
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifdef MPB_NAR_NOARITH                         // timing experiment: the panel stream alone (loads + tile writes, two tile reads per panel)
-        nonzero += *reinterpret_cast<const uint32_t *>(tile + x0) + *reinterpret_cast<const uint32_t *>(tile + (x0 ^ 64));
-#else
         // ---- the panel's two 64-byte halves, four 16-byte chunks each.  The chunks of a half that belong to ONE read go through
         // one straight-line run (nar_run<R, 4 x chunks>); the bytes of a read's last chunk past its end are made zero first (the
         // identity step), so a 300-base read's last 44 bases take the same code as the others, as 48.  A read may end -- and the
@@ -2325,15 +2294,11 @@ __global__ __launch_bounds__(256) void k_narrow_rs(const uint8_t *__restrict__ q
                 if (u >= istride) { u = 0; sread++; }
             }
         }
-#endif
         if (++cur_pk == NP) { cur_pk = 0; cur_sb += W; sread = 0; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile is overwritten by the next panel
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-#ifdef MPB_NAR_NOARITH
-    if (nonzero == 0x12345678u) ns[gw] = 1;                     // keeps the tile reads alive
-#endif
     if (lane == 0) wave_count[gw] = nlist;
 }
 
@@ -2855,16 +2820,6 @@ void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32
 #define MPB_PRE_LAUNCH(RG, LG)                                                                                          \
     hipLaunchKernelGGL((k_prepass<RG, LG>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist)
     const PreOut o = {ws.cls, ns_out, ee_out, pass_out, ws.bad_len, ws.wide_list, ws.wide_rows, ws.wide_count};
-#ifdef MPB_PREPASS_LINEAR                 // experiment builds: the linear walk for the plain prepass too (measured slower)
-    {
-        const PreDecode dec = {nullptr, nullptr, nullptr, 0, nullptr};
-        const uint32_t cpr = (uint32_t)(stride >> 4);
-        const uint32_t magic = cpr == 1 ? 0u : (uint32_t)(((1ull << 32) + cpr - 1) / cpr);
-        if (len) hipLaunchKernelGGL((k_classify_linear<true, false>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist, dec, magic);
-        else     hipLaunchKernelGGL((k_classify_linear<false, false>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist, dec, magic);
-        return;
-    }
-#endif
     const bool long_rows = prm.max_len > 16 * 12 * MPB_PRE_NB;        // more than one panel of 60 chunk columns
     if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true); else MPB_PRE_LAUNCH(true, false); }
     else     { if (long_rows) MPB_PRE_LAUNCH(false, true); else MPB_PRE_LAUNCH(false, false); }
@@ -2931,15 +2886,10 @@ void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *l
     // (64 reads per tile) plus one partial tile per class.  Classes with G > 1 have more tiles
     // per read; the kernel's tile loop is grid-strided, so they are still covered.
     const int64_t tiles = (n + 63) / 64 + MPB_NCLS;
-#ifdef MPB_TUNING_KNOBS          // experiment builds only (tools/): never in the shipped library
-    static const int chunk_tiles = getenv("MPB_DP_CHUNK") ? atoi(getenv("MPB_DP_CHUNK")) : MPB_DP_CHUNK;
-    static const int grid_cap = getenv("MPB_DP_GRID") ? atoi(getenv("MPB_DP_GRID")) : MPB_DP_GRID;
-#else
     // a small batch (the sub-batch a narrow pass hands back, a short file's last chunk) is latency: fewer tiles per wave so that
     // every SIMD gets one -- 8 tiles per class-body call only pay where there are tens of thousands of tiles
     const int chunk_tiles = tiles >= 32768 ? MPB_DP_CHUNK : tiles >= 16384 ? 4 : tiles >= 8192 ? 2 : 1;
     constexpr int grid_cap = MPB_DP_GRID;
-#endif
     int64_t want = (tiles + 4 * chunk_tiles - 1) / (4 * chunk_tiles);   // blocks if every wave took one chunk
     const int blocks = (int)(want < grid_cap ? (want > 0 ? want : 1) : grid_cap);
     DpArgs A = make_args(q, stride, len, prm, ws, ns, ee, pass, 0);
@@ -3072,8 +3022,7 @@ int mpb_narrow_lds_bytes()
 // instead of 4.2 GB read), 4-5 % slower at R = 3, 4: so only for two rows.
 int mpb_narrow_rs_reads_per_lane(int64_t stride, int rows0)
 {
-    static const bool off = getenv("MPB_NAR_NO_RS") != nullptr;      // A/B runs (tools/): the LDS-DMA form for every stride
-    if (off || stride % 16 != 0 || stride > (1 << 16)) return 0;
+    if (stride % 16 != 0 || stride > (1 << 16)) return 0;
     if (stride % 64 != 0 && rows0 != 2) return 0;
     int k = 1;                                                        // 128 / gcd(stride, 128): 1, 2, 4 or 8
     while ((k * stride) % 128 != 0) k *= 2;
@@ -3092,9 +3041,6 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
     const int per_blk = 64 * (rs_k ? rs_k : 1);              // reads of one row block / stream block
     const int64_t nblk = (n + per_blk - 1) / per_blk;
     int64_t blocks = (nblk + 3) / 4;
-#ifdef MPB_TUNING_KNOBS          // experiment builds only (tools/): never in the shipped library
-    if (getenv("MPB_NAR_GRID")) grid_blocks = atoi(getenv("MPB_NAR_GRID"));
-#endif
     if (blocks > grid_blocks) blocks = grid_blocks;         // persistent: a wave walks row blocks gw, gw + W, ...
     if (blocks > MPB_NAR_MAX_WAVES / 4) blocks = MPB_NAR_MAX_WAVES / 4;
     if (blocks < 1) blocks = 1;

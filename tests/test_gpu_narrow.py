@@ -205,3 +205,37 @@ def test_high_quality_full_size(eng, oracle):
     finally:
         for b in (d_q, d_ee, d_ns, d_pass):
             b.free()
+
+
+def test_no_memory_for_the_handed_back_reads_runs_the_batch_in_place(eng, oracle):
+    """the sub-batch of the reads a narrow pass hands back needs memory of its own (rows + results).  When there is none
+    -- here: the test takes nearly all of the device's free memory first -- the call must not fail with MPB_E_NOMEM: the whole batch
+    goes through the sorted pipeline in place (the same results; the finished reads are computed again).  And when a stale choice
+    meets a batch of bad reads (more than a quarter handed back, pass not forced) the same happens without the allocation being tried."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    n, stride, L = 1_500_000, 320, 300
+    q, _ = oracle.synth_fill(n, stride, fixed_len=L, seed=77, profile=0)            # BASELINE's model: most reads are handed back
+    ee, ns, ps, need = oracle.filter_batch(q, fixed_len=L, threads=16)
+    bufs = [eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n)]
+    d_q, d_ee, d_ns, d_pass = bufs
+    hog = None
+    try:
+        d_q.upload(q)
+        prm = eng.params(narrow_rows=2)
+        # once with room: workspaces of the pass and of the sorted pipeline exist from here on (only the sub-batch block is missing later)
+        eng.filter_device(d_q, 4096, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm)
+        eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=eng.params(no_narrow=True))
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        handed = int((need > 2).sum())
+        assert handed * (stride + 17) > 200 << 20                                  # the block it would need: hundreds of MB
+        hog = eng.alloc(max(1, free.value - (96 << 20)))                           # leave less than 100 MB
+        c = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm)
+        path = eng.last_path()
+        assert path["narrow_rows"] == 2 and path["n_fallback"] == n                # everything went through the sorted pipeline
+        assert same(d_ee.download(np.float64, n), ee) and np.array_equal(d_ns.download(np.int32, n), ns)
+        assert np.array_equal(d_pass.download(np.uint8, n), ps) and c.n_pass == int(ps.sum())
+    finally:
+        for b in bufs + ([hog] if hog is not None else []):
+            b.free()

@@ -303,7 +303,7 @@ def high_quality_rate(eng, n, stride, L, seed, d_ee, d_ns, d_pass):
                     "kernels_ms_per_step": kt,
                     "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": alg,
                                  "whole_step": {"achieved": alg / ms / 1e6, "frac": alg / ms / 1e6 / HBM_PEAK_GBS},
-                                 "kernel": "k_narrow_rs" if stride % 64 == 0 and not os.environ.get("MPB_NAR_NO_RS") else "k_narrow",
+                                 "kernel": "k_narrow_rs" if stride % 64 == 0 else "k_narrow",
                                  "avg_launch_ms": nar_ms,
                                  "achieved": (alg / nar_ms / 1e6) if nar_ms else None,
                                  "frac": (alg / nar_ms / 1e6 / HBM_PEAK_GBS) if nar_ms else None},

@@ -13,7 +13,31 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = os.path.join(ROOT, "moira_amd", "csrc", "mpb_kernels.hip")
 
+# k_narrow_rs / k_narrow_rg: the panel stream alone (loads + tile writes, two tile reads per panel, no arithmetic) and the
+# arithmetic alone (stale panels after the first two) -- round 5's -DMPB_NAR_NOARITH / -DMPB_NAR_NODMA, now patches
+RS_LOOP_HEAD = "        if (t + 1 < total) {                                    // in flight while this panel is computed on\n"
+RS_HALVES_OPEN = "#pragma unroll\n        for (int h = 0; h < 2; h++) {\n            if (ALIGNED) {"
+RS_AFTER_HALVES = "        if (++cur_pk == NP) { cur_pk = 0; cur_sb += W; sread = 0; }"
+
 VARIANTS = {
+    "rs_arith_alone": [
+        (RS_LOOP_HEAD, "        if (t + 1 < total && t < 1) {                           // EXPERIMENT: no loads after the second panel\n"),
+    ],
+    "rs_stream_alone": [
+        (RS_HALVES_OPEN,
+         "        nonzero += *reinterpret_cast<const uint32_t *>(tile + x0) + *reinterpret_cast<const uint32_t *>(tile + (x0 ^ 64));\n"
+         "        if (false)\n" + RS_HALVES_OPEN),
+        (RS_AFTER_HALVES, "        if (nonzero == 0x12345678u) ns[gw] = 1;                 // EXPERIMENT: keeps the tile reads alive\n" + RS_AFTER_HALVES),
+    ],
+    # every stride through the LDS-DMA ring form k_narrow (round 5's MPB_NAR_NO_RS=1)
+    "force_ring": [
+        ("    if (stride % 16 != 0 || stride > (1 << 16)) return 0;", "    return 0;                                                     // EXPERIMENT: never k_narrow_rs\n    if (stride % 16 != 0 || stride > (1 << 16)) return 0;"),
+    ],
+    # k_narrow_rg: no arithmetic (the gather stream, tile writes, epilogues and result stores stay)
+    "rg_stream_alone": [
+        ("                const int rem = cur_maxc - cb;                   // chunks of the group's longest read from here on\n                if (rem <= 0) continue;",
+         "                const int rem = cur_maxc - cb;                   // chunks of the group's longest read from here on\n                if (rem <= 0 || h >= 0) { nonzero += *reinterpret_cast<const uint32_t *>(tile + (x0 ^ (h << 6))); continue; }   // EXPERIMENT"),
+    ],
     # k_narrow_rg: results written at the SORTED position (64 g + lane) instead of the read's own index: coalesced stores, wrong
     # placement -- what the scattered 13-byte result stores cost
     "rg_coalesced_results": [
