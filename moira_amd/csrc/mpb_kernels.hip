@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(256) void k_narrow(const uint8_t *__restrict__ q, i
     // seg / wave_count: the reads this pass cannot finish.  A wave appends them to a segment of its own -- wave gw owns the
     // slots of the row blocks it walks, which start at 64 * (blocks owned by the waves before it) -- and leaves its count in
     // wave_count[gw]: no atomic (a returned atomic would drain the prefetch stream: vmcnt counts everything), and a list whose
-    // order does not depend on timing.  k_nar_offsets / k_nar_compact then make the dense list.
+    // order does not depend on timing.  k_nar_compact then makes the dense list.
     static_assert(D >= 2 && D <= 4, "ring depth");
     __shared__ nar_entry_t s_p[256];
     // one array per ring slot: a read of slot k is then provably independent of a DMA into slot k + 1 (the compiler orders
@@ -2329,78 +2329,127 @@ __global__ __launch_bounds__(256) void k_narrow_rs(const uint8_t *__restrict__ q
 // ------------------------------------------------------------------------------------------
 #define MPB_RG_WIN 4096                     // reads per sort window (64 groups)
 #define MPB_RG_BINS 64                      // sort keys per window: ceil(len / 16) >> key_shift
-#define MPB_RG_PAD(e) ((e) + 2 * ((e) >> 6))  // counter (bin, thread) -> 16-bit LDS slot: one pad dword per 64, so that the threads' runs of 64 are conflict-free
 
 // cost of a group = its chunks + a panel's fixed work per 8 chunks + the epilogue (in chunk units; it balances, nothing else)
 __device__ __forceinline__ int rg_group_cost(int chunks) { return chunks + ((chunks + 7) >> 3) + 2; }
 
+// exclusive prefix over the 256 threads of a block (wave scans by lane shuffles, the four wave totals through LDS)
+__device__ __forceinline__ uint32_t rg_block_excl_scan(uint32_t x, uint32_t *s_wave, int tid)
+{
+    const int lane = tid & 63, w = tid >> 6;
+    uint32_t incl = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) base += k < w ? s_wave[k] : 0;
+    __syncthreads();                                            // (s_wave is used again by the next pass)
+    return base + incl - x;
+}
+
+// One window: a stable LSD radix sort of its <= 4096 reads by the 6-bit key ceil(len / 16) >> key_shift, two passes of three bits.
+// A pass: thread t counts the digits of its 16 consecutive elements into its own column of an 8 x 256 counter matrix (in registers
+// first: no chain of dependent LDS updates, no atomics), the matrix is scanned digit-major (a thread's 8 counters are 16 contiguous
+// bytes: one b128 read, one write; the 256 partial sums by lane shuffles), and the thread places its elements in order.  28 KB of
+// LDS: five workgroups per CU (a block's life is a chain of LDS latencies and barriers, so what counts is how many run at once).
 __global__ __launch_bounds__(256) void k_rag_sort(const int32_t *__restrict__ len, int64_t n, int32_t max_len, int key_shift,
                                                   int2 *__restrict__ ord, int32_t *__restrict__ gpre,
                                                   unsigned long long *__restrict__ wsum)
 {
-    __shared__ uint16_t s_cnt[MPB_RG_BINS * 256 + 2 * 256];
-    __shared__ uint16_t s_ord[MPB_RG_WIN];
-    __shared__ int32_t s_len[MPB_RG_WIN];
-    __shared__ uint32_t s_part[256];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cnt[8 * 256];
+    __shared__ __attribute__((aligned(16))) uint16_t s_idx[2][MPB_RG_WIN];     // pass 1: local index | high digit << 12; pass 2: local index
+    __shared__ __attribute__((aligned(16))) uint16_t s_len[MPB_RG_WIN];        // lengths in natural order (0xffff: outside 0..max_len)
+    __shared__ uint32_t s_wave[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t w0 = (int64_t)blockIdx.x * MPB_RG_WIN;
     const int m = (int)min((int64_t)MPB_RG_WIN, n - w0);
+    // the window's lengths, loaded a line per 32 lanes (thread-contiguous loads of 16 ints cost a request per LANE), checked,
+    // parked in natural order (max_len <= MPB_RG_MAX_STRIDE = 4096: 16 bits hold them)
 #pragma unroll
-    for (int k = 0; k < MPB_RG_BINS; k++) s_cnt[MPB_RG_PAD(k * 256 + tid)] = 0;
-    // thread t owns reads 16 t .. 16 t + 15 of the window (consecutive: the order inside a key is the order in memory)
-    int lv[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int i = 16 * tid + r;
-        lv[r] = i < m ? len[w0 + i] : -2;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const bool bad = lv[r] < 0 || lv[r] > max_len;          // (a length outside the row: key 0, marked -1; -2: past the batch)
-        const int bin = bad ? 0 : ((lv[r] + 15) >> 4) >> key_shift;
-        if (lv[r] != -2) s_cnt[MPB_RG_PAD(bin * 256 + tid)]++;  // the thread's own column: no atomics
+    for (int k = 0; k < 16; k++) {
+        const int i = k * 256 + tid;
+        const int l = i < m ? len[w0 + i] : 0;
+        s_len[i] = (uint16_t)((l < 0 || l > max_len) ? 0xffff : l);        // (a length outside the row: key 0, marked for the pass)
     }
     __syncthreads();
-    // exclusive scan over (bin, thread): thread t takes counters 64 t .. 64 t + 63
-    uint32_t sum = 0;
-    for (int e = 0; e < 64; e++) sum += s_cnt[66 * tid + e];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t x = tid >= off ? s_part[tid - off] : 0;
+    auto key_of = [key_shift](uint32_t l) { return l == 0xffffu ? 0u : ((l + 15u) >> 4) >> key_shift; };
+    // thread t owns elements 16 t .. 16 t + 15 of the current order (pass 1: the natural order)
+    uint32_t el[16];                                            // pass 1: the key; pass 2: local index | high digit << 12
+    {
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(s_len + 16 * tid), b = *reinterpret_cast<const u32x4 *>(s_len + 16 * tid + 8);
+        const uint32_t ww[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) { el[2 * e] = key_of(ww[e] & 0xffffu); el[2 * e + 1] = key_of(ww[e] >> 16); }
+    }
+    const int mine = min(16, max(0, m - 16 * tid));             // elements of this thread that exist
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) {
+            __syncthreads();                                    // pass 1's order is complete
+            const u32x4 a = *reinterpret_cast<const u32x4 *>(s_idx[0] + 16 * tid), b = *reinterpret_cast<const u32x4 *>(s_idx[0] + 16 * tid + 8);
+            const uint32_t ww[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) { el[2 * e] = ww[e] & 0xffffu; el[2 * e + 1] = ww[e] >> 16; }
+        }
+        // the thread's eight digit counts, in registers (16-bit fields of two 64-bit words)
+        unsigned long long c_lo = 0, c_hi = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int d = pass == 0 ? (int)(el[r] & 7u) : (int)(el[r] >> 12);
+            const unsigned long long inc = r < mine ? 1ull << (16 * (d & 3)) : 0ull;
+            c_lo += (d & 4) ? 0ull : inc;
+            c_hi += (d & 4) ? inc : 0ull;
+        }
+#pragma unroll
+        for (int d = 0; d < 8; d++) s_cnt[d * 256 + tid] = (uint16_t)(((d & 4) ? c_hi : c_lo) >> (16 * (d & 3)));   // the thread's own column
         __syncthreads();
-        s_part[tid] += x;
-        __syncthreads();
-    }
-    uint32_t run = s_part[tid] - sum;
-    for (int e = 0; e < 64; e++) {
-        const uint32_t c = s_cnt[66 * tid + e];
-        s_cnt[66 * tid + e] = (uint16_t)run;
-        run += c;
-    }
-    __syncthreads();
+        // digit-major exclusive scan: thread t holds counters 8 t .. 8 t + 7 (one digit, eight threads)
+        u32x4 c4 = *reinterpret_cast<const u32x4 *>(s_cnt + 8 * tid);
+        uint32_t cc[8] = {c4.x & 0xffffu, c4.x >> 16, c4.y & 0xffffu, c4.y >> 16, c4.z & 0xffffu, c4.z >> 16, c4.w & 0xffffu, c4.w >> 16};
+        uint32_t sum = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        if (lv[r] == -2) continue;
-        const bool bad = lv[r] < 0 || lv[r] > max_len;
-        const int bin = bad ? 0 : ((lv[r] + 15) >> 4) >> key_shift;
-        const uint32_t pos = s_cnt[MPB_RG_PAD(bin * 256 + tid)]++;
-        s_ord[pos] = (uint16_t)(16 * tid + r);
-        s_len[pos] = bad ? -1 : lv[r];
+        for (int e = 0; e < 8; e++) sum += cc[e];
+        uint32_t run = rg_block_excl_scan(sum, s_wave, tid);
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const uint32_t c = cc[e]; cc[e] = run; run += c; }
+        c4.x = cc[0] | (cc[1] << 16); c4.y = cc[2] | (cc[3] << 16); c4.z = cc[4] | (cc[5] << 16); c4.w = cc[6] | (cc[7] << 16);
+        *reinterpret_cast<u32x4 *>(s_cnt + 8 * tid) = c4;
+        __syncthreads();
+        unsigned long long p_lo = 0, p_hi = 0;                  // where the thread's next element of each digit goes
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const unsigned long long v = (unsigned long long)s_cnt[d * 256 + tid] << (16 * (d & 3));
+            if (d & 4) p_hi |= v; else p_lo |= v;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int d = pass == 0 ? (int)(el[r] & 7u) : (int)(el[r] >> 12);
+            const uint32_t pos = (uint32_t)(((d & 4) ? p_hi : p_lo) >> (16 * (d & 3))) & 0xffffu;
+            const unsigned long long inc = 1ull << (16 * (d & 3));
+            p_lo += (d & 4) ? 0ull : inc;
+            p_hi += (d & 4) ? inc : 0ull;
+            if (r < mine) s_idx[pass][pos] = (uint16_t)(pass == 0 ? (uint32_t)(16 * tid + r) | ((el[r] >> 3) << 12) : el[r] & 0xfffu);
+        }
     }
     __syncthreads();
-    for (int p = tid; p < m; p += 256) ord[w0 + p] = make_int2((int)(w0 + s_ord[p]), s_len[p]);
-    // a group's cost comes from the 16-byte chunks of its longest read; gpre[g] = cost of the window's groups up to and with g
-    // (one wave: lane = group), wsum[window] = the window's total
+    for (int p = tid; p < m; p += 256) {
+        const int i = s_idx[1][p];
+        const uint32_t l = s_len[i];
+        ord[w0 + p] = make_int2((int)(w0 + i), l == 0xffffu ? -1 : (int)l);
+    }
+    // A group's cost comes from the 16-byte chunks of its longest read.  The order is ascending in the key, so that is the key of the
+    // group's last entry (its upper edge when keys are coarser than a chunk: the cost only balances the waves' ranges; the pass
+    // finds a group's exact longest read itself).  gpre[g] = cost of the window's groups up to and with g, wsum[window] = the total.
     if (w == 0) {
         int c = 0;
         if (lane * 64 < m) {
-            int mx = 0;
-            for (int t = 0; t < 64; t++) {
-                const int k = lane * 64 + ((t + lane) & 63);      // (rotated by the lane: no bank conflict)
-                if (k < m) mx = max(mx, s_len[k]);
-            }
-            c = rg_group_cost((mx + 15) >> 4);
+            const uint32_t k = key_of(s_len[s_idx[1][min(m, lane * 64 + 64) - 1]]);
+            c = rg_group_cost((int)(key_shift ? ((k + 1) << key_shift) - 1 : k));
         }
         int pre = c;
 #pragma unroll
@@ -2480,7 +2529,7 @@ __global__ __launch_bounds__(256, 4) void k_narrow_rg(const uint8_t *__restrict_
     const int ngroups = (int)((n + 63) >> 6), nwin = (int)((n + MPB_RG_WIN - 1) / MPB_RG_WIN), nwaves = (int)gridDim.x * 4;
     const int g0 = __builtin_amdgcn_readfirstlane(rg_first_group(wpre, gpre, nwin, ngroups, gw, nwaves, lane));
     const int g1 = __builtin_amdgcn_readfirstlane(rg_first_group(wpre, gpre, nwin, ngroups, gw + 1, nwaves, lane));
-    if (lane == 0) gstart[gw] = g0;                           // (where the wave's list segment starts: k_nar_compact_rg)
+    if (lane == 0) gstart[gw] = g0;                           // (where the wave's list segment starts: k_nar_compact)
     if (g0 >= g1) {
         if (lane == 0) wave_count[gw] = 0;
         return;
@@ -2635,51 +2684,29 @@ __global__ __launch_bounds__(256, 4) void k_narrow_rg(const uint8_t *__restrict_
     if (lane == 0) wave_count[gw] = nlist;
 }
 
-// segment of wave g (64 slots per group it owns, from gstart) -> list[wave_off[g] ...): one block per wave
-__global__ __launch_bounds__(256) void k_nar_compact_rg(const int32_t *__restrict__ seg, const int32_t *__restrict__ wave_count,
-                                                        const int32_t *__restrict__ wave_off, const int32_t *__restrict__ gstart,
-                                                        int32_t *__restrict__ list)
-{
-    const int g = blockIdx.x;
-    const int cnt = wave_count[g];
-    const int32_t *src = seg + 64 * (int64_t)gstart[g];
-    int32_t *dst = list + wave_off[g];
-    for (int k = threadIdx.x; k < cnt; k += 256) dst[k] = src[k];
-}
-
-// exclusive prefix of the waves' list counts (one block); total -> *count
-__global__ __launch_bounds__(1024) void k_nar_offsets(const int32_t *__restrict__ wave_count, int nwaves,
-                                                      int32_t *__restrict__ wave_off, int32_t *__restrict__ count)
-{
-    __shared__ int s_sum[1024];
-    const int tid = threadIdx.x;
-    const int per = (nwaves + 1023) / 1024;
-    const int g0 = tid * per, g1 = min(nwaves, g0 + per);
-    int sum = 0;
-    for (int g = g0; g < g1; g++) sum += wave_count[g];
-    s_sum[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int x = tid >= off ? s_sum[tid - off] : 0;
-        __syncthreads();
-        s_sum[tid] += x;
-        __syncthreads();
-    }
-    int run = s_sum[tid] - sum;
-    for (int g = g0; g < g1; g++) { wave_off[g] = run; run += wave_count[g]; }
-    if (tid == 1023) *count = s_sum[1023];
-}
-
-// segment of wave g -> list[wave_off[g] ...): one block per wave
+// The waves' list segments -> the dense list, in wave order: block g sums the counts of the waves before it (at most 8192 ints,
+// from L2), copies its wave's segment behind them, and the last block leaves the total in *count.  One launch; no atomics, so the
+// list's order does not depend on timing.  seg_start: where wave g's segment begins -- per_blk x (row blocks owned by the waves
+// before it) for the fixed-length forms (gstart == nullptr), 64 x gstart[g] for the ragged pass.
 __global__ __launch_bounds__(256) void k_nar_compact(const int32_t *__restrict__ seg, const int32_t *__restrict__ wave_count,
-                                                     const int32_t *__restrict__ wave_off, int64_t nblk, int nwaves,
-                                                     int per_blk, int32_t *__restrict__ list)
+                                                     int64_t nblk, int nwaves, int per_blk, const int32_t *__restrict__ gstart,
+                                                     int32_t *__restrict__ list, int32_t *__restrict__ count)
 {
-    const int64_t g = blockIdx.x;
+    __shared__ int s_part[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    int sum = 0;
+    for (int k = tid; k < g; k += 256) sum += wave_count[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((tid & 63) == 0) s_part[tid >> 6] = sum;
+    __syncthreads();
+    const int off0 = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     const int cnt = wave_count[g];
-    const int32_t *src = seg + (int64_t)per_blk * (g * (nblk / nwaves) + min(g, nblk % nwaves));
-    int32_t *dst = list + wave_off[g];
-    for (int k = threadIdx.x; k < cnt; k += 256) dst[k] = src[k];
+    const int32_t *src = gstart ? seg + 64 * (int64_t)gstart[g]
+                                : seg + (int64_t)per_blk * ((int64_t)g * (nblk / nwaves) + min((int64_t)g, nblk % nwaves));
+    int32_t *dst = list + off0;
+    for (int k = tid; k < cnt; k += 256) dst[k] = src[k];
+    if (g == nwaves - 1 && tid == 0) *count = off0 + cnt;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3064,8 +3091,7 @@ void mpb_launch_narrow(int rows0, const uint8_t *q, int64_t n, int64_t stride, i
     }
 #undef MPB_NRS_LAUNCH
 #undef MPB_NAR_LAUNCH
-    hipLaunchKernelGGL(k_nar_offsets, dim3(1), dim3(1024), 0, s, ws.nar_wave_count, nwaves, ws.nar_wave_off, ws.nar_count);
-    hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, ws.nar_wave_off, nblk, nwaves, per_blk, list);
+    hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, nblk, nwaves, per_blk, (const int32_t *)nullptr, list, ws.nar_count);
 }
 
 // ragged batches (k_narrow_rg): sort windows by length, cut the groups into one range per wave, walk them
@@ -3110,8 +3136,7 @@ void mpb_launch_narrow_ragged(int rows0, const uint8_t *q, int64_t n, int64_t st
     default: MPB_NRG_LAUNCH(4); break;
     }
 #undef MPB_NRG_LAUNCH
-    hipLaunchKernelGGL(k_nar_offsets, dim3(1), dim3(1024), 0, s, ws.nar_wave_count, nwaves, ws.nar_wave_off, ws.nar_count);
-    hipLaunchKernelGGL(k_nar_compact_rg, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, ws.nar_wave_off, ws.rg_gstart, list);
+    hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, (int64_t)0, nwaves, 64, ws.rg_gstart, list, ws.nar_count);
 }
 
 void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const int32_t *len, const MpbDevParams &prm,

@@ -2,7 +2,8 @@
 """Experiment builds WITHOUT switches in the shipped kernels: a variant is a list of exact text replacements applied
 to a COPY of moira_amd/csrc/mpb_kernels.hip; the copy is written next to the original's includes so that it compiles unchanged.
 
-    python tools/experiments/make_variant.py NAME OUT.hip      # writes the patched source, exits non-zero if a patch does not apply
+    python tools/experiments/make_variant.py NAME OUT.hip [SRC.hip]   # writes the patched source (NAME "none": SRC as it is, with
+                                                                         # absolute includes); exits non-zero if a patch does not apply
     python tools/experiments/make_variant.py --list
 
 Use with tools/experiments/variants.sh:   name:""@/tmp/var/NAME.hip
@@ -20,6 +21,17 @@ RS_HALVES_OPEN = "#pragma unroll\n        for (int h = 0; h < 2; h++) {\n       
 RS_AFTER_HALVES = "        if (++cur_pk == NP) { cur_pk = 0; cur_sb += W; sread = 0; }"
 
 VARIANTS = {
+    # the narrow passes' table as {p'} alone (8 bytes: half the LDS cycles of a look-up), 1 - p recomputed by the IEEE subtraction
+    # the host used (one more FP64 instruction per base): round 5's -DMPB_NAR_LUT64.  Bit-exact (mpb_create checks a == 1 - p').
+    "nar_lut64": [
+        ("typedef double2 nar_entry_t;\n#define NAR_P(e) ((e).y)\n#define NAR_A(e) ((e).x)\n",
+         "typedef double nar_entry_t;\n#define NAR_P(e) (e)\n#define NAR_A(e) (1.0 - (e))\n"),
+        ("s_p[tid] = tid == 255 ? make_double2(__builtin_nan(\"\"), __builtin_nan(\"\")) : lut_g[tid];",
+         "s_p[tid] = tid == 255 ? __builtin_nan(\"\") : lut_g[tid].y;", 3),
+    ],
+    # k_narrow_rs (rows of a multiple of 64 bytes): the two halves of a panel as CHAINED runs -- half 0's run looks up the first
+    # eight bases of half 1 in its tail, half 1's run starts without waiting for the LDS.  Bit-exact; a unified diff.
+    "rs_chained_halves": "patches/rs_chained_halves.diff",
     "rs_arith_alone": [
         (RS_LOOP_HEAD, "        if (t + 1 < total && t < 1) {                           // EXPERIMENT: no loads after the second panel\n"),
     ],
@@ -58,12 +70,29 @@ def main():
             print(k)
         return 0
     name, out = sys.argv[1], sys.argv[2]
-    s = open(SRC).read()
-    for old, new in VARIANTS[name]:
-        if s.count(old) != 1:
-            sys.stderr.write("variant %s: a patch applies %d times (must be exactly once):\n%s\n" % (name, s.count(old), old))
-            return 1
-        s = s.replace(old, new)
+    src = sys.argv[3] if len(sys.argv) > 3 else SRC        # another copy of the kernel file (an A/B baseline kept aside); "none": no patch
+    s = open(src).read()
+    for part in ([] if name == "none" else name.split("+")):     # A+B: both, in that order
+        v = VARIANTS[part]
+        if isinstance(v, str):                                 # a unified diff next to this script
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                a, b = os.path.join(td, "a.hip"), os.path.join(td, "b.hip")
+                open(a, "w").write(s)
+                r = subprocess.run(["patch", "-s", "-o", b, a, os.path.join(os.path.dirname(os.path.abspath(__file__)), v)],
+                                   capture_output=True, text=True)
+                if r.returncode != 0:
+                    sys.stderr.write("variant %s: %s does not apply:\n%s%s\n" % (part, v, r.stdout, r.stderr))
+                    return 1
+                s = open(b).read()
+            continue
+        for item in v:
+            old, new, times = item if len(item) == 3 else (item[0], item[1], 1)
+            if s.count(old) != times:
+                sys.stderr.write("variant %s: a patch applies %d times (must be exactly %d):\n%s\n" % (part, s.count(old), times, old))
+                return 1
+            s = s.replace(old, new)
     # the copy lives elsewhere: make its relative includes absolute
     s = s.replace('#include "mpb_internal.h"', '#include "%s"' % os.path.join(ROOT, "moira_amd", "csrc", "mpb_internal.h"))
     s = s.replace('#include "../../include/mpb_synth.h"', '#include "%s"' % os.path.join(ROOT, "include", "mpb_synth.h"))

@@ -9,7 +9,8 @@ PROBE=${PROBE:-tools/narrow_probe.py}; N=${N:-10000000}
 mkdir -p /tmp/var
 for v in ${VARIANTS:-whole: arith_alone:rs_arith_alone stream_alone:rs_stream_alone}; do
   name=${v%%:*}; patch=${v#*:}; SRC=moira_amd/csrc/mpb_kernels.hip
-  if [ -n "$patch" ]; then python tools/experiments/make_variant.py $patch /tmp/var/$patch.hip || exit 1; SRC=/tmp/var/$patch.hip; fi
+  if [ "${patch:0:1}" = "@" ]; then python tools/experiments/make_variant.py none /tmp/var/$name.hip ${patch:1} || exit 1; SRC=/tmp/var/$name.hip      # name:@another_copy_of_the_kernels.hip
+  elif [ -n "$patch" ]; then python tools/experiments/make_variant.py $patch /tmp/var/$patch.hip || exit 1; SRC=/tmp/var/$patch.hip; fi
   /opt/rocm/bin/hipcc $FL $EXTRA $SRC moira_amd/csrc/mpb_api.cpp moira_amd/csrc/mpb_broker.cpp -o /tmp/var/$name.so 2>/tmp/var/$name.err || { tail -5 /tmp/var/$name.err; exit 1; }
   echo "== $name ($patch $EXTRA)"
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE" $MORE_SETS; do
