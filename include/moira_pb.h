@@ -214,7 +214,9 @@ int mpb_encode_ascii_device(mpb_ctx *ctx, const uint8_t *d_q, int64_t n, int64_t
  *   d_q         device, n rows of row_stride bytes (row_stride % 16 == 0, 16-B aligned; a 64-B aligned
  *               matrix with row_stride % 64 == 0 is the fast layout: every 64-byte lane group then reads one
  *               sector -- a matrix offset by 16 bytes costs the prepass 7 %; and the narrow pass of batches of good reads
- *               then walks whole 128-byte lines at every row count, at other strides only with two rows)
+ *               then walks whole 128-byte lines at every row count, at other strides only with two rows; for RAGGED batches
+ *               (d_len != NULL) make row_stride a multiple of 128: the narrow pass of ragged batches fetches, per read, only the
+ *               lines its bases lie in, and a row that starts inside a line shares that line with its neighbour)
  *   d_len       device int32[n], or NULL when every read has `fixed_len` bases
  *   outputs     device: d_ee double[n], d_ns int32[n], d_pass uint8[n]
  *   counts      host, may be NULL (when non-NULL the call synchronises)
@@ -226,7 +228,12 @@ int mpb_encode_ascii_device(mpb_ctx *ctx, const uint8_t *d_q, int64_t n, int64_t
  * behaviour (first CDF row already above 1-alpha -> ee = 0,
  * ref: moira/moira.py:1611,1629 vs moira/bernoullimodule.c:254).
  * d_ee[i] is the value process_data returns (after +Ns / floor).
- * Asynchronous on the context's stream unless `counts` is given.
+ * Asynchronous on the context's stream unless `counts` is given -- with one exception since round 5: a batch that is eligible for
+ * the narrow pass (mpb_path_info below: fixed-length or ragged rows of up to 4096 bytes, default table, none of the opt-in flags,
+ * >= 262144 reads or MPB_FLAG_NARROW_ROWS) synchronises on the stream inside the call -- once per 64 calls of the same batch shape
+ * for the sample that picks the pass, and after every narrow pass for the 4-byte count of the reads it hands to the sorted
+ * pipeline (the sub-batch is sized from it).  Callers that queue steps behind each other and must not stall pass
+ * MPB_FLAG_NO_NARROW.
  *
  * Read length: up to 65535 bases (row_stride <= 65536; rounds 1-3: 16383).  A read whose DP needs at most 1024 rows --
  * every read of up to 1023 bases, and any longer read with fewer than about a thousand expected errors -- runs in one wave
@@ -470,6 +477,8 @@ int mpb_last_class_histogram(mpb_ctx *ctx, int32_t *caps, int64_t *counts, int32
  * (0 for a read MPB_FLAG_DECISION_ONLY settled without a DP); host array of n int32.  Diagnostic: what
  * tools/class_efficiency.py uses to build single-class batches.  Synchronises. */
 int mpb_last_read_budgets(mpb_ctx *ctx, int32_t *caps_out, int64_t n);
+/* (Both fail with MPB_E_INVALID when the last filter call took the narrow pass: the workspace then describes the sub-batch it handed
+ * back, or an earlier batch.  Ask for them after a call with MPB_FLAG_NO_NARROW.) */
 /* Algorithmic DP cells of the last mpb_filter_device call made with MPB_FLAG_COUNT_CELLS (0 without it).  Synchronises. */
 int mpb_last_algorithmic_cells(mpb_ctx *ctx, int64_t *cells);
 
@@ -477,10 +486,16 @@ int mpb_last_algorithmic_cells(mpb_ctx *ctx, int64_t *cells);
  * Which pass the last mpb_filter_device call took (round 5).
  * A batch of GOOD reads -- nearly every read's CDF crosses 1 - alpha within its first 2..4 rows of the table
  * (ref: moira/bernoullimodule.c:152-166,219-251: rows 0..j depend on no later row) --
- * is bound by HBM, not by FP64 issue, and the sorted pipeline would read the matrix twice.  Such a batch (fixed length,
- * >= 262144 reads, default table, none of the opt-in flags) takes the NARROW PASS instead: the matrix is read once, in natural
- * order, one read per lane with narrow_rows rows in registers; reads it cannot finish (more rows needed, or a lower-case 'n')
- * are gathered into a dense sub-batch and run through the sorted pipeline, and their results are scattered back.  The choice is
+ * is bound by HBM, not by FP64 issue, and the sorted pipeline would read the matrix twice.  Such a batch (>= 262144 reads,
+ * default table, none of the opt-in flags) takes the NARROW PASS instead: the matrix is read once, one read per lane with
+ * narrow_rows rows in registers; reads it cannot finish (more rows needed, or a lower-case 'n') are gathered into a dense
+ * sub-batch and run through the sorted pipeline, and their results are scattered back (when that sub-batch would be more than a
+ * quarter of the batch, or there is no device memory for it, the whole batch runs through the sorted pipeline in place instead and
+ * n_fallback reports n).  Fixed-length batches are walked in natural order.  RAGGED batches (round 6: d_len != NULL, rows of up
+ * to 4096 bytes -- e.g. the contigs of the reference's paired mode, moira/moira.py:789-801) are first sorted by length inside
+ * windows of 4096 consecutive reads (8 bytes per read of workspace), so that the 64 reads a wave walks together end together,
+ * and only the 128-byte lines a read's bases lie in are fetched; in the sample's histogram each read then weighs its 16-byte
+ * chunks, and a length outside its row is a read the pass hands back (the sorted pipeline reports it).  The choice is
  * made from a sample of at most 0.1 % of the reads (the prepass' row prediction on 256..4096 reads spread over the batch), is
  * reused while the batches of a context keep their shape and parameters (re-sampled when a pass had to hand back more reads
  * than the sample promised, and every 64 calls), and steers speed only: every read's result is the reference's bit for bit

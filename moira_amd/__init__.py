@@ -7,4 +7,4 @@ Only what the path needs:
   dropin/      `bernoulli` module with moira's calculate_errors_PB signature
   shard.py     host-side split/gather across the GPUs of a node
 """
-__version__ = "0.5.0"
+__version__ = "0.6.0"

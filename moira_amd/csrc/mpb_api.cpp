@@ -25,7 +25,7 @@
 #include <unordered_map>
 #include <vector>
 
-#define MPB_VERSION_STR "moira_pb 0.5.0 (gfx950)"
+#define MPB_VERSION_STR "moira_pb 0.6.0 (gfx950)"
 
 static thread_local char g_err[512] = "";
 

@@ -32,6 +32,10 @@ VARIANTS = {
     # k_narrow_rs (rows of a multiple of 64 bytes): the two halves of a panel as CHAINED runs -- half 0's run looks up the first
     # eight bases of half 1 in its tail, half 1's run starts without waiting for the LDS.  Bit-exact; a unified diff.
     "rs_chained_halves": "patches/rs_chained_halves.diff",
+    # k_narrow_rg without the forced four waves per SIMD (the compiler then takes 126 / 132 / 138 registers: three waves at R >= 3)
+    "rg_no_min_waves": [
+        ("__global__ __launch_bounds__(256, 4) void k_narrow_rg(", "__global__ __launch_bounds__(256) void k_narrow_rg("),
+    ],
     "rs_arith_alone": [
         (RS_LOOP_HEAD, "        if (t + 1 < total && t < 1) {                           // EXPERIMENT: no loads after the second panel\n"),
     ],
