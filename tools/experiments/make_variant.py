@@ -32,6 +32,30 @@ VARIANTS = {
     # k_narrow_rs (rows of a multiple of 64 bytes): the two halves of a panel as CHAINED runs -- half 0's run looks up the first
     # eight bases of half 1 in its tail, half 1's run starts without waiting for the LDS.  Bit-exact; a unified diff.
     "rs_chained_halves": "patches/rs_chained_halves.diff",
+    # k_narrow_rg: when a group is armed, every lane asks for one dword of line c8 (c8 >= 1) of each of the eight rows its load
+    # instructions cover -- the rows' later lines are requested from DRAM together with their first, and wait in the L2 / the
+    # Infinity Cache for the panel that needs them.  Results unchanged (the dwords are never looked at).
+    "rg_touch_rows": [
+        ("        rows[lane] = (uint32_t)rowoff;                          // (the loads of the group before this one have all been issued)\n    };\n",
+         "        rows[lane] = (uint32_t)rowoff;                          // (the loads of the group before this one have all been issued)\n"
+         "        {\n"
+         "            const uint32_t line = (c8 >= 1 && 8 * c8 < ld_maxc) ? (uint32_t)(c8 * 128) : 0u;      // (lanes with nothing to ask for: line 0 again)\n"
+         "            _Pragma(\"unroll\") for (int j = 0; j < 8; j++)\n"
+         "                touch[j] = *(const __attribute__((address_space(1))) uint32_t *)(wbase + (rows[8 * j + r8] + line));\n"
+         "        }\n"
+         "    };\n"),
+        ("    uint32_t *const rows = s_row[w];\n", "    uint32_t *const rows = s_row[w];\n    uint32_t junk = 0, touch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // EXPERIMENT: where the touch loads land\n"),
+        ("            {\n                int next_pk = pk + 1;\n                const bool next_group = next_pk == np && g + 1 < g1;",
+         "            if (pk == 0) { _Pragma(\"unroll\") for (int j = 0; j < 8; j++) junk += touch[j]; }     // (older than the panel the tile write waited for)\n"
+         "            {\n                int next_pk = pk + 1;\n                const bool next_group = next_pk == np && g + 1 < g1;"),
+        ("    if (lane == 0) wave_count[gw] = nlist;\n}\n\n// The waves' list segments",
+         "    if (junk == 0x12345678u) ns[0] = 1;\n    if (lane == 0) wave_count[gw] = nlist;\n}\n\n// The waves' list segments"),
+    ],
+    # k_narrow_rg: the arithmetic alone -- no row is loaded (the tile keeps what it held: zeros / stale bytes; results are garbage)
+    "rg_arith_alone": [
+        ("        if (8 * pk + c8 < ld_maxc) {                            // (the group's last panel: only the chunks its longest read has)",
+         "        if (8 * pk + c8 < ld_maxc && n < 0) {                   // EXPERIMENT: never"),
+    ],
     # k_narrow_rg without the forced four waves per SIMD (the compiler then takes 126 / 132 / 138 registers: three waves at R >= 3)
     "rg_no_min_waves": [
         ("__global__ __launch_bounds__(256, 4) void k_narrow_rg(", "__global__ __launch_bounds__(256) void k_narrow_rg("),
