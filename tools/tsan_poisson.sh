@@ -24,8 +24,9 @@ void mpb_launch_encode(const uint8_t *, int64_t, int64_t, int32_t, uint8_t *, ui
 void mpb_launch_count(const uint8_t *, int64_t, const MpbWorkspace &, hipStream_t) STUB
 void mpb_launch_synth(uint8_t *, int64_t, int64_t, int32_t, int32_t, int32_t, int32_t *, uint64_t, int64_t, hipStream_t, int) STUB
 void mpb_launch_narrow(int, const uint8_t *, int64_t, int64_t, int32_t, const MpbDevParams &, const MpbWorkspace &, double *, int32_t *, uint8_t *, int32_t *, int, hipStream_t) STUB
-void mpb_launch_sample(const uint8_t *, int64_t, int64_t, int32_t, const MpbDevParams &, const MpbWorkspace &, int, hipStream_t) STUB
-void mpb_launch_gather_rows(const uint8_t *, int64_t, const int32_t *, int64_t, uint8_t *, hipStream_t) STUB
+void mpb_launch_sample(const uint8_t *, int64_t, int64_t, int32_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int, hipStream_t) STUB
+void mpb_launch_narrow_ragged(int, const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, double *, int32_t *, uint8_t *, int32_t *, int, hipStream_t) STUB
+void mpb_launch_gather_rows(const uint8_t *, int64_t, const int32_t *, const int32_t *, int64_t, uint8_t *, int32_t *, hipStream_t) STUB
 void mpb_launch_scatter_back(const int32_t *, int64_t, const double *, const int32_t *, const uint8_t *, double *, int32_t *, uint8_t *, hipStream_t) STUB
 void mpb_launch_serve(const MpbServeBox &, const double2 *, uint32_t, uint32_t, hipStream_t) STUB
 int mpb_narrow_lds_bytes() { return 1 << 15; }
