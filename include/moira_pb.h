@@ -102,7 +102,7 @@ extern "C" {
 #define MPB_K_LAMBDA    5   /* Poisson approximation: per-read sum of error probabilities */
 #define MPB_K_WIDE      6   /* reads that need more than 1024 DP rows: one workgroup per read */
 #define MPB_K_NARROW    7   /* natural-order narrow pass: one read per lane, 2..4 DP rows, the matrix read once */
-#define MPB_K_FALLBACK  8   /* ... its list compaction, the gather of the unfinished reads and the scatter of their results */
+#define MPB_K_FALLBACK  8   /* (rounds 5: the gather of the unfinished reads and the scatter of their results; unused since round 6: they run where they lie) */
 #define MPB_K_SAMPLE    9   /* ... the batch sample that picks the pass */
 #define MPB_K_COUNT     10
 
@@ -488,10 +488,10 @@ int mpb_last_algorithmic_cells(mpb_ctx *ctx, int64_t *cells);
  * (ref: moira/bernoullimodule.c:152-166,219-251: rows 0..j depend on no later row) --
  * is bound by HBM, not by FP64 issue, and the sorted pipeline would read the matrix twice.  Such a batch (>= 262144 reads,
  * default table, none of the opt-in flags) takes the NARROW PASS instead: the matrix is read once, one read per lane with
- * narrow_rows rows in registers; reads it cannot finish (more rows needed, or a lower-case 'n') are gathered into a dense
- * sub-batch and run through the sorted pipeline, and their results are scattered back (when that sub-batch would be more than a
- * quarter of the batch, or there is no device memory for it, the whole batch runs through the sorted pipeline in place instead and
- * n_fallback reports n).  Fixed-length batches are walked in natural order.  RAGGED batches (round 6: d_len != NULL, rows of up
+ * narrow_rows rows in registers; reads it cannot finish (more rows needed, or a lower-case 'n') are listed and run through the
+ * sorted pipeline WHERE THEY LIE (round 6: its classification and sort walk the list, its DP addresses rows and results by read
+ * anyway; round 5 gathered them into a dense sub-batch of their own); when they are more than half of the batch the whole batch
+ * runs through the sorted pipeline instead and n_fallback reports n.  Fixed-length batches are walked in natural order.  RAGGED batches (round 6: d_len != NULL, rows of up
  * to 4096 bytes -- e.g. the contigs of the reference's paired mode, moira/moira.py:789-801) are first sorted by length inside
  * windows of 4096 consecutive reads (8 bytes per read of workspace), so that the 64 reads a wave walks together end together,
  * and only the 128-byte lines a read's bases lie in are fetched; in the sample's histogram each read then weighs its 16-byte

@@ -102,9 +102,6 @@ struct mpb_ctx {
     bool narrow_ok = false;              // the default table satisfies a == 1 - b for every score (checked by mpb_create)
     void *ws_nar = nullptr;              // wave segments + dense list + per-wave counts / offsets
     int64_t ws_nar_cap = 0;
-    void *fb_block = nullptr;            // the sub-batch the narrow pass could not finish: rows | ee | ns | pass
-    int64_t fb_cap = 0;                  // ... reads it holds
-    int64_t fb_stride = 0;
     int32_t *pin_words = nullptr;        // pinned host words: [0] list count, [16..32) the sample histogram
     struct NarrowChoice {                // the last decision, reused while the batches keep their shape (it steers speed only)
         bool valid = false; int64_t n = 0, stride = 0; int32_t fixed_len = 0; double alpha = 0; uint32_t flags = 0;
@@ -292,7 +289,6 @@ int mpb_destroy(mpb_ctx *c)
     if (c->pin_host) (void)hipHostFree(c->pin_host);
     if (c->pin_words) (void)hipHostFree(c->pin_words);
     if (c->ws_nar) (void)hipFree(c->ws_nar);
-    if (c->fb_block) (void)hipFree(c->fb_block);
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_lut_private) (void)hipFree(c->d_lut_private);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -661,12 +657,13 @@ static int prepare_batch(mpb_ctx *c, int64_t n, int32_t max_len)
 
 // everything after the classification: scan -> scatter -> DP -> wide reads -> overflow pass (-> counts)
 static int filter_device_tail(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len,
-                              const MpbDevParams &prm, double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
+                              const MpbDevParams &prm, double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts,
+                              const int32_t *d_list = nullptr)
 {
     hipStream_t s = c->stream;
     const int32_t max_len = prm.max_len;
     { Span t(c, MPB_K_SCAN);     mpb_launch_scan(n, d_len, c->ws, s); }
-    { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, d_len, d_ns, prm, c->ws, s); }
+    { Span t(c, MPB_K_SCATTER);  mpb_launch_scatter(n, d_len, d_ns, prm, c->ws, s, d_list); }
     { Span t(c, MPB_K_DP);       mpb_launch_dp(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     if (max_len + 1 > MPB_TILE_MAX_ROWS) { Span t(c, MPB_K_WIDE); mpb_launch_wide(d_q, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
     { Span t(c, MPB_K_OVERFLOW); mpb_launch_overflow(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, s); }
@@ -721,40 +718,13 @@ static int ensure_narrow_workspace(mpb_ctx *c, int64_t n)
     return MPB_OK;
 }
 
-// the dense sub-batch of the reads a narrow pass handed back: m rows of `stride` bytes + their results
-struct FallbackBlock { uint8_t *q; double *ee; int32_t *ns; uint8_t *pass; int32_t *len; };
-static int ensure_fallback_block(mpb_ctx *c, int64_t m, int64_t stride, FallbackBlock *out)
-{
-    if (m > c->fb_cap || stride > c->fb_stride) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        serve_quiesce(c);
-        if (c->fb_block) { HIPCHK(hipFree(c->fb_block)); c->fb_block = nullptr; c->fb_cap = 0; c->fb_stride = 0; }
-        const int64_t cap = m + m / 4 + 4096;
-        const int64_t st = stride;
-        const size_t bytes = (size_t)(align_up(cap * st, 256) + align_up(cap * 8, 256) + 2 * align_up(cap * 4, 256) + align_up(cap, 256));
-        if (hipMalloc(&c->fb_block, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            c->fb_block = nullptr;
-            return fail(MPB_E_NOMEM, "no device memory for the sub-batch of %lld reads the narrow pass handed back (%zu bytes)", (long long)m, bytes);
-        }
-        c->fb_cap = cap;
-        c->fb_stride = st;
-    }
-    char *p = (char *)c->fb_block;
-    out->q = (uint8_t *)p; p += align_up(c->fb_cap * c->fb_stride, 256);
-    out->ee = (double *)p; p += align_up(c->fb_cap * 8, 256);
-    out->ns = (int32_t *)p; p += align_up(c->fb_cap * 4, 256);
-    out->len = (int32_t *)p; p += align_up(c->fb_cap * 4, 256);
-    out->pass = (uint8_t *)p;
-    return MPB_OK;
-}
-
 // The choice, from the sample's histogram of rows.  Costs per read in units of 0.083 ms per 10 M reads of 300 bases, fitted to
-// measured steps (profiles/r05_narrow_rate.txt, r05_narrow_mix.txt): the narrow pass 4 + 3 R for every read whatever it needs; the
-// sorted pipeline 9 (classification + sort: its second read of the matrix) + 3.9 per row of the read's class (its predictor gives
-// the few-row reads one row more than they need); a read the narrow pass hands back pays 1.3 x the sorted pipeline (its sub-batch
-// holds only the expensive classes: no narrow tiles to share a CU with, three more passes over its rows) + 3 for the gather and the
-// scatter.  The pass must finish at least 80 % of the sample and promise at least 5 %: measured break-even is near 20 % handed back.
+// measured steps (profiles/r05_narrow_rate.txt; round 6: profiles/r06_narrow_mix.txt, r06_ragged_mix.txt): the narrow pass 4 + 3 R for
+// every read whatever it needs; the sorted pipeline 9 (classification + sort: its second read of the matrix) + 3.9 per row of the
+// read's class (its predictor gives the few-row reads one row more than they need); a read the narrow pass hands back pays the sorted
+// pipeline's cost x 1.05 + 1 -- since round 6 it runs through that pipeline where it lies (round 5 gathered it into a dense sub-batch:
+// x 1.3 + 3), so the pass wins up to about 40 % handed back (round 5: 20 %).  The pass must finish at least 55 % of the sample and
+// promise at least 5 %.
 static int narrow_rows_from_sample(const int32_t *hist, int n_sample)
 {
     if (n_sample <= 0) return 0;
@@ -770,9 +740,9 @@ static int narrow_rows_from_sample(const int32_t *hist, int n_sample)
     for (int R = MPB_NAR_MIN_ROWS; R <= MPB_NAR_MAX_ROWS; R++) {
         int64_t done = 0;
         for (int r = 1; r <= R; r++) done += hist[r];
-        if ((double)done < 0.80 * n_sample) continue;
-        double cost = (double)n_sample * (4.0 + 3.0 * R) + hist[0] * (1.3 * lower_n_cost + 3.0);
-        for (int r = R + 1; r < MPB_NAR_BUCKETS; r++) cost += hist[r] * (1.3 * sorted_cost(r) + 3.0);
+        if ((double)done < 0.55 * n_sample) continue;
+        double cost = (double)n_sample * (4.0 + 3.0 * R) + hist[0] * (1.05 * lower_n_cost + 1.0);
+        for (int r = R + 1; r < MPB_NAR_BUCKETS; r++) cost += hist[r] * (1.05 * sorted_cost(r) + 1.0);
         if (cost < best_cost) { best = R; best_cost = cost; }
     }
     return best;
@@ -786,16 +756,20 @@ static bool narrow_eligible(const mpb_ctx *c, int64_t n, int64_t row_stride, con
     return d_len ? row_stride <= MPB_RG_MAX_STRIDE : fixed_len >= 1;
 }
 
+// d_list != nullptr: the sorted pipeline over the n reads d_list[0 .. n) of a matrix of n_matrix reads (the reads a narrow pass hands
+// back), where they lie: rows, lengths, class bytes and results are addressed by read (so the workspace is sized for the matrix: about
+// 12 bytes per read, what the sorted pipeline would have taken for the same batch), the permutation by position; counts must be NULL.
 static int filter_device_general(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len,
                                  int32_t fixed_len, int32_t max_len, const mpb_filter_params *params,
-                                 double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
+                                 double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts,
+                                 const int32_t *d_list = nullptr, int64_t n_matrix = 0)
 {
     int rc;
-    if ((rc = prepare_batch(c, n, max_len))) return rc;
+    if ((rc = prepare_batch(c, d_list && n_matrix > n ? n_matrix : n, max_len))) return rc;
     const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
     if (params->flags & MPB_FLAG_COUNT_CELLS) HIPCHK(hipMemsetAsync(c->ws.alg_cells, 0, sizeof(unsigned long long), c->stream));
-    { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, c->stream); }
-    return filter_device_tail(c, d_q, n, row_stride, d_len, prm, d_ee, d_ns, d_pass, counts);
+    { Span t(c, MPB_K_PREPASS);  mpb_launch_prepass(d_q, n, row_stride, d_len, prm, c->ws, d_ns, d_ee, d_pass, c->stream, d_list); }
+    return filter_device_tail(c, d_q, n, row_stride, d_len, prm, d_ee, d_ns, d_pass, counts, d_list);
 }
 
 // 0: the sorted pipeline; 2..4: the narrow pass with that many rows.  May draw a sample (one small launch + a synchronisation).
@@ -849,27 +823,22 @@ static int filter_device_narrow(mpb_ctx *c, int rows0, const uint8_t *d_q, int64
     c->last_path.n_fallback = m;
     const bool forced = ((params->flags >> 8) & 15u) != 0;
     // a pass that hands back far more than its sample can have promised: look again next time
-    if (!forced && m > n / 4) c->nar_choice.valid = false;
-    int64_t novf = 0;
+    if (!forced && m > n / 2) c->nar_choice.valid = false;
+    int32_t novf = 0;
     if (m > 0) {
-        // The reads handed back go through the sorted pipeline as a dense sub-batch of their own.  When that sub-batch would be a
-        // large part of the batch (a stale choice met a batch of bad reads: ADVICE r5), or there is no memory for it, the WHOLE
-        // batch takes the sorted pipeline in place instead: the same results, the finished reads are simply computed again.
-        FallbackBlock fb;
-        const bool in_place = (!forced && m > n / 4) || ensure_fallback_block(c, m, row_stride, &fb) != MPB_OK;
-        if (in_place) {
+        // The reads handed back go through the sorted pipeline WHERE THEY LIE (round 6: the prepass and the scatter walk the list,
+        // the DP addresses rows and results by read anyway): no dense copy of their rows, no block of memory for it.  When they
+        // are most of the batch (a stale choice met a batch of bad reads) the whole batch takes the sorted pipeline instead:
+        // the same results, one pass over everything is cheaper than a list of most of it (break-even near one half).
+        if (!forced && m > n / 2) {
             c->last_path.n_fallback = n;
             return filter_device_general(c, d_q, n, row_stride, d_len, fixed_len, prm.max_len, params, d_ee, d_ns, d_pass, counts);
         }
-        { Span t(c, MPB_K_FALLBACK); mpb_launch_gather_rows(d_q, row_stride, d_len, c->ws.nar_list, m, fb.q, d_len ? fb.len : nullptr, s); }
         mpb_filter_params sub = *params;
         sub.flags = (sub.flags & ~(15u << 8)) | MPB_FLAG_NO_NARROW;
-        mpb_filter_counts sc;
-        // the sub-batch's counts are only fetched (a synchronisation) when the caller wants counts
-        if ((rc = filter_device_general(c, fb.q, m, row_stride, d_len ? fb.len : nullptr, fixed_len, prm.max_len, &sub, fb.ee, fb.ns, fb.pass, counts ? &sc : nullptr))) return rc;
-        if (counts) novf = sc.n_overflow;
-        { Span t(c, MPB_K_FALLBACK); mpb_launch_scatter_back(c->ws.nar_list, m, fb.ee, fb.ns, fb.pass, d_ee, d_ns, d_pass, s); }
+        if ((rc = filter_device_general(c, d_q, m, row_stride, d_len, fixed_len, prm.max_len, &sub, d_ee, d_ns, d_pass, nullptr, c->ws.nar_list, n))) return rc;
         HIPCHK(hipGetLastError());
+        if (counts) HIPCHK(hipMemcpyAsync(&novf, c->ws.ovf_count, sizeof(novf), hipMemcpyDeviceToHost, s));
     }
     if (counts) {
         if ((rc = ensure_workspace(c, 1))) return rc;

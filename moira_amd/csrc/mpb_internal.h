@@ -141,9 +141,10 @@ struct MpbWorkspace {
 #define MPB_LAMBDA_MAX_STRIDE (1 << 24)     // k_lambda addresses the 64 rows of a wave with 32-bit byte offsets
 
 // Launch wrappers (mpb_kernels.hip).  All asynchronous on `s`.
+// list != nullptr (round 6): the pass (and the scatter below) runs over the n reads list[0 .. n) of the matrix, not its first n rows
 void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
-                        double *ee_out, uint8_t *pass_out, hipStream_t s);
+                        double *ee_out, uint8_t *pass_out, hipStream_t s, const int32_t *list = nullptr);
 void mpb_launch_decode_classify(const uint8_t *seq, const uint8_t *qual, int32_t offset, uint8_t *out, int32_t *err,
                                 int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                                 const MpbWorkspace &ws, int32_t *ns_out, double *ee_out, uint8_t *pass_out, hipStream_t s);
@@ -185,7 +186,7 @@ struct MpbServeBox {
 void mpb_launch_serve(const MpbServeBox &box, const double2 *lut, uint32_t generation, uint32_t lifetime_ms, hipStream_t s);
 void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipStream_t s);
 void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const MpbDevParams &prm, const MpbWorkspace &ws,
-                        hipStream_t s);
+                        hipStream_t s, const int32_t *list = nullptr);
 void mpb_launch_dp(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                    const MpbDevParams &prm, const MpbWorkspace &ws, const int32_t *ns,
                    double *ee, uint8_t *pass, hipStream_t s);
@@ -215,12 +216,6 @@ void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixe
 void mpb_launch_narrow_ragged(int rows0, const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
                               const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks,
                               hipStream_t s);
-// rows list[0..m) of q -> the dense matrix q2 (m rows of `stride` bytes; their lengths -> len2 when len != nullptr), and
-// results back: ee[list[k]] = ee2[k] ...
-void mpb_launch_gather_rows(const uint8_t *q, int64_t stride, const int32_t *len, const int32_t *list, int64_t m, uint8_t *q2,
-                            int32_t *len2, hipStream_t s);
-void mpb_launch_scatter_back(const int32_t *list, int64_t m, const double *ee2, const int32_t *ns2, const uint8_t *pass2,
-                             double *ee, int32_t *ns, uint8_t *pass, hipStream_t s);
 void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, int32_t min_len,
                       int32_t max_len, int32_t *len, uint64_t seed, int64_t first_read,
                       hipStream_t s, int32_t profile = 0);

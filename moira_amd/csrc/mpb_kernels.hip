@@ -232,6 +232,8 @@ struct PreOut {
 // One read's statistics -> row budget -> class byte, Ns, histogram count (or: settled / wide / bad length).
 // mu, var, k3: fp32 sums of p, p(1-p), p(1-p)(1-2p) over the scored bases; ambi = 'N' count | 'n' count << 16;
 // li = the (clamped) length, bad = the caller-supplied length did not fit the row.
+// i: the read (not its position in the pass, when the pass runs over a LIST of reads: k_prepass<.., LISTED>): class bytes, ns, ee and
+// pass are all indexed by read -- the DP looks a read's class byte up by its id (the 'has an upper-case N' bit, moira.py:911).
 __device__ __forceinline__ void class_read(int64_t i, float mu, float var, float k3, uint32_t ambi, int li, bool bad, bool ragged,
                                            const MpbDevParams &prm, const PreOut &o, int *s_hist, int nb)
 {
@@ -284,10 +286,14 @@ __device__ __forceinline__ void class_read(int64_t i, float mu, float var, float
 // LONG <=> rows of more than 960 bytes: walked in panels (below); the short-row instances are one panel by construction.
 // (Classified at source -- text in, packed matrix out, classified on the way -- is k_classify_linear below: with three
 // streams to move, a linear walk beats this kernel's row-per-lane shape; for the one stream here it is the other way round.)
-template <bool RAGGED, bool LONG>
+// LISTED (round 6) <=> the pass runs over the n reads list[0 .. n) of the matrix instead of its first n rows: the reads a narrow pass
+// hands back are classified where they lie (no dense copy of their rows); everything a read owns -- class byte, ns, ee, pass -- is
+// indexed by the read, so the class-byte array must hold the whole matrix' reads; only the block histograms go by position.
+template <bool RAGGED, bool LONG, bool LISTED>
 __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, int64_t n,
                                                  int64_t stride, const int32_t *__restrict__ len_arg,
-                                                 MpbDevParams prm, PreOut o, int32_t *__restrict__ blockhist)
+                                                 MpbDevParams prm, PreOut o, int32_t *__restrict__ blockhist,
+                                                 const int32_t *__restrict__ list)
 {
     __shared__ float2 s_tab[256];
     __shared__ float4 s_row[4][64];               // per read: {mu, var, k3, ambiguity counts (bits of an int: N | n << 16)}
@@ -310,8 +316,8 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
     if (wave_row0 >= n) break;                    // wave-uniform; nothing below is a block barrier
 
     for (int rb = 0; rb < 64; rb += 16) {
-        const int64_t i = wave_row0 + rb + r16;
-        const bool live = i < n;
+        const bool live = wave_row0 + rb + r16 < n;
+        const int64_t i = LISTED ? (live ? (int64_t)list[wave_row0 + rb + r16] : 0) : wave_row0 + rb + r16;
         const int li = live ? (len ? clamp_len(len[i], prm.max_len) : prm.fixed_len) : 0;
         int ncol = (li + 15) >> 4;                // chunk columns to walk: the longest read of the 16
         int nfull = live ? (li >> 4) : (1 << 20); // columns complete in every live lane
@@ -382,8 +388,9 @@ __global__ __launch_bounds__(256) void k_prepass(const uint8_t *__restrict__ q, 
     wave_lds_fence();          // s_row[w] is private to this wave: no block barrier
     // ---- classing: one lane per read, all 64 lanes busy (was: 16 of 64, four times) ----
     {
-        const int64_t i = wave_row0 + lane;
-        if (i < n) {
+        const int64_t k = wave_row0 + lane;
+        if (k < n) {
+            const int64_t i = LISTED ? (int64_t)list[k] : k;
             const float4 e = s_row[w][lane];
             const int li = len ? clamp_len(len[i], prm.max_len) : prm.fixed_len;
             class_read(i, e.x, e.y, e.z, __float_as_uint(e.w), li, RAGGED && li != len[i], RAGGED, prm, o, s_hist, nb);
@@ -608,7 +615,8 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
                                                  const int32_t *__restrict__ blockhist,
                                                  const MpbTables *__restrict__ tb,
                                                  const int32_t *__restrict__ ns,
-                                                 int32_t *__restrict__ perm, uint16_t *__restrict__ perm_ns)
+                                                 int32_t *__restrict__ perm, uint16_t *__restrict__ perm_ns,
+                                                 const int32_t *__restrict__ list)      // (the pass runs over list[0 .. n): k_prepass<.., LISTED>)
 {
     constexpr int nb = RAGGED ? MPB_LEN_BINS : 1;
     constexpr int nkeys = MPB_NCLS * nb;
@@ -619,13 +627,15 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
     for (int k = tid; k < nkeys; k += 256) s_base[k] = tb->key_base[k] + blockhist[(int64_t)k * gridDim.x + blockIdx.x];
     // everything this thread needs from global memory for all its rounds, requested up front: the rounds
     // themselves are then LDS / ballot work only (they used to pay two dependent HBM round trips each)
-    int kk_r[MPB_PRE_ROUNDS], ns_r[MPB_PRE_ROUNDS], c_r[MPB_PRE_ROUNDS], len_r[MPB_PRE_ROUNDS];
+    int kk_r[MPB_PRE_ROUNDS], ns_r[MPB_PRE_ROUNDS], c_r[MPB_PRE_ROUNDS], len_r[MPB_PRE_ROUNDS], id_r[MPB_PRE_ROUNDS];
 #pragma unroll
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {      // independent loads: all in flight together
-        const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + tid;
-        c_r[round] = i < n ? (int)cls[i] : 0xff;
-        ns_r[round] = i < n ? ns[i] : 0;
-        len_r[round] = (len && i < n) ? len[i] : 0;
+        const int64_t k = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + tid;
+        const int64_t i = (list && k < n) ? (int64_t)list[k] : k;
+        id_r[round] = (int)i;
+        c_r[round] = k < n ? (int)cls[i] : 0xff;
+        ns_r[round] = k < n ? ns[i] : 0;
+        len_r[round] = (len && k < n) ? len[i] : 0;
     }
 #pragma unroll
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
@@ -637,7 +647,6 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
     for (int round = 0; round < MPB_PRE_ROUNDS; round++) {
         for (int k = tid; k < 4 * nkeys; k += 256) (&s_wcnt[0][0])[k] = 0;
         __syncthreads();
-        const int64_t i = (int64_t)blockIdx.x * MPB_PRE_READS + round * 256 + tid;
         const int kk = kk_r[round];
         int rank = 0;
         unsigned long long remaining = __ballot(kk >= 0);
@@ -653,7 +662,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint8_t *__restrict__ cls
         if (kk >= 0) {
             int off = s_base[kk];
             for (int ww = 0; ww < w; ww++) off += s_wcnt[ww][kk];
-            perm[off + rank] = (int32_t)i;
+            perm[off + rank] = (int32_t)id_r[round];
             perm_ns[off + rank] = (uint16_t)ns_r[round];
         }
         __syncthreads();
@@ -2800,39 +2809,6 @@ __global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, i
     }
 }
 
-// the listed rows as a dense matrix: thread per 16-byte chunk
-__global__ __launch_bounds__(256) void k_gather_rows(const uint8_t *__restrict__ q, int64_t stride,
-                                                     const int32_t *__restrict__ list, int64_t m, uint8_t *__restrict__ q2)
-{
-    const int64_t cpr = stride >> 4;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= m * cpr) return;
-    const int64_t k = g / cpr;
-    const int64_t c = g - k * cpr;
-    const int64_t i = list[k];
-    *reinterpret_cast<uint4 *>(q2 + k * stride + c * 16) = *reinterpret_cast<const uint4 *>(q + i * stride + c * 16);
-}
-
-__global__ __launch_bounds__(256) void k_gather_len(const int32_t *__restrict__ len, const int32_t *__restrict__ list, int64_t m,
-                                                    int32_t *__restrict__ len2)
-{
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k < m) len2[k] = len[list[k]];
-}
-
-__global__ __launch_bounds__(256) void k_scatter_back(const int32_t *__restrict__ list, int64_t m,
-                                                      const double *__restrict__ ee2, const int32_t *__restrict__ ns2,
-                                                      const uint8_t *__restrict__ pass2, double *__restrict__ ee,
-                                                      int32_t *__restrict__ ns, uint8_t *__restrict__ pass)
-{
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= m) return;
-    const int64_t i = list[k];
-    ee[i] = ee2[k];
-    ns[i] = ns2[k];
-    pass[i] = pass2[k];
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -2842,14 +2818,19 @@ static inline int pre_blocks(int64_t n) { return (int)((n + MPB_PRE_READS - 1) /
 
 void mpb_launch_prepass(const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
                         const MpbDevParams &prm, const MpbWorkspace &ws, int32_t *ns_out,
-                        double *ee_out, uint8_t *pass_out, hipStream_t s)
+                        double *ee_out, uint8_t *pass_out, hipStream_t s, const int32_t *list)
 {
-#define MPB_PRE_LAUNCH(RG, LG)                                                                                          \
-    hipLaunchKernelGGL((k_prepass<RG, LG>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist)
+#define MPB_PRE_LAUNCH(RG, LG, LS)                                                                                      \
+    hipLaunchKernelGGL((k_prepass<RG, LG, LS>), dim3(pre_blocks(n)), dim3(256), 0, s, q, n, stride, len, prm, o, ws.blockhist, list)
     const PreOut o = {ws.cls, ns_out, ee_out, pass_out, ws.bad_len, ws.wide_list, ws.wide_rows, ws.wide_count};
     const bool long_rows = prm.max_len > 16 * 12 * MPB_PRE_NB;        // more than one panel of 60 chunk columns
-    if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true); else MPB_PRE_LAUNCH(true, false); }
-    else     { if (long_rows) MPB_PRE_LAUNCH(false, true); else MPB_PRE_LAUNCH(false, false); }
+    if (list) {
+        if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true, true); else MPB_PRE_LAUNCH(true, false, true); }
+        else     { if (long_rows) MPB_PRE_LAUNCH(false, true, true); else MPB_PRE_LAUNCH(false, false, true); }
+    } else {
+        if (len) { if (long_rows) MPB_PRE_LAUNCH(true, true, false); else MPB_PRE_LAUNCH(true, false, false); }
+        else     { if (long_rows) MPB_PRE_LAUNCH(false, true, false); else MPB_PRE_LAUNCH(false, false, false); }
+    }
 #undef MPB_PRE_LAUNCH
 }
 
@@ -2881,14 +2862,14 @@ void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipS
 }
 
 void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const MpbDevParams &prm, const MpbWorkspace &ws,
-                        hipStream_t s)
+                        hipStream_t s, const int32_t *list)
 {
     if (len)
         hipLaunchKernelGGL((k_scatter<true>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len, prm.len_shift,
-                           ws.blockhist, ws.tables, ns, ws.perm, ws.perm_ns);
+                           ws.blockhist, ws.tables, ns, ws.perm, ws.perm_ns, list);
     else
         hipLaunchKernelGGL((k_scatter<false>), dim3(pre_blocks(n)), dim3(256), 0, s, ws.cls, n, len, prm.max_len, prm.len_shift,
-                           ws.blockhist, ws.tables, ns, ws.perm, ws.perm_ns);
+                           ws.blockhist, ws.tables, ns, ws.perm, ws.perm_ns, list);
 }
 
 // cap of the DP grid (blocks of 4 waves); beyond it the chunk loop strides
@@ -3146,16 +3127,3 @@ void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixe
     hipLaunchKernelGGL(k_sample, dim3((unsigned)((n_sample + 3) / 4)), dim3(256), 0, s, q, n, stride, fixed_len, len, prm, n_sample, ws.nar_sample);
 }
 
-void mpb_launch_gather_rows(const uint8_t *q, int64_t stride, const int32_t *len, const int32_t *list, int64_t m, uint8_t *q2,
-                            int32_t *len2, hipStream_t s)
-{
-    const int64_t chunks = m * (stride / 16);
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, q, stride, list, m, q2);
-    if (len) hipLaunchKernelGGL(k_gather_len, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, len, list, m, len2);
-}
-
-void mpb_launch_scatter_back(const int32_t *list, int64_t m, const double *ee2, const int32_t *ns2, const uint8_t *pass2,
-                             double *ee, int32_t *ns, uint8_t *pass, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_scatter_back, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, list, m, ee2, ns2, pass2, ee, ns, pass);
-}

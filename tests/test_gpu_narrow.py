@@ -207,11 +207,12 @@ def test_high_quality_full_size(eng, oracle):
             b.free()
 
 
-def test_no_memory_for_the_handed_back_reads_runs_the_batch_in_place(eng, oracle):
-    """the sub-batch of the reads a narrow pass hands back needs memory of its own (rows + results).  When there is none
-    -- here: the test takes nearly all of the device's free memory first -- the call must not fail with MPB_E_NOMEM: the whole batch
-    goes through the sorted pipeline in place (the same results; the finished reads are computed again).  And when a stale choice
-    meets a batch of bad reads (more than a quarter handed back, pass not forced) the same happens without the allocation being tried."""
+def test_the_handed_back_reads_need_no_memory_of_their_own(eng, oracle):
+    """ADVICE r5 (a stale choice + a tight HBM budget made the call fail with MPB_E_NOMEM: the reads a narrow pass handed back were
+    gathered into a dense block of their own).  Round 6: they run through the sorted pipeline where they lie (the prepass and the
+    scatter walk the list), so the call needs no block at all -- here the test takes nearly all of the device's free memory first,
+    forces the pass on BASELINE's model (most reads handed back) and gets the oracle's results.  And when a stale choice meets a batch
+    of bad reads (more than a quarter handed back, pass not forced) the whole batch takes the sorted pipeline (n_fallback == n)."""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
     n, stride, L = 1_500_000, 320, 300
@@ -223,17 +224,17 @@ def test_no_memory_for_the_handed_back_reads_runs_the_batch_in_place(eng, oracle
     try:
         d_q.upload(q)
         prm = eng.params(narrow_rows=2)
-        # once with room: workspaces of the pass and of the sorted pipeline exist from here on (only the sub-batch block is missing later)
-        eng.filter_device(d_q, 4096, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm)
-        eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=eng.params(no_narrow=True))
+        # once with room: the workspaces of the pass and of the sorted pipeline exist from here on
+        eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm)
         free, total = C.c_size_t(0), C.c_size_t(0)
         assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
         handed = int((need > 2).sum())
-        assert handed * (stride + 17) > 200 << 20                                  # the block it would need: hundreds of MB
-        hog = eng.alloc(max(1, free.value - (96 << 20)))                           # leave less than 100 MB
+        assert handed * (stride + 17) > 200 << 20                                  # what a dense copy of them would take: hundreds of MB
+        hog = eng.alloc(max(1, free.value - (64 << 20)))                           # leave about 64 MB
+        d_ee.upload(np.full(n, -7.0))
         c = eng.filter_device(d_q, n, stride, fixed_len=L, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass, params=prm)
         path = eng.last_path()
-        assert path["narrow_rows"] == 2 and path["n_fallback"] == n                # everything went through the sorted pipeline
+        assert path["narrow_rows"] == 2 and path["n_fallback"] == handed
         assert same(d_ee.download(np.float64, n), ee) and np.array_equal(d_ns.download(np.int32, n), ns)
         assert np.array_equal(d_pass.download(np.uint8, n), ps) and c.n_pass == int(ps.sum())
     finally:

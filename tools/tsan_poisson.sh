@@ -10,10 +10,10 @@ cat > $D/stubs.cpp <<'CPP'
 #include "mpb_internal.h"
 #include <cstdlib>
 #define STUB { abort(); }
-void mpb_launch_prepass(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int32_t *, double *, uint8_t *, hipStream_t) STUB
+void mpb_launch_prepass(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int32_t *, double *, uint8_t *, hipStream_t, const int32_t *) STUB
 void mpb_launch_small(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int32_t *, double *, uint8_t *, hipStream_t, const MpbSmallHost *) STUB
 void mpb_launch_scan(int64_t, const int32_t *, const MpbWorkspace &, hipStream_t) STUB
-void mpb_launch_scatter(int64_t, const int32_t *, const int32_t *, const MpbDevParams &, const MpbWorkspace &, hipStream_t) STUB
+void mpb_launch_scatter(int64_t, const int32_t *, const int32_t *, const MpbDevParams &, const MpbWorkspace &, hipStream_t, const int32_t *) STUB
 void mpb_launch_dp(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, const int32_t *, double *, uint8_t *, hipStream_t) STUB
 void mpb_launch_overflow(const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, const int32_t *, double *, uint8_t *, hipStream_t) STUB
 void mpb_launch_lambda(const uint8_t *, int64_t, int64_t, const int32_t *, int32_t, const double2 *, double *, int32_t *, int32_t *, hipStream_t) STUB
@@ -26,8 +26,6 @@ void mpb_launch_synth(uint8_t *, int64_t, int64_t, int32_t, int32_t, int32_t, in
 void mpb_launch_narrow(int, const uint8_t *, int64_t, int64_t, int32_t, const MpbDevParams &, const MpbWorkspace &, double *, int32_t *, uint8_t *, int32_t *, int, hipStream_t) STUB
 void mpb_launch_sample(const uint8_t *, int64_t, int64_t, int32_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int, hipStream_t) STUB
 void mpb_launch_narrow_ragged(int, const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, double *, int32_t *, uint8_t *, int32_t *, int, hipStream_t) STUB
-void mpb_launch_gather_rows(const uint8_t *, int64_t, const int32_t *, const int32_t *, int64_t, uint8_t *, int32_t *, hipStream_t) STUB
-void mpb_launch_scatter_back(const int32_t *, int64_t, const double *, const int32_t *, const uint8_t *, double *, int32_t *, uint8_t *, hipStream_t) STUB
 void mpb_launch_serve(const MpbServeBox &, const double2 *, uint32_t, uint32_t, hipStream_t) STUB
 int mpb_narrow_lds_bytes() { return 1 << 15; }
 int mpb_narrow_rs_lds_bytes() { return 1 << 15; }
