@@ -93,6 +93,10 @@ extern "C" {
                                     whatever the sample says and however small the batch; reads it cannot finish still go through the
                                     sorted pipeline, so results are identical. */
 
+#define MPB_FLAG_NARROW_SPLIT(c) (((uint32_t)(c) & 255u) << 12)   /* test / measurement hook, with MPB_FLAG_NARROW_ROWS(r >= 3) on a
+                                    ragged batch: groups of the pass whose longest read has at most c 16-byte chunks run with r - 1
+                                    rows ("mixed rows"; the library picks c from its sample by itself).  Results are identical. */
+
 /* kernel ids for mpb_kernel_time() */
 #define MPB_K_PREPASS   0   /* lambda/sigma/Ns estimate + row classing        */
 #define MPB_K_SCAN      1   /* class histogram scan / tile table              */
@@ -510,6 +514,9 @@ typedef struct mpb_path_info {
     int32_t sampled;
     int64_t n_fallback;
     int32_t sample_hist[16];
+    int32_t narrow_split;   /* round 6, ragged batches with narrow_rows >= 3: groups of the pass whose longest read has at most this
+                               many 16-byte chunks ran with narrow_rows - 1 rows (0: none) */
+    int32_t reserved_;
 } mpb_path_info;
 int mpb_last_path(mpb_ctx *ctx, mpb_path_info *out);
 

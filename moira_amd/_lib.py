@@ -42,7 +42,7 @@ class FilterParams(C.Structure):
 
 class PathInfo(C.Structure):
     _fields_ = [("narrow_rows", C.c_int32), ("sampled", C.c_int32), ("n_fallback", C.c_int64),
-                ("sample_hist", C.c_int32 * 16)]
+                ("sample_hist", C.c_int32 * 16), ("narrow_split", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class FilterCounts(C.Structure):

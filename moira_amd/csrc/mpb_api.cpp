@@ -105,7 +105,7 @@ struct mpb_ctx {
     int32_t *pin_words = nullptr;        // pinned host words: [0] list count, [16..32) the sample histogram
     struct NarrowChoice {                // the last decision, reused while the batches keep their shape (it steers speed only)
         bool valid = false; int64_t n = 0, stride = 0; int32_t fixed_len = 0; double alpha = 0; uint32_t flags = 0;
-        int rows0 = 0; int calls = 0;
+        int rows0 = 0; int split = 0; int calls = 0;
     } nar_choice;
     mpb_path_info last_path{};
     // ---- the per-read entry's resident server (round 5; k_serve with ONE mailbox entry, see serve_one) ----
@@ -773,34 +773,50 @@ static int filter_device_general(mpb_ctx *c, const uint8_t *d_q, int64_t n, int6
 }
 
 // 0: the sorted pipeline; 2..4: the narrow pass with that many rows.  May draw a sample (one small launch + a synchronisation).
+// *split (ragged batches, *rows0 >= 3): groups whose longest read has at most that many 16-byte chunks run with a row less (0: none)
 static int narrow_choose(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len, int32_t fixed_len,
-                         const mpb_filter_params *params, const MpbDevParams &prm, int *rows0)
+                         const mpb_filter_params *params, const MpbDevParams &prm, int *rows0, int *split)
 {
     *rows0 = 0;
+    *split = 0;
     c->last_path.sampled = 0;
     const int forced = (int)((params->flags >> 8) & 15u);
-    if (forced) { *rows0 = forced < MPB_NAR_MIN_ROWS ? MPB_NAR_MIN_ROWS : forced > MPB_NAR_MAX_ROWS ? MPB_NAR_MAX_ROWS : forced; return MPB_OK; }
+    if (forced) {
+        *rows0 = forced < MPB_NAR_MIN_ROWS ? MPB_NAR_MIN_ROWS : forced > MPB_NAR_MAX_ROWS ? MPB_NAR_MAX_ROWS : forced;
+        *split = d_len ? (int)((params->flags >> 12) & 255u) : 0;          // MPB_FLAG_NARROW_SPLIT (test / measurement hook)
+        return MPB_OK;
+    }
     if (n < MPB_NAR_AUTO_MIN_READS) return MPB_OK;
     auto &ch = c->nar_choice;
     if (d_len) fixed_len = -1;                                // (a ragged batch of the same shape is another batch)
     const bool same = ch.valid && ch.n == n && ch.stride == row_stride && ch.fixed_len == fixed_len &&
                       memcmp(&ch.alpha, &params->alpha, sizeof(double)) == 0 && ch.flags == params->flags;
-    if (same && ch.calls < 64) { ch.calls++; *rows0 = ch.rows0; return MPB_OK; }
+    if (same && ch.calls < 64) { ch.calls++; *rows0 = ch.rows0; *split = ch.split; return MPB_OK; }
     // a sample of <= 0.1 % of the reads: the prepass' row prediction on 256 .. 4096 reads spread over the batch
     int n_sample = (int)(n / 1024 < 256 ? 256 : n / 1024 > 4096 ? 4096 : n / 1024);
     { Span t(c, MPB_K_SAMPLE); mpb_launch_sample(d_q, n, row_stride, fixed_len, d_len, prm, c->ws, n_sample, c->stream); }
-    HIPCHK(hipMemcpyAsync(c->pin_words + 16, c->ws.nar_sample, MPB_NAR_BUCKETS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->pin_words + 16, c->ws.nar_sample, (MPB_NAR_BUCKETS + 2) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->last_path.sampled = 1;
     int weight = 0;                                           // reads, or (ragged batches) their 16-byte chunks
     for (int k = 0; k < MPB_NAR_BUCKETS; k++) { c->last_path.sample_hist[k] = c->pin_words[16 + k]; weight += c->pin_words[16 + k]; }
     *rows0 = narrow_rows_from_sample(c->pin_words + 16, weight);
+    if (d_len && *rows0 >= 3) {
+        // mixed rows: the shortest sampled read that needs rows0 rows has `need` chunks; groups safely below it take a row less
+        // (a tenth of margin, at least one chunk; not worth a second code path below four chunks)
+        const int need = c->pin_words[16 + MPB_NAR_BUCKETS + (*rows0 - 3)];
+        if (need > 0 && need < (1 << 20)) {
+            const int cut = need - 1 - need / 10;
+            if (cut >= 4) *split = cut > 255 ? 255 : cut;
+        }
+    }
+    ch.split = *split;
     ch.valid = true; ch.n = n; ch.stride = row_stride; ch.fixed_len = fixed_len; ch.alpha = params->alpha; ch.flags = params->flags;
     ch.rows0 = *rows0; ch.calls = 0;
     return MPB_OK;
 }
 
-static int filter_device_narrow(mpb_ctx *c, int rows0, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len,
+static int filter_device_narrow(mpb_ctx *c, int rows0, int split, const uint8_t *d_q, int64_t n, int64_t row_stride, const int32_t *d_len,
                                 int32_t fixed_len, const mpb_filter_params *params, const MpbDevParams &prm,
                                 double *d_ee, int32_t *d_ns, uint8_t *d_pass, mpb_filter_counts *counts)
 {
@@ -813,13 +829,14 @@ static int filter_device_narrow(mpb_ctx *c, int rows0, const uint8_t *d_q, int64
     const int per_cu = (160 * 1024) / lds;
     const int grid = (c->n_cu > 0 ? c->n_cu : 256) * (per_cu > 0 ? per_cu : 1);
     { Span t(c, MPB_K_NARROW);
-      if (d_len) mpb_launch_narrow_ragged(rows0, d_q, n, row_stride, d_len, prm, c->ws, d_ee, d_ns, d_pass, c->ws.nar_list, grid, s);
+      if (d_len) mpb_launch_narrow_ragged(rows0, split, d_q, n, row_stride, d_len, prm, c->ws, d_ee, d_ns, d_pass, c->ws.nar_list, grid, s);
       else mpb_launch_narrow(rows0, d_q, n, row_stride, fixed_len, prm, c->ws, d_ee, d_ns, d_pass, c->ws.nar_list, grid, s); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->pin_words, c->ws.nar_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const int64_t m = c->pin_words[0];
     c->last_path.narrow_rows = rows0;
+    c->last_path.narrow_split = d_len && rows0 >= 3 ? split : 0;
     c->last_path.n_fallback = m;
     const bool forced = ((params->flags >> 8) & 15u) != 0;
     // a pass that hands back far more than its sample can have promised: look again next time
@@ -835,7 +852,7 @@ static int filter_device_narrow(mpb_ctx *c, int rows0, const uint8_t *d_q, int64
             return filter_device_general(c, d_q, n, row_stride, d_len, fixed_len, prm.max_len, params, d_ee, d_ns, d_pass, counts);
         }
         mpb_filter_params sub = *params;
-        sub.flags = (sub.flags & ~(15u << 8)) | MPB_FLAG_NO_NARROW;
+        sub.flags = (sub.flags & ~((15u << 8) | (255u << 12))) | MPB_FLAG_NO_NARROW;
         if ((rc = filter_device_general(c, d_q, m, row_stride, d_len, fixed_len, prm.max_len, &sub, d_ee, d_ns, d_pass, nullptr, c->ws.nar_list, n))) return rc;
         HIPCHK(hipGetLastError());
         if (counts) HIPCHK(hipMemcpyAsync(&novf, c->ws.ovf_count, sizeof(novf), hipMemcpyDeviceToHost, s));
@@ -878,9 +895,9 @@ int mpb_filter_device(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_str
     if ((rc = ensure_workspace(c, 1))) return rc;    // the small block (tables, counters) exists from here on
     if (narrow_eligible(c, n, row_stride, d_len, fixed_len, params)) {
         const MpbDevParams prm = make_dev_params(params, fixed_len, max_len);
-        int rows0 = 0;
-        if ((rc = narrow_choose(c, d_q, n, row_stride, d_len, fixed_len, params, prm, &rows0))) return rc;
-        if (rows0) return filter_device_narrow(c, rows0, d_q, n, row_stride, d_len, fixed_len, params, prm, d_ee, d_ns, d_pass, counts);
+        int rows0 = 0, split = 0;
+        if ((rc = narrow_choose(c, d_q, n, row_stride, d_len, fixed_len, params, prm, &rows0, &split))) return rc;
+        if (rows0) return filter_device_narrow(c, rows0, split, d_q, n, row_stride, d_len, fixed_len, params, prm, d_ee, d_ns, d_pass, counts);
     }
     return filter_device_general(c, d_q, n, row_stride, d_len, fixed_len, max_len, params, d_ee, d_ns, d_pass, counts);
 }

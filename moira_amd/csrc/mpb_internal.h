@@ -114,7 +114,8 @@ struct MpbWorkspace {
     int32_t  *nar_seg;     // [n + 64] ... as the waves of k_narrow listed them, a segment per wave
     int32_t  *nar_list;    // [n + 64] ... compacted: the dense list the sub-batch is gathered by
     int32_t  *nar_wave_count, *nar_wave_off;   // [MPB_NAR_MAX_WAVES] entries of each wave's segment / where it goes in nar_list
-    int32_t  *nar_sample;  // [MPB_NAR_BUCKETS] histogram of the batch sample that picks the pass (k_sample)
+    int32_t  *nar_sample;  // [MPB_NAR_BUCKETS + 2] histogram of the batch sample that picks the pass (k_sample) + the chunks of the
+                           // shortest sampled reads that need a third / a fourth row (ragged batches)
     // the narrow pass of RAGGED batches (k_narrow_rg, round 6)
     int2     *rg_ord;      // [n + 64] {read, length} in the order the pass walks them: windows of 4096 reads sorted by length
     int32_t  *rg_gpre;     // [n / 64 + 2] cost of each group of 64 entries (from its longest read), summed up inside its window
@@ -213,9 +214,10 @@ void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixe
                        const MpbWorkspace &ws, int n_sample, hipStream_t s);
 // the narrow pass of a RAGGED batch (k_rag_sort, k_rag_plan, k_narrow_rg): rows of up to MPB_RG_MAX_STRIDE bytes
 #define MPB_RG_MAX_STRIDE 4096
-void mpb_launch_narrow_ragged(int rows0, const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
-                              const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks,
-                              hipStream_t s);
+// split_chunks > 0 (rows0 >= 3): groups whose longest read has at most that many 16-byte chunks run with rows0 - 1 rows
+void mpb_launch_narrow_ragged(int rows0, int split_chunks, const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
+                              const MpbDevParams &prm, const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list,
+                              int grid_blocks, hipStream_t s);
 void mpb_launch_synth(uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, int32_t min_len,
                       int32_t max_len, int32_t *len, uint64_t seed, int64_t first_read,
                       hipStream_t s, int32_t profile = 0);

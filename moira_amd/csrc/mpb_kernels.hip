@@ -2367,6 +2367,7 @@ __device__ __forceinline__ uint32_t rg_block_excl_scan(uint32_t x, uint32_t *s_w
 // bytes: one b128 read, one write; the 256 partial sums by lane shuffles), and the thread places its elements in order.  28 KB of
 // LDS: five workgroups per CU (a block's life is a chain of LDS latencies and barriers, so what counts is how many run at once).
 __global__ __launch_bounds__(256) void k_rag_sort(const int32_t *__restrict__ len, int64_t n, int32_t max_len, int key_shift,
+                                                  int32_t split, int32_t low_pct,
                                                   int2 *__restrict__ ord, int32_t *__restrict__ gpre,
                                                   unsigned long long *__restrict__ wsum)
 {
@@ -2458,7 +2459,9 @@ __global__ __launch_bounds__(256) void k_rag_sort(const int32_t *__restrict__ le
         int c = 0;
         if (lane * 64 < m) {
             const uint32_t k = key_of(s_len[s_idx[1][min(m, lane * 64 + 64) - 1]]);
-            c = rg_group_cost((int)(key_shift ? ((k + 1) << key_shift) - 1 : k));
+            const int chunks = (int)(key_shift ? ((k + 1) << key_shift) - 1 : k);
+            c = rg_group_cost(chunks) * 8;                      // (eighths, so that the short groups' discount has a resolution)
+            if (chunks <= split) c = c * low_pct / 100;         // mixed rows: a group that runs with a row less is that much cheaper
         }
         int pre = c;
 #pragma unroll
@@ -2519,10 +2522,14 @@ __device__ __forceinline__ int rg_first_group(const unsigned long long *__restri
     return lo * 64 + (m ? __builtin_ctzll(m) : ng - 1);
 }
 
-template <int R>
+// RLO < R (round 6, "mixed rows"): a group whose longest read has at most `split` chunks runs with RLO rows, the others with R --
+// how many rows a read of a given quality needs grows with its length (a clean read needs the third row from about 400 bases on), the
+// groups are sorted by length, and a row less is 3 of a base's 7 FP64 operations.  `split` comes from the batch's sample (the shortest
+// sampled read that needs R rows, less a margin); a read of a short group that needs R rows after all is handed back like any other.
+template <int R, int RLO>
 __global__ __launch_bounds__(256, 4) void k_narrow_rg(const uint8_t *__restrict__ q, int64_t n, int64_t stride,
                                                    const int2 *__restrict__ ord, const unsigned long long *__restrict__ wpre,
-                                                   const int32_t *__restrict__ gpre, int32_t *__restrict__ gstart,
+                                                   const int32_t *__restrict__ gpre, int32_t *__restrict__ gstart, int32_t split,
                                                    MpbDevParams prm, const double2 *__restrict__ lut_g,
                                                    double *__restrict__ ee, int32_t *__restrict__ ns, uint8_t *__restrict__ pass,
                                                    int32_t *__restrict__ seg, int32_t *__restrict__ wave_count)
@@ -2635,11 +2642,21 @@ __global__ __launch_bounds__(256, 4) void k_narrow_rg(const uint8_t *__restrict_
                             wd[4 * c + d] = mask_dword(wd[4 * c + d], nbl - 16 * c - 4 * d);                 \
                     }                                                                                        \
                 }
-                switch (rem >= 4 ? 4 : rem) {
-                case 4: { NRG_LOAD(4) nar_run<R, 16>(v, nonzero, s_p, wd); break; }
-                case 3: { NRG_LOAD(3) nar_run<R, 12>(v, nonzero, s_p, wd); break; }
-                case 2: { NRG_LOAD(2) nar_run<R, 8>(v, nonzero, s_p, wd); break; }
-                default: { NRG_LOAD(1) nar_run<R, 4>(v, nonzero, s_p, wd); break; }
+                if (RLO < R && cur_maxc <= split) {               // a short group: rows 0 .. RLO-1 only (v[RLO ..] stay zero)
+                    double (&vl)[RLO] = *reinterpret_cast<double (*)[RLO]>(&v[0]);
+                    switch (rem >= 4 ? 4 : rem) {
+                    case 4: { NRG_LOAD(4) nar_run<RLO, 16>(vl, nonzero, s_p, wd); break; }
+                    case 3: { NRG_LOAD(3) nar_run<RLO, 12>(vl, nonzero, s_p, wd); break; }
+                    case 2: { NRG_LOAD(2) nar_run<RLO, 8>(vl, nonzero, s_p, wd); break; }
+                    default: { NRG_LOAD(1) nar_run<RLO, 4>(vl, nonzero, s_p, wd); break; }
+                    }
+                } else {
+                    switch (rem >= 4 ? 4 : rem) {
+                    case 4: { NRG_LOAD(4) nar_run<R, 16>(v, nonzero, s_p, wd); break; }
+                    case 3: { NRG_LOAD(3) nar_run<R, 12>(v, nonzero, s_p, wd); break; }
+                    case 2: { NRG_LOAD(2) nar_run<R, 8>(v, nonzero, s_p, wd); break; }
+                    default: { NRG_LOAD(1) nar_run<R, 4>(v, nonzero, s_p, wd); break; }
+                    }
                 }
 #undef NRG_LOAD
             }
@@ -2806,6 +2823,11 @@ __global__ __launch_bounds__(256) void k_sample(const uint8_t *__restrict__ q, i
         rows = max(min(rows, li - ambi + 1), 1);
         atomicAdd(hist + ((lower > 0 || bad_len) ? 0 : min(rows, MPB_NAR_BUCKETS - 1)),      // an 'n' is what the narrow pass hands back
                   len ? max(1, (li + 15) >> 4) : 1);
+        // ragged batches: the shortest sampled reads (in chunks) that need a third / a fourth row (k_narrow_rg's mixed rows)
+        if (len && lower == 0 && !bad_len) {
+            if (rows >= 3) atomicMin(hist + MPB_NAR_BUCKETS, (li + 15) >> 4);
+            if (rows >= 4) atomicMin(hist + MPB_NAR_BUCKETS + 1, (li + 15) >> 4);
+        }
     }
 }
 
@@ -3083,9 +3105,9 @@ int mpb_narrow_rg_key_shift(int64_t stride)
     return ks;
 }
 
-void mpb_launch_narrow_ragged(int rows0, const uint8_t *q, int64_t n, int64_t stride, const int32_t *len, const MpbDevParams &prm,
-                              const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list, int grid_blocks,
-                              hipStream_t s)
+void mpb_launch_narrow_ragged(int rows0, int split_chunks, const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
+                              const MpbDevParams &prm, const MpbWorkspace &ws, double *ee, int32_t *ns, uint8_t *pass, int32_t *list,
+                              int grid_blocks, hipStream_t s)
 {
     const int64_t ngroups = (n + 63) / 64, nwin = (n + MPB_RG_WIN - 1) / MPB_RG_WIN;
     int64_t blocks = (ngroups + 3) / 4;
@@ -3095,7 +3117,7 @@ void mpb_launch_narrow_ragged(int rows0, const uint8_t *q, int64_t n, int64_t st
     const int ri = rows0 < 2 ? 2 : rows0 > 4 ? 4 : rows0;
     if (!per_cu[ri]) {
         int nb = 0;
-        const void *fn = ri == 2 ? (const void *)k_narrow_rg<2> : ri == 3 ? (const void *)k_narrow_rg<3> : (const void *)k_narrow_rg<4>;
+        const void *fn = ri == 2 ? (const void *)k_narrow_rg<2, 2> : ri == 3 ? (const void *)k_narrow_rg<3, 2> : (const void *)k_narrow_rg<4, 3>;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
         per_cu[ri] = nb;
     }
@@ -3108,13 +3130,16 @@ void mpb_launch_narrow_ragged(int rows0, const uint8_t *q, int64_t n, int64_t st
     if (blocks > MPB_NAR_MAX_WAVES / 4) blocks = MPB_NAR_MAX_WAVES / 4;
     if (blocks < 1) blocks = 1;
     const int nwaves = (int)blocks * 4;
-    hipLaunchKernelGGL(k_rag_sort, dim3((unsigned)nwin), dim3(256), 0, s, len, n, prm.max_len, mpb_narrow_rg_key_shift(stride), ws.rg_ord, ws.rg_gpre, ws.rg_wsum);
+    // (what a short group costs against a full one, from the pure kernels' times at R - 1 and R: 0.86 at 2 / 3, 0.80 at 3 / 4)
+    hipLaunchKernelGGL(k_rag_sort, dim3((unsigned)nwin), dim3(256), 0, s, len, n, prm.max_len, mpb_narrow_rg_key_shift(stride),
+                       split_chunks > 0 && rows0 >= 3 ? split_chunks : -1, rows0 >= 4 ? 80 : 86, ws.rg_ord, ws.rg_gpre, ws.rg_wsum);
     hipLaunchKernelGGL(k_rag_scan, dim3(1), dim3(1024), 0, s, ws.rg_wsum, (int)nwin, ws.rg_wpre);
-#define MPB_NRG_LAUNCH(RR) hipLaunchKernelGGL((k_narrow_rg<RR>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, ws.rg_ord, ws.rg_wpre, ws.rg_gpre, ws.rg_gstart, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
+#define MPB_NRG_LAUNCH(RR, RL) hipLaunchKernelGGL((k_narrow_rg<RR, RL>), dim3((unsigned)blocks), dim3(256), 0, s, q, n, stride, ws.rg_ord, ws.rg_wpre, ws.rg_gpre, ws.rg_gstart, split_chunks, prm, ws.lut, ee, ns, pass, ws.nar_seg, ws.nar_wave_count)
+    const bool mixed = split_chunks > 0 && rows0 >= 3;       // short groups with a row less (k_narrow_rg<R, R - 1>)
     switch (rows0) {
-    case 2: MPB_NRG_LAUNCH(2); break;
-    case 3: MPB_NRG_LAUNCH(3); break;
-    default: MPB_NRG_LAUNCH(4); break;
+    case 2: MPB_NRG_LAUNCH(2, 2); break;
+    case 3: if (mixed) MPB_NRG_LAUNCH(3, 2); else MPB_NRG_LAUNCH(3, 3); break;
+    default: if (mixed) MPB_NRG_LAUNCH(4, 3); else MPB_NRG_LAUNCH(4, 4); break;
     }
 #undef MPB_NRG_LAUNCH
     hipLaunchKernelGGL(k_nar_compact, dim3((unsigned)nwaves), dim3(256), 0, s, ws.nar_seg, ws.nar_wave_count, (int64_t)0, nwaves, 64, ws.rg_gstart, list, ws.nar_count);
@@ -3124,6 +3149,7 @@ void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixe
                        const MpbWorkspace &ws, int n_sample, hipStream_t s)
 {
     (void)hipMemsetAsync(ws.nar_sample, 0, MPB_NAR_BUCKETS * sizeof(int32_t), s);
+    (void)hipMemsetAsync(ws.nar_sample + MPB_NAR_BUCKETS, 0x7f, 2 * sizeof(int32_t), s);       // the two minima: 0x7f7f7f7f = none
     hipLaunchKernelGGL(k_sample, dim3((unsigned)((n_sample + 3) / 4)), dim3(256), 0, s, q, n, stride, fixed_len, len, prm, n_sample, ws.nar_sample);
 }
 

@@ -124,14 +124,14 @@ class Engine:
     @staticmethod
     def params(alpha=0.005, uncert=0.01, maxerrors=None, ambigs="treat_as_errors", round_=False,
                fast_fma=False, test_underpredict=False, decision_only=False, batched_only=False, count_cells=False,
-               no_narrow=False, narrow_rows=0):
+               no_narrow=False, narrow_rows=0, narrow_split=0):
         if ambigs not in L.AMBIG:
             raise ValueError("ambigs must be one of %s" % sorted(L.AMBIG))
         flags = (L.FLAG_ROUND if round_ else 0) | (L.FLAG_FAST_FMA if fast_fma else 0) | \
                 (L.FLAG_TEST_UNDERPREDICT if test_underpredict else 0) | \
                 (L.FLAG_DECISION_ONLY if decision_only else 0) | \
                 (L.FLAG_BATCHED_ONLY if batched_only else 0) | (L.FLAG_COUNT_CELLS if count_cells else 0) | \
-                (L.FLAG_NO_NARROW if no_narrow else 0) | L.FLAG_NARROW_ROWS(narrow_rows)
+                (L.FLAG_NO_NARROW if no_narrow else 0) | L.FLAG_NARROW_ROWS(narrow_rows) | ((int(narrow_split) & 255) << 12)
         return L.FilterParams(float(alpha), float(uncert),
                               math.nan if maxerrors is None else float(maxerrors),
                               L.AMBIG[ambigs], flags)
@@ -338,11 +338,11 @@ class Engine:
                                                        ptr(d_len) if d_len is not None else None, seed, first_read, profile))
 
     def last_path(self):
-        """Which pass the last filter_device call took: dict(narrow_rows, sampled, n_fallback, sample_hist)."""
+        """Which pass the last filter_device call took: dict(narrow_rows, narrow_split, sampled, n_fallback, sample_hist)."""
         info = L.PathInfo()
         L.check(self.lib.mpb_last_path(self.ctx, C.byref(info)))
         return {"narrow_rows": info.narrow_rows, "sampled": bool(info.sampled), "n_fallback": info.n_fallback,
-                "sample_hist": list(info.sample_hist)}
+                "sample_hist": list(info.sample_hist), "narrow_split": info.narrow_split}
 
     # ---- measurement ----------------------------------------------------------------------------
     def timing(self, on=True):

@@ -131,6 +131,44 @@ def test_reference_vectors_as_they_are(eng):
     assert done > 10_000
 
 
+@pytest.mark.parametrize("rows,split", [(3, 4), (3, 12), (3, 20), (3, 30), (3, 38), (3, 255), (4, 10), (4, 25)])
+@pytest.mark.parametrize("profile", [0, 1])
+def test_mixed_rows(eng, oracle, rows, split, profile):
+    """Mixed rows (k_narrow_rg<R, R - 1>): groups whose longest read has at most `split` chunks run with a row less.  Whatever the
+    split -- below every read, in the middle of the length range, above every read -- the results are the oracle's: a read of a
+    short group that needs the row it did not get is handed back like any other."""
+    n = 40_000 + split
+    q, lens = oracle.synth_fill(n, 640, min_len=50, max_len=600, seed=17, profile=profile)
+    ee, ns, ps, need = oracle.filter_batch(q, lens=lens, threads=8)
+    e1, n1, p1, c, path = run_ragged(eng, q, lens, narrow_rows=rows, narrow_split=split)
+    assert path["narrow_rows"] == rows and path["narrow_split"] == split
+    assert same(e1, ee) and np.array_equal(n1, ns) and np.array_equal(p1, ps) and c.n_pass == int(ps.sum())
+    # at least the reads that need more than `rows` rows are handed back, at most those that need more than rows - 1
+    assert int((need > rows).sum()) <= path["n_fallback"] <= int((need > rows - 1).sum())
+    if split == 255:
+        assert path["n_fallback"] == int((need > rows - 1).sum())       # every group is a short one
+
+
+def test_the_library_mixes_rows_by_itself_on_clean_ragged_reads(eng, oracle):
+    """Clean reads of 50..600 bases need a third row from about 400 bases on: the library takes three rows, and two for the groups
+    safely below the shortest sampled read that needs the third (mpb_path_info.narrow_split); nothing is handed back."""
+    n, stride = 600_000, 640
+    bufs = [eng.alloc(n * stride), eng.alloc(n * 8), eng.alloc(n * 4), eng.alloc(n), eng.alloc(n * 4)]
+    d_q, d_ee, d_ns, d_pass, d_len = bufs
+    try:
+        eng.synth_fill(d_q, n, stride, min_len=50, max_len=600, d_len=d_len, seed=33, profile=1)
+        hq, hl = d_q.download(np.uint8, n * stride).reshape(n, stride), d_len.download(np.int32, n)
+        ee, ns, ps, need = oracle.filter_batch(hq, lens=hl, threads=16)
+        c = eng.filter_device(d_q, n, stride, d_len=d_len, d_ee=d_ee, d_ns=d_ns, d_pass=d_pass)
+        path = eng.last_path()
+        shortest3 = int(((hl[need >= 3] + 15) // 16).min())
+        assert path["narrow_rows"] == 3 and 15 <= path["narrow_split"] < shortest3 and path["n_fallback"] == 0, (path, shortest3)
+        assert same(d_ee.download(np.float64, n), ee) and np.array_equal(d_pass.download(np.uint8, n), ps) and c.n_pass == int(ps.sum())
+    finally:
+        for b in bufs:
+            b.free()
+
+
 def paired_golden_contigs(eng):
     recs = []
     for kind in ("good", "bad"):

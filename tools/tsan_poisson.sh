@@ -25,7 +25,7 @@ void mpb_launch_count(const uint8_t *, int64_t, const MpbWorkspace &, hipStream_
 void mpb_launch_synth(uint8_t *, int64_t, int64_t, int32_t, int32_t, int32_t, int32_t *, uint64_t, int64_t, hipStream_t, int) STUB
 void mpb_launch_narrow(int, const uint8_t *, int64_t, int64_t, int32_t, const MpbDevParams &, const MpbWorkspace &, double *, int32_t *, uint8_t *, int32_t *, int, hipStream_t) STUB
 void mpb_launch_sample(const uint8_t *, int64_t, int64_t, int32_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, int, hipStream_t) STUB
-void mpb_launch_narrow_ragged(int, const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, double *, int32_t *, uint8_t *, int32_t *, int, hipStream_t) STUB
+void mpb_launch_narrow_ragged(int, int, const uint8_t *, int64_t, int64_t, const int32_t *, const MpbDevParams &, const MpbWorkspace &, double *, int32_t *, uint8_t *, int32_t *, int, hipStream_t) STUB
 void mpb_launch_serve(const MpbServeBox &, const double2 *, uint32_t, uint32_t, hipStream_t) STUB
 int mpb_narrow_lds_bytes() { return 1 << 15; }
 int mpb_narrow_rs_lds_bytes() { return 1 << 15; }
