@@ -508,6 +508,9 @@ int mpb_last_algorithmic_cells(mpb_ctx *ctx, int64_t *cells);
  *   sampled      1 when this call drew a sample (sample_hist is then its histogram: [0] reads with a lower-case 'n', [r] reads
  *                that need r rows (r = 1..14), [15] more), 0 when it reused the previous decision
  *   n_fallback   reads the narrow pass handed to the sorted pipeline
+ *   narrow_split ragged batches, narrow_rows >= 3 ("mixed rows"): how many rows a read of a given quality needs grows with its length,
+ *                and the pass walks its reads sorted by length -- groups whose longest read has at most this many 16-byte chunks
+ *                (safely fewer than the shortest sampled read that needed narrow_rows rows) ran with narrow_rows - 1 rows; 0: none
  */
 typedef struct mpb_path_info {
     int32_t narrow_rows;
