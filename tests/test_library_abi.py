@@ -123,6 +123,16 @@ def test_no_fma_in_exact_dp_kernel():
         ndiv = b.count("v_div_fixup_f64")
         assert ndiv >= 1 and b.count("v_fma_f64") == 3 * ndiv and b.count("v_fmac_f64") == 2 * ndiv, b.split(":")[0]
         assert "scratch_" not in b, b.split(":")[0]                         # no spills
+    # round 6: the narrow pass of ragged batches, pure (R rows everywhere) and with mixed rows (short groups with a row less): the same rule;
+    # the forced four waves per SIMD cost R >= 3 a few spilled per-group values (scratch), never a fused cell
+    ragged = [b for b in bodies if re.match(r"_ZN\S*k_narrow_rgILi\d", b)]
+    assert sorted(re.search(r"k_narrow_rgILi(\d)ELi(\d)E", b).groups() for b in ragged) == [("2", "2"), ("3", "2"), ("3", "3"), ("4", "3"), ("4", "4")]
+    for b in ragged:
+        ndiv = b.count("v_div_fixup_f64")
+        assert ndiv >= 1 and b.count("v_fma_f64") == 3 * ndiv and b.count("v_fmac_f64") == 2 * ndiv, b.split(":")[0]
+    for name in ("k_narrow_rgILi2ELi2E", "k_narrow_rgILi3ELi2E", "k_narrow_rgILi3ELi3E", "k_narrow_rgILi4ELi3E", "k_narrow_rgILi4ELi4E"):
+        m = re.search(r"\.amdhsa_kernel _ZN\S*%s\S*\n(?:.*\n)*?\s*\.amdhsa_next_free_vgpr (\d+)" % name, text)
+        assert m and int(m.group(1)) <= 128, (name, m and m.group(1))
     # k_dp / k_small / k_serve call the class bodies: all three keep the 128-register budget (4 waves per SIMD) -- a caller
     # declared with looser launch bounds would let the shared bodies grow and halve k_dp's occupancy
     for name in ("k_dpILb0ELb0E", "k_smallILb0E", "k_serve", "k_narrow_rsILi2ELb1E", "k_narrow_rsILi3ELb1E", "k_narrow_rsILi4ELb1E", "k_narrow_rsILi2ELb0E"):
