@@ -558,32 +558,53 @@ __global__ __launch_bounds__(256) void k_scan(int32_t *__restrict__ blockhist, i
     if (tid == 255) tb->kcount[c] = s_part[255];
 }
 
-__global__ void k_tables(MpbTables *__restrict__ tb, int nb, int32_t *__restrict__ ovf_count,
-                         unsigned long long *__restrict__ pass_count)
+// One block of 512 threads (round 6: the single-thread form walked the 512 keys of a ragged batch through dependent global loads and
+// stores, 38 us; this one 5): the keys' counts come into LDS, a thread per class sums its bins and lays out its keys, one thread
+// lays out the classes (perm slots padded to 64, tiles widest class first).
+__global__ __launch_bounds__(512) void k_tables(MpbTables *__restrict__ tb, int nb, int32_t *__restrict__ ovf_count,
+                                                unsigned long long *__restrict__ pass_count)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int base = 0;
-    for (int c = 0; c < MPB_NCLS; c++) {
-        tb->perm_base[c] = base;
+    __shared__ int s_k[MPB_SKEYS], s_cnt[MPB_NCLS], s_base[MPB_NCLS + 1], s_tile[MPB_NCLS + 1];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < MPB_NCLS * nb; k += 512) s_k[k] = tb->kcount[k];
+    __syncthreads();
+    if (tid < MPB_NCLS) {
         int cnt = 0;
-        for (int b = 0; b < nb; b++) {                   // a class's keys are consecutive, shortest reads first
-            tb->key_base[c * nb + b] = base + cnt;
-            cnt += tb->kcount[c * nb + b];
+        for (int b = 0; b < nb; b++) cnt += s_k[tid * nb + b];
+        s_cnt[tid] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int base = 0;
+        for (int c = 0; c < MPB_NCLS; c++) { s_base[c] = base; base += (s_cnt[c] + 63) & ~63; }
+        s_base[MPB_NCLS] = base;
+        int t = 0;
+        for (int c = MPB_NCLS - 1; c >= 0; c--) {        // widest (most expensive) tiles first
+            const int rpt = 64 / c_classes[c].G;
+            s_tile[c] = t;
+            t += (s_cnt[c] + rpt - 1) / rpt;
         }
-        tb->count[c] = cnt;
-        base += (cnt + 63) & ~63;
+        s_tile[MPB_NCLS] = t;
     }
-    tb->perm_base[MPB_NCLS] = base;
-    int t = 0;
-    for (int c = MPB_NCLS - 1; c >= 0; c--) {        // widest (most expensive) tiles first
-        const int rpt = 64 / c_classes[c].G;
-        tb->tile_start[c] = t;
-        t += (tb->count[c] + rpt - 1) / rpt;
+    __syncthreads();
+    if (tid < MPB_NCLS) {
+        const int c = tid;
+        tb->perm_base[c] = s_base[c];
+        tb->count[c] = s_cnt[c];
+        tb->tile_start[c] = s_tile[c];
+        int run = s_base[c];
+        for (int b = 0; b < nb; b++) {                   // a class's keys are consecutive, shortest reads first
+            tb->key_base[c * nb + b] = run;
+            run += s_k[c * nb + b];
+        }
     }
-    tb->tile_start[MPB_NCLS] = t;
-    tb->total_tiles = t;
-    *ovf_count = 0;
-    *pass_count = 0ull;
+    if (tid == 0) {
+        tb->perm_base[MPB_NCLS] = s_base[MPB_NCLS];
+        tb->tile_start[MPB_NCLS] = s_tile[MPB_NCLS];
+        tb->total_tiles = s_tile[MPB_NCLS];
+        *ovf_count = 0;
+        *pass_count = 0ull;
+    }
 }
 
 // overflow pass: every listed read goes to one class `wc`
@@ -2880,7 +2901,7 @@ void mpb_launch_scan(int64_t n, const int32_t *len, const MpbWorkspace &ws, hipS
 {
     const int nb = len ? MPB_LEN_BINS : 1;
     hipLaunchKernelGGL(k_scan, dim3(MPB_NCLS * nb), dim3(256), 0, s, ws.blockhist, pre_blocks(n), ws.tables);
-    hipLaunchKernelGGL(k_tables, dim3(1), dim3(64), 0, s, ws.tables, nb, ws.ovf_count, ws.pass_count);
+    hipLaunchKernelGGL(k_tables, dim3(1), dim3(512), 0, s, ws.tables, nb, ws.ovf_count, ws.pass_count);
 }
 
 void mpb_launch_scatter(int64_t n, const int32_t *len, const int32_t *ns, const MpbDevParams &prm, const MpbWorkspace &ws,
