@@ -1318,7 +1318,11 @@ static int filter_host_pipeline(mpb_ctx *c, const uint8_t *q, int64_t n, int64_t
             mpb_launch_lambda(d_q, m, row_stride, len ? d_len : nullptr, fixed_len, c->ws.lut, d_ee, d_ns, c->ws.ovf_count, c->stream);
             rc = hipGetLastError() == hipSuccess ? MPB_OK : fail(MPB_E_HIP, "k_lambda launch failed");
         } else {
-            rc = mpb_filter_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, params, d_ee, d_ns, d_pass, nullptr);
+            // (the chunks always take the sorted pipeline: the narrow pass synchronises on its count of handed-back reads, which would
+            // stall the three-stream overlap of a path that is bound by the link anyway)
+            mpb_filter_params chunk_prm = *params;
+            chunk_prm.flags = (chunk_prm.flags & ~((15u << 8) | (255u << 12))) | MPB_FLAG_NO_NARROW;
+            rc = mpb_filter_device(c, d_q, m, row_stride, len ? d_len : nullptr, fixed_len, &chunk_prm, d_ee, d_ns, d_pass, nullptr);
         }
         if (rc) { drain_pipeline(c); return rc; }
         e = hipEventRecord(sl.k_done, c->stream);

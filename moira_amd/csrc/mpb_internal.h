@@ -212,7 +212,7 @@ int mpb_narrow_rs_lds_bytes();
 // predicted row budgets of `n_sample` reads spread over the batch -> ws.nar_sample (zeroed here)
 void mpb_launch_sample(const uint8_t *q, int64_t n, int64_t stride, int32_t fixed_len, const int32_t *len, const MpbDevParams &prm,
                        const MpbWorkspace &ws, int n_sample, hipStream_t s);
-// the narrow pass of a RAGGED batch (k_rag_sort, k_rag_plan, k_narrow_rg): rows of up to MPB_RG_MAX_STRIDE bytes
+// the narrow pass of a RAGGED batch (k_rag_sort, k_rag_scan, k_narrow_rg): rows of up to MPB_RG_MAX_STRIDE bytes
 #define MPB_RG_MAX_STRIDE 4096
 // split_chunks > 0 (rows0 >= 3): groups whose longest read has at most that many 16-byte chunks run with rows0 - 1 rows
 void mpb_launch_narrow_ragged(int rows0, int split_chunks, const uint8_t *q, int64_t n, int64_t stride, const int32_t *len,
