@@ -841,6 +841,9 @@ static int filter_device_narrow(mpb_ctx *c, int rows0, int split, const uint8_t 
     const bool forced = ((params->flags >> 8) & 15u) != 0;
     // a pass that hands back far more than its sample can have promised: look again next time
     if (!forced && m > n / 2) c->nar_choice.valid = false;
+    // mixed rows whose cut was too bold (reads of the short groups needed the row they did not get: the sample's shortest such read
+    // was not the batch's): the next calls of this shape run without a cut
+    if (!forced && split > 0 && m > n / 512) c->nar_choice.split = 0;
     int32_t novf = 0;
     if (m > 0) {
         // The reads handed back go through the sorted pipeline WHERE THEY LIE (round 6: the prepass and the scatter walk the list,
