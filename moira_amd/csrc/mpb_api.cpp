@@ -106,6 +106,7 @@ struct mpb_ctx {
     struct NarrowChoice {                // the last decision, reused while the batches keep their shape (it steers speed only)
         bool valid = false; int64_t n = 0, stride = 0; int32_t fixed_len = 0; double alpha = 0; uint32_t flags = 0;
         int rows0 = 0; int split = 0; int calls = 0;
+        double expect_back = 0;          // share of the sample (by weight) that needs more rows than rows0 or holds an 'n'
     } nar_choice;
     mpb_path_info last_path{};
     // ---- the per-read entry's resident server (round 5; k_serve with ONE mailbox entry, see serve_one) ----
@@ -811,6 +812,11 @@ static int narrow_choose(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_
         }
     }
     ch.split = *split;
+    {
+        double back = c->pin_words[16];
+        for (int r = *rows0 + 1; r < MPB_NAR_BUCKETS; r++) back += c->pin_words[16 + r];
+        ch.expect_back = weight > 0 ? back / weight : 0.0;
+    }
     ch.valid = true; ch.n = n; ch.stride = row_stride; ch.fixed_len = fixed_len; ch.alpha = params->alpha; ch.flags = params->flags;
     ch.rows0 = *rows0; ch.calls = 0;
     return MPB_OK;
@@ -841,9 +847,10 @@ static int filter_device_narrow(mpb_ctx *c, int rows0, int split, const uint8_t 
     const bool forced = ((params->flags >> 8) & 15u) != 0;
     // a pass that hands back far more than its sample can have promised: look again next time
     if (!forced && m > n / 2) c->nar_choice.valid = false;
-    // mixed rows whose cut was too bold (reads of the short groups needed the row they did not get: the sample's shortest such read
-    // was not the batch's): the next calls of this shape run without a cut
-    if (!forced && split > 0 && m > n / 512) c->nar_choice.split = 0;
+    // mixed rows whose cut was too bold (reads of the short groups needed the row they did not get -- the sample's shortest such read
+    // was not the batch's -- so that clearly more came back than the sample's own share of unfinished reads): the next calls of this
+    // shape run without a cut
+    if (!forced && split > 0 && (double)m > (1.5 * c->nar_choice.expect_back + 0.002) * (double)n) c->nar_choice.split = 0;
     int32_t novf = 0;
     if (m > 0) {
         // The reads handed back go through the sorted pipeline WHERE THEY LIE (round 6: the prepass and the scatter walk the list,
