@@ -183,3 +183,65 @@ def test_the_python2_form_of_the_dropin(oracle):
     st = broker.stats(name)
     assert st is not None and st["served"] >= 51
     broker.shutdown(name)
+
+
+def test_a_direct_slot_cannot_pick_the_kernels_modes(oracle):
+    """in direct serving the resident kernel reads a request's 64 bytes of parameters from the CLIENT-writable slot; the
+    broker thread's checks do not cover that path.  The wave takes only alpha's threshold and the prediction constants from them:
+    forged opt-in flags, an ambiguity mode, a limit change nothing (the answer is the honest call's, bit for bit), and a threshold
+    outside (0, 1) is answered "ask the host" (pass = 2), never obeyed."""
+    import ctypes as C
+    import struct
+    from moira_amd import broker
+    name = "gputestforge_%d" % os.getpid()
+    cl = broker.client(0, name=name, idle_exit=5.0)
+    try:
+        rng = np.random.default_rng(5)
+        s = "".join("ACGT"[int(v)] for v in rng.integers(0, 4, 300))
+        s = s[:50] + "N" + s[51:]                                        # an 'N': forged ambiguity modes would show in ee / pass
+        q = [int(v) for v in rng.integers(20, 41, 300)]
+        want = oracle.ee_rowwise(s, q, 0.005)[:2]
+        assert cl.calculate_errors_PB(s, q, 0.005) == want              # the kernel is up, the slot holds an honest request
+
+        class Handle(C.Structure):                                       # the client handle starts with the Mapping {base, bytes}, then the slot index
+            _fields_ = [("base", C.c_void_p), ("bytes", C.c_size_t), ("slot", C.c_int)]
+        hd = Handle.from_address(cl.h.value)
+        raw = (C.c_char * hd.bytes).from_address(hd.base)
+        n_slots, slot_bytes = (int(v) for v in np.frombuffer(raw, np.int32, 2, 8))
+        so = hd.bytes - n_slots * slot_bytes + hd.slot * slot_bytes
+        door = np.frombuffer(raw, np.uint64, 1, so + 320)
+        done = np.frombuffer(raw, np.uint32, 1, so + 384)
+        d_ns = np.frombuffer(raw, np.int32, 1, so + 388)
+        d_ee = np.frombuffer(raw, np.float64, 1, so + 392)
+        d_pass = np.frombuffer(raw, np.uint8, 1, so + 400)
+        prm = np.frombuffer(raw, np.uint8, 64, so + 448)
+        honest = bytes(prm)
+        thr, uncert, maxerr, z, zq, clow, mode, flags = struct.unpack_from("<dddfffiI", honest, 0)
+        assert abs(thr - 0.995) < 1e-12 and flags == 0
+        if int(door[0]) == 0 or int(done[0]) != int(door[0]) & 0xffffffff:
+            pytest.skip("the broker is not serving the slots directly on this box (registration refused): nothing to forge")
+
+        def forged_call(blob):
+            prm[:] = np.frombuffer(blob, np.uint8)
+            tok = (int(door[0]) & 0xffffffff) + 1
+            door[0] = (300 << 32) | tok                                  # the row of the honest call still lies in the slot
+            t0 = time.time()
+            while int(done[0]) != tok and time.time() - t0 < 10:
+                time.sleep(0.0005)
+            assert int(done[0]) == tok
+            return float(d_ee[0]), int(d_ns[0]), int(d_pass[0])
+        # every opt-in flag, "disallow", a tiny uncert, a maxerrors: none of it may show
+        blob = bytearray(honest)
+        struct.pack_into("<dd", blob, 8, 1e-9, 1e-9)
+        struct.pack_into("<iI", blob, 36, 2, 0xffffffff)
+        ee, ns_, ps = forged_call(bytes(blob))
+        assert (ee, ns_) == want and ps != 2
+        for bad_thr in (2.0, 0.0, -1.0, float("nan")):
+            blob = bytearray(honest)
+            struct.pack_into("<d", blob, 0, bad_thr)
+            assert forged_call(bytes(blob))[2] == 2                      # handed to the host, which checks alpha
+        prm[:] = np.frombuffer(honest, np.uint8)
+        assert cl.calculate_errors_PB(s, q, 0.005) == want              # the client's own next call: its token follows the forged ones
+    finally:
+        cl.close()
+        broker.shutdown(name)
