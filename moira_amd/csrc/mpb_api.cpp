@@ -804,10 +804,11 @@ static int narrow_choose(mpb_ctx *c, const uint8_t *d_q, int64_t n, int64_t row_
     *rows0 = narrow_rows_from_sample(c->pin_words + 16, weight);
     if (d_len && *rows0 >= 3) {
         // mixed rows: the shortest sampled read that needs rows0 rows has `need` chunks; groups safely below it take a row less
-        // (a tenth of margin, at least one chunk; not worth a second code path below four chunks)
+        // (a sixteenth of margin and a chunk -- a cut that turns out too bold is dropped after the call that shows it, below; not
+        // worth a second code path below four chunks)
         const int need = c->pin_words[16 + MPB_NAR_BUCKETS + (*rows0 - 3)];
         if (need > 0 && need < (1 << 20)) {
-            const int cut = need - 1 - need / 10;
+            const int cut = need - 1 - need / 16;
             if (cut >= 4) *split = cut > 255 ? 255 : cut;
         }
     }
