@@ -32,6 +32,13 @@ VARIANTS = {
     # k_narrow_rs (rows of a multiple of 64 bytes): the two halves of a panel as CHAINED runs -- half 0's run looks up the first
     # eight bases of half 1 in its tail, half 1's run starts without waiting for the LDS.  Bit-exact; a unified diff.
     "rs_chained_halves": "patches/rs_chained_halves.diff",
+    # k_narrow_rg without the planned cut (k_rag_scan, rg_first_group, the groups' costs): claim k = position 63 - k / nwin of window
+    # k % nwin (every window's longest groups first), wave gw takes one claim of every stripe of W, odd stripes with the waves in
+    # reverse; list slots and counts per GROUP, compacted in group order.  Bit-exact; a unified diff.  (profiles/r06_narrow_variants.txt
+    # section 10: within 1.5 % of the planned cut either way -- a SIMD's four waves share its FP64 pipe, so a wave that ends early
+    # gives its cycles to the others and the 9 % spread of the waves' ranges never shows.  One atomic claim per group instead: 1.10 ms,
+    # a single address takes about 70 M atomics a second.)
+    "rg_striped_claims": "patches/rg_striped_claims.diff",
     # k_narrow_rg: when a group is armed, every lane asks for one dword of line c8 (c8 >= 1) of each of the eight rows its load
     # instructions cover -- the rows' later lines are requested from DRAM together with their first, and wait in the L2 / the
     # Infinity Cache for the panel that needs them.  Results unchanged (the dwords are never looked at).
