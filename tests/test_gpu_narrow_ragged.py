@@ -1,4 +1,4 @@
-"""The narrow pass on RAGGED batches (round 6: k_rag_sort, k_rag_plan, k_narrow_rg; include/moira_pb.h mpb_path_info): one padded
+"""The narrow pass on RAGGED batches (round 6: k_rag_sort, k_rag_scan, k_narrow_rg; include/moira_pb.h mpb_path_info): one padded
 matrix + int32 len[], as the reference's paired mode produces them (moira/moira.py:789-801 -> make_contig, :1376-1558).
 Whichever pass computes a read -- the narrow pass in its length-sorted order, or the sorted pipeline on the sub-batch it hands
 back -- the result must be the reference's bit for bit (moira/bernoullimodule.c:152-166,219-251; the per-read limit

@@ -1,5 +1,5 @@
 """Step time of ragged resident batches through mpb_filter_device: the library's own choice, the narrow pass forced with 2 / 3 / 4
-rows (k_rag_sort + k_rag_plan + k_narrow_rg) and the sorted pipeline, with the per-kernel split (HIP events) and the share of
+rows (k_rag_sort + k_rag_scan + k_narrow_rg) and the sorted pipeline, with the per-kernel split (HIP events) and the share of
 the 8 TB/s roof at B = sum(len + 17) algorithmic bytes.
 
     python tools/ragged_rate.py [--reads 5000000] [--only hq|contigs|config5]
