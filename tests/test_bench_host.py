@@ -252,3 +252,65 @@ def test_masked_share_reproduces_a_hand_made_tiling():
     # class 160: bins 100 -> 1, 280..310 -> 4: order [100, 300, 280, 290 | 310]: tiles of 4
     assert issued == 2 * 64 * (100 + 100) + 160 * 4 * (300 + 310)
     assert abs(per_class[2] - (1 - 2 * 6410 / (2 * 64 * 200))) < 1e-12
+
+
+def _write_counter_csv(path, rows):
+    import csv
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Correlation_Id", "Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+        for r in rows:
+            w.writerow(r)
+
+
+def test_live_counter_csvs_become_bytes_per_launch(tmp_path):
+    """what bench.py does with the CSVs of its own rocprofv3 --pmc child passes -- counters averaged over a kernel's
+    dispatches, reads = 32 / 64 / 128-byte requests x their sizes, writes = 64-byte requests x 64 + the others x 32
+    (MI355X_MICROARCH.md, HBM)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_extras as X
+    dp = "void (anonymous namespace)::k_dp<false, false>(DpArgs)"
+    rs = "void (anonymous namespace)::k_narrow_rs<2, true>(unsigned char const*, long)"
+    rd_rows, wr_rows, sq_rows = [], [], []
+    for d, (r32, r64, r128, wr, wr64) in enumerate([(100, 10, 1000, 300, 200), (300, 30, 3000, 500, 400)]):
+        for name, val in (("TCC_EA0_RDREQ_sum", r32 + r64 + r128), ("TCC_EA0_RDREQ_32B_sum", r32), ("TCC_EA0_RDREQ_64B_sum", r64),
+                          ("TCC_EA0_RDREQ_128B_sum", r128)):
+            rd_rows.append([d, d, dp, name, val, 1000, 4000])
+        for name, val in (("TCC_EA0_WRREQ_sum", wr), ("TCC_EA0_WRREQ_64B_sum", wr64)):
+            wr_rows.append([d, d, dp, name, val, 1000, 4000])
+        for name, val in (("SQ_INSTS_VALU", 512 * 2000), ("GRBM_GUI_ACTIVE", 8 * 4000)):
+            sq_rows.append([d, d, dp, name, val, 0, 2000])                     # 2 us: 4000 cycles = 2 GHz
+    rd_rows.append([9, 9, rs, "TCC_EA0_RDREQ_128B_sum", 7, 0, 10])
+    rd_rows.append([9, 9, "some_other_kernel(int)", "TCC_EA0_RDREQ_128B_sum", 1, 0, 10])
+    _write_counter_csv(str(tmp_path / "tccrd" / "host" / "1_counter_collection.csv"), rd_rows)
+    _write_counter_csv(str(tmp_path / "tccwr" / "host" / "2_counter_collection.csv"), wr_rows)
+    _write_counter_csv(str(tmp_path / "sq" / "host" / "3_counter_collection.csv"), sq_rows)
+    k = X.parse_pmc_csvs(str(tmp_path))
+    assert set(k) == {"k_dp<false, false>", "k_narrow_rs<2, true>", "some_other_kernel"}
+    v = k["k_dp<false, false>"]
+    assert v["TCC_EA0_RDREQ_128B_sum"] == 2000 and v["duration_us_tccrd"] == 3.0 and v["duration_us_sq"] == 2.0
+    rd, wr = X.pmc_bytes(v)
+    assert rd == 32 * 200 + 64 * 20 + 128 * 2000
+    assert wr == 64 * 300 + 32 * (400 - 300)
+    assert X.pmc_bytes(k["k_narrow_rs<2, true>"]) == (128 * 7, None)           # no write pass seen for it: None, never a guess
+
+
+def test_a_failing_counter_pass_is_an_error_entry_not_an_exception(monkeypatch, tmp_path):
+    """Any failure of the live passes leaves {'error': ...}: bench.py then keeps the committed profiles/ values and says so
+    (`traffic_source`)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_extras as X
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/sh\necho 'no counters today' >&2\nexit 3\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ.get("PATH", ""))
+    r = X.pmc_live(1000, 300, 1, 320, deadline_s=20.0)
+    assert set(r) == {"error"} and "exit code 3" in r["error"] and "no counters today" in r["error"]
+    slow = tmp_path / "slow"
+    slow.mkdir()
+    (slow / "rocprofv3").write_text("#!/bin/sh\nsleep 30\n")
+    (slow / "rocprofv3").chmod(0o755)
+    monkeypatch.setenv("PATH", str(slow) + os.pathsep + os.environ.get("PATH", ""))
+    r = X.pmc_live(1000, 300, 1, 320, deadline_s=6.0)
+    assert set(r) == {"error"} and "deadline" in r["error"]
